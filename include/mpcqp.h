@@ -1,0 +1,181 @@
+/*
+ * mpcqp.h -- C-ABI of the MI355X-native batched LinMPC step (condense + QP solve).
+ *
+ * Drop-in boundary for the LinMPC `moveinput!` hot path of JuliaControl/ModelPredictiveControl.jl
+ * v2.11.0 (citations are relative to /root/reference).  The reference has no FFI of its own for
+ * this path: the seam is the `optim::JuMP.GenericModel` field (src/controller/linmpc.jl:14,245)
+ * driven by five JuMP calls -- set_normalized_rhs (src/controller/transcription.jl:845),
+ * set_objective_coefficient (src/controller/execute.jl:513), set_start_value
+ * (src/controller/transcription.jl:1005), optimize! (src/controller/execute.jl:472) and value
+ * (:502).  This library replaces, for a batch of B independent controllers of identical
+ * dimensions:
+ *
+ *     mpcqp_set_model    <->  init_predmat   src/controller/transcription.jl:115-194   (kernel K1)
+ *     mpcqp_set_weights  <->  init_quadprog  src/controller/construct.jl:837-845       (kernel K2)
+ *     mpcqp_set_bounds   <->  setconstraint! src/controller/construct.jl:324-559 (bound vectors,
+ *                             softness columns, Inf = absent row: transcription.jl:692-700)
+ *     mpcqp_step         <->  initpred! + linconstraint! + optim_objective! + getinput!
+ *                             src/controller/execute.jl:247-277, transcription.jl:811-848,
+ *                             execute.jl:466-505, execute.jl:536-546                   (kernel K3)
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every array is float64 unless stated.
+ *   - batch layout: problem-major, COLUMN-major inside a problem, i.e. exactly a Julia
+ *     Array{Float64,3} of size (rows, cols, B) / Array{Float64,2} of size (n, B) passed as
+ *     Ptr{Float64} with zero copy.
+ *   - all signals are DEVIATION variables (operating points already subtracted), as the
+ *     reference stores them (con.U0min = umin - Uop, src/controller/construct.jl:359).
+ *   - +-Inf in a bound means "row absent" (the i_b rule).  A NULL bound pointer means the whole
+ *     group is absent; a NULL softness pointer means the reference defaults (0 for u and Δu,
+ *     1 for y and x̂end, src/controller/construct.jl:909-913).
+ *   - host entry points (`*_host` suffix omitted) take HOST pointers and are synchronous, like
+ *     `moveinput!`; the `_device` twins take DEVICE pointers of the handle's GPU, enqueue on the
+ *     given hipStream_t (passed as void*) and return immediately -- this is what a resident
+ *     closed loop (and bench.py) uses.
+ *   - return value: 0 = ok, negative = API misuse (mirrors the DimensionMismatch/ArgumentError
+ *     of validate_args, src/controller/construct.jl:702-710).  Nothing throws across the ABI.
+ *   - per-problem solver outcome in status[]: see MPCQP_STATUS_*; on MPCQP_STATUS_ERROR the
+ *     returned Z̃ is the shifted warm start (src/controller/execute.jl:499-500).
+ *   - a handle is NOT thread-safe (neither is a LinMPC: its buffers are mutated in place,
+ *     src/controller/construct.jl:4-16); distinct handles are independent.
+ */
+#ifndef MPCQP_H
+#define MPCQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpcqp_handle_s* mpcqp_handle;
+
+/* error codes (return values) */
+#define MPCQP_OK                 0
+#define MPCQP_ERR_NULL          -1   /* required pointer is NULL                              */
+#define MPCQP_ERR_DIMS          -2   /* inconsistent dimensions (DimensionMismatch)           */
+#define MPCQP_ERR_ARG           -3   /* illegal value (ArgumentError)                         */
+#define MPCQP_ERR_UNSUPPORTED   -4   /* legal in the reference, not built here (see DESIGN)   */
+#define MPCQP_ERR_ORDER         -5   /* call order: model/weights/bounds before step          */
+#define MPCQP_ERR_DEVICE        -6   /* HIP runtime error (mpcqp_last_hip_error for detail)   */
+#define MPCQP_ERR_NOMEM         -7
+
+/* per-problem solver status, cf. issolved/iserror src/general.jl:52-61 */
+#define MPCQP_STATUS_OPTIMAL          0
+#define MPCQP_STATUS_ITERATION_LIMIT  1   /* solution kept (@warn branch, execute.jl:491-496)  */
+#define MPCQP_STATUS_ERROR            2   /* infeasible / numerical: warm start returned       */
+
+/* flags of mpcqp_dims.flags */
+#define MPCQP_FLAG_RY_CONSTANT   (1u << 0)  /* Ry is (ny,B): ry held over Hp, like R̂y=repeat(ry,Hp) */
+#define MPCQP_FLAG_COLD_START    (1u << 1)  /* ignore Ztilde on input: warm start = 0              */
+#define MPCQP_FLAG_KEEP_QP       (1u << 2)  /* keep q̃ and F of the last step for mpcqp_get         */
+
+typedef struct {
+    int32_t  batch;     /* B: number of independent controllers                              */
+    int32_t  nxhat;     /* augmented states nx̂ (estimator/construct.jl:305-323)               */
+    int32_t  nu, ny, nd;
+    int32_t  Hp;        /* prediction horizon                                                 */
+    int32_t  Hc;        /* number of free moves = length(nb) (construct.jl:629-660)           */
+    const int32_t* nb;  /* [Hc] move-blocking lengths, sum == Hp; NULL = [1,..,1,Hp-Hc+1]     */
+    int32_t  neps;      /* 1 iff Cwt is finite (slack variable ϵ present, construct.jl:903)   */
+    int32_t  device;    /* HIP device ordinal                                                 */
+    uint32_t flags;     /* MPCQP_FLAG_*                                                       */
+    int32_t  max_iter;  /* interior-point iteration cap, 0 = default (60)                     */
+    double   gap_tol;   /* absolute mean complementarity target, 0 = default (1e-12)          */
+    double   res_tol;   /* relative primal/dual residual target, 0 = default (1e-9)           */
+    double   dual_reg;  /* dual proximal regularisation δ, 0 = default (1e-12)                */
+} mpcqp_dims;
+
+/* sizes derived from dims (for allocating caller-side arrays) */
+typedef struct {
+    int32_t nZ;      /* nu*Hc + neps  (decision vector Z̃ = [ΔU; ϵ])                         */
+    int32_t nDU;     /* nu*Hc                                                                */
+    int32_t nU;      /* nu*Hp                                                                */
+    int32_t nY;      /* ny*Hp                                                                */
+    int32_t nD;      /* nd*Hp                                                                */
+} mpcqp_sizes;
+
+const char* mpcqp_version(void);
+const char* mpcqp_strerror(int code);
+const char* mpcqp_last_hip_error(void);
+
+int mpcqp_create(const mpcqp_dims* dims, mpcqp_handle* out);
+int mpcqp_destroy(mpcqp_handle h);
+int mpcqp_get_sizes(mpcqp_handle h, mpcqp_sizes* out);
+
+/* Augmented model of every controller (estim.Â, B̂u, Ĉ, B̂d, D̂d, f̂op - x̂op;
+ * src/controller/transcription.jl:118,190).  Ahat (nx̂,nx̂,B), Bu (nx̂,nu,B), C (ny,nx̂,B),
+ * Bd (nx̂,nd,B) / Dd (ny,nd,B) (NULL iff nd == 0), fop_minus_xop (nx̂,B) or NULL (= 0).
+ * Runs K1 (prediction tables) and, when weights are already set, K2 (Hessian) -- this is also
+ * the `setmodel!` path (src/controller/execute.jl:684-790).                                  */
+int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const double* C,
+                    const double* Bd, const double* Dd, const double* fop_minus_xop);
+
+/* Diagonal weights: Mdiag (nY,B), Ndiag (nDU,B), Ldiag (nU,B), Cwt (B) (ignored when neps == 0).
+ * (`Diagonal(repeat(Mwt,Hp))` etc., src/controller/linmpc.jl:236-238.)  Runs K2 when the model
+ * is set.  Dense M_Hp/N_Hc/L_Hp: MPCQP_ERR_UNSUPPORTED path, not in this ABI yet.            */
+int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
+                      const double* Ldiag, const double* Cwt);
+
+/* Bounds (deviation values) and softness (ECR) vectors; shapes (nU,B), (nDU,B), (nY,B), (nx̂,B).
+ * Field order follows ControllerConstraint (src/controller/construct.jl:126-199).            */
+typedef struct {
+    const double *U0min, *U0max;       /* (nU,B)  */
+    const double *DUmin, *DUmax;       /* (nDU,B) */
+    const double *Y0min, *Y0max;       /* (nY,B)  */
+    const double *x0min, *x0max;       /* (nx̂,B)  terminal */
+    const double *C_umin, *C_umax;     /* (nU,B)  softness, NULL = 0 */
+    const double *C_dumin, *C_dumax;   /* (nDU,B) NULL = 0 */
+    const double *C_ymin, *C_ymax;     /* (nY,B)  NULL = 1 */
+    const double *c_x0min, *c_x0max;   /* (nx̂,B)  NULL = 1 */
+} mpcqp_bounds;
+int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bounds);
+
+/* One control period for the whole batch (== B calls of moveinput!, execute.jl:59-80).
+ *   xhat0  (nx̂,B)  estim.x̂0                       lastu0 (nu,B)  u(k-1) - uop
+ *   Ry     (nY,B) or (ny,B) with MPCQP_FLAG_RY_CONSTANT: R̂y - Yop (deviation setpoints)
+ *   Ru     (nU,B) R̂u - Uop, or NULL (= 0, the default R̂u = Uop)
+ *   d0     (nd,B), Dhat0 (nD,B): measured disturbance and its preview (NULL iff nd == 0)
+ *   Ztilde (nZ,B) in: previous optimum (shifted inside, transcription.jl:997-1007);
+ *                 out: optimum (or the shifted warm start when status == ERROR)
+ *   u0     (nu,B) out: u(k) - uop = Z̃[1:nu] + lastu0 (execute.jl:536-546)
+ *   status (B) int32, iters (B) int32 (NULL allowed for iters)
+ *   Yhat0  (nY,B) optional out: Ŷ0 = Ẽ Z̃ + F (predict!, transcription.jl:1136-1145); NULL ok
+ */
+int mpcqp_step(mpcqp_handle h, const double* xhat0, const double* lastu0, const double* Ry,
+               const double* Ru, const double* d0, const double* Dhat0, double* Ztilde,
+               double* u0, int32_t* status, int32_t* iters, double* Yhat0);
+
+/* Same with DEVICE pointers on the handle's GPU, asynchronous on `stream` (a hipStream_t). */
+int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
+                      const double* Ry, const double* Ru, const double* d0, const double* Dhat0,
+                      double* Ztilde, double* u0, int32_t* status, int32_t* iters,
+                      double* Yhat0, void* stream);
+
+/* Re-run K1+K2 on the resident model/weights (timing of the setmodel! path). */
+int mpcqp_recondense_device(mpcqp_handle h, void* stream);
+
+/* Read back condensed quantities for parity tests / getinfo (host pointers).
+ *   HESSIAN  H̃ (nZ,nZ,B)                       construct.jl:837-845
+ *   STEPRESP Σ_m = Ĉ S(m) B̂u (ny,nu,Hp,B)       transcription.jl:134-139 (E is block-Toeplitz in it)
+ *   KMAT     K (nY,nx̂,B)                        transcription.jl:143-147
+ *   BVEC     B (nY,B)                           transcription.jl:184-192
+ *   QTILDE   q̃ (nZ,B), FVEC F (nY,B) of the last step (needs MPCQP_FLAG_KEEP_QP)
+ */
+#define MPCQP_GET_HESSIAN   1
+#define MPCQP_GET_STEPRESP  2
+#define MPCQP_GET_KMAT      3
+#define MPCQP_GET_BVEC      4
+#define MPCQP_GET_QTILDE    5
+#define MPCQP_GET_FVEC      6
+int mpcqp_get(mpcqp_handle h, int which, double* out);
+
+/* Device time of the kernels of the last step / recondense on this handle, measured with HIP
+ * events on the stream they ran on (milliseconds; < 0 if not available).                     */
+double mpcqp_last_step_ms(mpcqp_handle h);
+double mpcqp_last_condense_ms(mpcqp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCQP_H */

@@ -1,0 +1,477 @@
+"""Host-side mirror of the reference's LinMPC interface over the C-ABI of include/mpcqp.h.
+
+Two layers:
+
+* `Handle` -- 1:1 ctypes binding of the C entry points (what a Julia `ccall` shim binds, see
+  INTEGRATION.md).  Works with host (NumPy) pointers or raw device pointers.
+* `BatchLinMPC` -- B logical `LinMPC` controllers of identical dimensions with the reference's
+  vocabulary: constructor keywords of `LinMPC(estim; Hp, Hc, Mwt, Nwt, Lwt, Cwt)`
+  (/root/reference/src/controller/linmpc.jl:288-316), `setconstraint!` keywords
+  (src/controller/construct.jl:324-350), `moveinput!` arguments (src/controller/execute.jl:59-70),
+  `getinfo` keys (src/controller/execute.jl:145-198), and the same error behaviour
+  (DimensionMismatch -> ValueError, ArgumentError -> ValueError, status policy of
+  src/controller/execute.jl:482-503).
+
+There is no CPU fallback: the shared library is the HIP build and every compute call needs a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libmpcqp.so")
+
+# flags / codes of include/mpcqp.h
+FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP = 1, 2, 4
+STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
+GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC = 1, 2, 3, 4, 5, 6
+EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
+           "mpcqp_destroy", "mpcqp_get_sizes", "mpcqp_set_model", "mpcqp_set_weights",
+           "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_recondense_device",
+           "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class Dims(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("nxhat", C.c_int32), ("nu", C.c_int32), ("ny", C.c_int32),
+                ("nd", C.c_int32), ("Hp", C.c_int32), ("Hc", C.c_int32), ("nb", _ip),
+                ("neps", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("max_iter", C.c_int32), ("gap_tol", C.c_double), ("res_tol", C.c_double),
+                ("dual_reg", C.c_double)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("nZ", "nDU", "nU", "nY", "nD")]
+
+
+BOUND_FIELDS = ("U0min", "U0max", "DUmin", "DUmax", "Y0min", "Y0max", "x0min", "x0max",
+                "C_umin", "C_umax", "C_dumin", "C_dumax", "C_ymin", "C_ymax", "c_x0min", "c_x0max")
+
+
+class Bounds(C.Structure):
+    _fields_ = [(k, _dp) for k in BOUND_FIELDS]
+
+
+class MpcqpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load (once) the HIP shared library.  `path` is for tests only."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension is not built (run `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` or `make -C modelpredictivecontrol.jl_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.mpcqp_version.restype = C.c_char_p
+    lib.mpcqp_strerror.restype = C.c_char_p
+    lib.mpcqp_strerror.argtypes = [C.c_int]
+    lib.mpcqp_last_hip_error.restype = C.c_char_p
+    lib.mpcqp_create.argtypes = [C.POINTER(Dims), C.POINTER(C.c_void_p)]
+    lib.mpcqp_destroy.argtypes = [C.c_void_p]
+    lib.mpcqp_get_sizes.argtypes = [C.c_void_p, C.POINTER(Sizes)]
+    lib.mpcqp_set_model.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.mpcqp_set_weights.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    lib.mpcqp_set_bounds.argtypes = [C.c_void_p, C.POINTER(Bounds)]
+    lib.mpcqp_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
+    lib.mpcqp_step_device.argtypes = [C.c_void_p] + [C.c_void_p] * 12
+    lib.mpcqp_recondense_device.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpcqp_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.mpcqp_last_step_ms.restype = C.c_double
+    lib.mpcqp_last_step_ms.argtypes = [C.c_void_p]
+    lib.mpcqp_last_condense_ms.restype = C.c_double
+    lib.mpcqp_last_condense_ms.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _chk(lib, rc):
+    if rc != 0:
+        msg = lib.mpcqp_strerror(rc).decode()
+        if rc == -6:
+            msg += ": " + lib.mpcqp_last_hip_error().decode()
+        raise MpcqpError(f"mpcqp error {rc}: {msg}")
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def colmajor(M):
+    """(B, rows, cols) logical -> the ABI's column-major-per-problem buffer (= Julia (rows,cols,B))."""
+    return _f64(np.asarray(M, float).transpose(0, 2, 1))
+
+
+class Handle:
+    """Thin binding of the C-ABI; array arguments are already in ABI layout."""
+
+    def __init__(self, B, nxhat, nu, ny, nd, Hp, Hc, nb=None, neps=1, device=0, flags=0,
+                 max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0, lib=None):
+        self.lib = lib or load_library()
+        self._nb = None
+        d = Dims(batch=B, nxhat=nxhat, nu=nu, ny=ny, nd=nd, Hp=Hp, Hc=Hc, neps=neps, device=device,
+                 flags=flags, max_iter=max_iter, gap_tol=gap_tol, res_tol=res_tol, dual_reg=dual_reg)
+        if nb is not None:
+            self._nb = (C.c_int32 * len(nb))(*[int(v) for v in nb])
+            d.nb = C.cast(self._nb, _ip)
+        self.h = C.c_void_p()
+        _chk(self.lib, self.lib.mpcqp_create(C.byref(d), C.byref(self.h)))
+        s = Sizes()
+        _chk(self.lib, self.lib.mpcqp_get_sizes(self.h, C.byref(s)))
+        self.B, self.nxhat, self.nu, self.ny, self.nd, self.Hp, self.Hc = B, nxhat, nu, ny, nd, Hp, Hc
+        self.nZ, self.nDU, self.nU, self.nY, self.nD = s.nZ, s.nDU, s.nU, s.nY, s.nD
+        self.flags = flags
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.mpcqp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_model(self, Ahat, Bu, Cm, Bd=None, Dd=None, dop=None):
+        args = [None if a is None else _f64(a) for a in (Ahat, Bu, Cm, Bd, Dd, dop)]
+        _chk(self.lib, self.lib.mpcqp_set_model(self.h, *[_ptr(a) for a in args]))
+
+    def set_weights(self, Mdiag, Ndiag, Ldiag, Cwt=None):
+        args = [None if a is None else _f64(a) for a in (Mdiag, Ndiag, Ldiag, Cwt)]
+        _chk(self.lib, self.lib.mpcqp_set_weights(self.h, *[_ptr(a) for a in args]))
+
+    def set_bounds(self, **kw):
+        b = Bounds()
+        keep = []
+        for k in BOUND_FIELDS:
+            v = kw.get(k)
+            if v is not None:
+                a = _f64(v)
+                keep.append(a)
+                setattr(b, k, a.ctypes.data_as(_dp))
+        _chk(self.lib, self.lib.mpcqp_set_bounds(self.h, C.byref(b)))
+
+    def step(self, xhat0, lastu0, Ry, Z, Ru=None, d0=None, Dhat0=None, want_Yhat=False):
+        """Host-pointer step.  Z (B,nZ) is updated in place.  Returns u0, status, iters[, Yhat0]."""
+        B = self.B
+        x, lu, ry = _f64(xhat0), _f64(lastu0), _f64(Ry)
+        ru = None if Ru is None else _f64(Ru)
+        dd0 = None if d0 is None else _f64(d0)
+        dh = None if Dhat0 is None else _f64(Dhat0)
+        nry = self.ny if (self.flags & FLAG_RY_CONSTANT) else self.nY
+        if x.size != B * self.nxhat or lu.size != B * self.nu or ry.size != B * nry or Z.size != B * self.nZ:
+            raise ValueError("DimensionMismatch in step arguments")
+        assert Z.dtype == np.float64 and Z.flags.c_contiguous
+        u0 = np.empty((B, self.nu))
+        status = np.empty(B, np.int32)
+        iters = np.empty(B, np.int32)
+        yh = np.empty((B, self.nY)) if want_Yhat else None
+        _chk(self.lib, self.lib.mpcqp_step(self.h, _ptr(x), _ptr(lu), _ptr(ry), _ptr(ru), _ptr(dd0),
+                                           _ptr(dh), _ptr(Z), _ptr(u0), _ptr(status), _ptr(iters),
+                                           _ptr(yh)))
+        return (u0, status, iters, yh) if want_Yhat else (u0, status, iters)
+
+    def step_device(self, xhat0, lastu0, Ry, Z, u0, status, iters=0, Ru=0, d0=0, Dhat0=0, Yhat0=0,
+                    stream=0):
+        """All arguments are integer device addresses (0 = NULL); asynchronous on `stream`."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _chk(self.lib, self.lib.mpcqp_step_device(self.h, v(xhat0), v(lastu0), v(Ry), v(Ru), v(d0),
+                                                  v(Dhat0), v(Z), v(u0), v(status), v(iters),
+                                                  v(Yhat0), v(stream)))
+
+    def recondense_device(self, stream=0):
+        _chk(self.lib, self.lib.mpcqp_recondense_device(self.h, C.c_void_p(int(stream)) if stream else None))
+
+    def get(self, which):
+        shape = {GET_HESSIAN: (self.B, self.nZ, self.nZ), GET_STEPRESP: (self.B, self.Hp, self.nu, self.ny),
+                 GET_KMAT: (self.B, self.nxhat, self.nY), GET_BVEC: (self.B, self.nY),
+                 GET_QTILDE: (self.B, self.nZ), GET_FVEC: (self.B, self.nY)}[which]
+        out = np.empty(shape)
+        _chk(self.lib, self.lib.mpcqp_get(self.h, which, _ptr(out)))
+        return out
+
+    def last_step_ms(self):
+        return self.lib.mpcqp_last_step_ms(self.h)
+
+    def last_condense_ms(self):
+        return self.lib.mpcqp_last_condense_ms(self.h)
+
+
+def move_blocking(Hp, Hc):
+    """`move_blocking` (src/controller/construct.jl:629-660): integer or vector Hc -> nb."""
+    if np.isscalar(Hc):
+        Hc = int(Hc)
+        nb = [1] * Hc
+        if Hc > 0:
+            nb[-1] = Hp - Hc + 1
+        return nb
+    nb = [int(v) for v in Hc]
+    if not all(v > 0 for v in nb):
+        raise ValueError("Move blocking vector must be strictly positive integers.")
+    if sum(nb) < Hp:
+        nb = nb + [Hp - sum(nb)]
+    elif sum(nb) > Hp:
+        keep = int(np.argmax(np.cumsum(nb) >= Hp)) + 1
+        nb = nb[:keep]
+        if sum(nb) > Hp:
+            nb[-1] = Hp - sum(nb[:-1])
+    return nb
+
+
+class BatchLinMPC:
+    """B independent `LinMPC` controllers on augmented models (Â, B̂u, Ĉ, B̂d, D̂d), one GPU.
+
+    Array arguments carry a leading batch axis: Ahat (B,nx̂,nx̂), Bhu (B,nx̂,nu), Chat (B,ny,nx̂),
+    Bhd (B,nx̂,nd), Dhd (B,ny,nd).  Weights are per channel (ny / nu values, shared or (B,·)),
+    repeated over the horizons like `Diagonal(repeat(Mwt, Hp))`; Cwt scalar or (B,).
+    """
+
+    def __init__(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None, *, Hp, Hc=2, Mwt=None, Nwt=None,
+                 Lwt=None, Cwt=1e5, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
+                 cold_start=False, keep_qp=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
+                 lib=None):
+        Ahat, Bhu, Chat = (np.asarray(a, float) for a in (Ahat, Bhu, Chat))
+        if Ahat.ndim != 3 or Bhu.ndim != 3 or Chat.ndim != 3:
+            raise ValueError("model matrices need a leading batch axis")
+        B, nxh, nu = Bhu.shape
+        ny = Chat.shape[1]
+        nd = 0 if Bhd is None else np.asarray(Bhd).shape[2]
+        if Ahat.shape != (B, nxh, nxh) or Chat.shape != (B, ny, nxh):
+            raise ValueError("DimensionMismatch between Ahat, Bhu, Chat")
+        Hp = int(Hp)
+        if Hp < 1:
+            raise ValueError("Prediction horizon Hp should be ≥ 1")
+        nb = move_blocking(Hp, Hc)
+        Hc = len(nb)
+        if Hc < 1:
+            raise ValueError("Control horizon Hc should be ≥ 1")
+        if Hc > Hp:
+            raise ValueError("Control horizon Hc should be ≤ prediction horizon Hp")
+        cw = np.broadcast_to(np.asarray(Cwt, float), (B,)).copy()
+        if np.any(cw < 0):
+            raise ValueError("Cwt weight should be ≥ 0")
+        if np.isinf(cw).any() and not np.isinf(cw).all():
+            raise ValueError("Cwt must be finite for all controllers of a batch, or Inf for all")
+        self.neps = 0 if np.isinf(cw).all() else 1
+        self.B, self.nxh, self.nu, self.ny, self.nd, self.Hp, self.Hc, self.nb = B, nxh, nu, ny, nd, Hp, Hc, nb
+        flags = FLAG_RY_CONSTANT * 0 | (FLAG_COLD_START if cold_start else 0) | (FLAG_KEEP_QP if keep_qp else 0)
+        self.hd = Handle(B, nxh, nu, ny, nd, Hp, Hc, nb=nb, neps=self.neps, device=device, flags=flags,
+                         max_iter=max_iter, gap_tol=gap_tol, res_tol=res_tol, dual_reg=dual_reg, lib=lib)
+        self.nZ, self.nDU, self.nU, self.nY = self.hd.nZ, self.hd.nDU, self.hd.nU, self.hd.nY
+        vec = lambda v, n: np.zeros((B, n)) if v is None else np.broadcast_to(np.asarray(v, float), (B, n)).copy()
+        self.uop, self.yop, self.dop = vec(uop, nu), vec(yop, ny), vec(dop, nd)
+        self.xhop, self.fhop = vec(xhop, nxh), vec(fhop, nxh)
+        self.Uop, self.Yop, self.Dop = np.tile(self.uop, Hp), np.tile(self.yop, Hp), np.tile(self.dop, Hp)
+        self.Cwt = cw
+        self.setmodel(Ahat, Bhu, Chat, Bhd, Dhd)
+        self.setweights(Mwt, Nwt, Lwt)
+        # default constraints: none (src/controller/construct.jl:887-913)
+        self._b = {k: None for k in BOUND_FIELDS}
+        self.Z = np.zeros((B, self.nZ))            # mpc.Z̃ (previous optimum)
+        self.lastu0 = np.zeros((B, nu))            # mpc.lastu0
+        self.solved_once = False
+        self.status = np.zeros(B, np.int32)
+        self.iters = np.zeros(B, np.int32)
+
+    # -- model / weights ---------------------------------------------------------------------
+    def setmodel(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None):
+        """`setmodel!` re-condensation path (src/controller/execute.jl:684-790): K1 (+K2)."""
+        dopv = self.fhop - self.xhop
+        self.hd.set_model(colmajor(Ahat), colmajor(Bhu), colmajor(Chat),
+                          None if self.nd == 0 else colmajor(Bhd),
+                          None if self.nd == 0 else colmajor(Dhd),
+                          dopv if np.any(dopv != 0) else None)
+
+    def setweights(self, Mwt=None, Nwt=None, Lwt=None):
+        """Defaults of src/general.jl:3-6 (Mwt=1, Nwt=0.1, Lwt=0)."""
+        B, Hp, Hc = self.B, self.Hp, self.Hc
+        w = lambda v, n, dflt: (np.full((B, n), dflt) if v is None
+                                else np.broadcast_to(np.asarray(v, float), (B, n)).copy())
+        M, N, L = w(Mwt, self.ny, 1.0), w(Nwt, self.nu, 0.1), w(Lwt, self.nu, 0.0)
+        for name, a in (("Mwt", M), ("Nwt", N), ("Lwt", L)):
+            if np.any(a < 0):
+                raise ValueError(f"{name} values should be nonnegative")
+        self.Mwt, self.Nwt, self.Lwt = M, N, L
+        self.hd.set_weights(np.tile(M, Hp), np.tile(N, Hc), np.tile(L, Hp),
+                            self.Cwt if self.neps else None)
+
+    # -- constraints --------------------------------------------------------------------------
+    def setconstraint(self, *, umin=None, umax=None, Δumin=None, Δumax=None, ymin=None, ymax=None,
+                      x̂min=None, x̂max=None, Umin=None, Umax=None, ΔUmin=None, ΔUmax=None,
+                      Ymin=None, Ymax=None, c_umin=None, c_umax=None, c_Δumin=None, c_Δumax=None,
+                      c_ymin=None, c_ymax=None, c_x̂min=None, c_x̂max=None,
+                      Deltaumin=None, Deltaumax=None, xhatmin=None, xhatmax=None,
+                      DeltaUmin=None, DeltaUmax=None, c_Deltaumin=None, c_Deltaumax=None,
+                      c_xhatmin=None, c_xhatmax=None):
+        """`setconstraint!` (src/controller/construct.jl:324-559), nw = 0 subset, with the ASCII
+        aliases.  Bounds are engineering values (operating points are subtracted here, :356-435);
+        per-channel vectors (n,) or (B,n) are repeated over the horizon, capitalised keywords take
+        the whole horizon."""
+        Δumin = Deltaumin if Δumin is None else Δumin
+        Δumax = Deltaumax if Δumax is None else Δumax
+        x̂min = xhatmin if x̂min is None else x̂min
+        x̂max = xhatmax if x̂max is None else x̂max
+        ΔUmin = DeltaUmin if ΔUmin is None else ΔUmin
+        ΔUmax = DeltaUmax if ΔUmax is None else ΔUmax
+        c_Δumin = c_Deltaumin if c_Δumin is None else c_Δumin
+        c_Δumax = c_Deltaumax if c_Δumax is None else c_Δumax
+        c_x̂min = c_xhatmin if c_x̂min is None else c_x̂min
+        c_x̂max = c_xhatmax if c_x̂max is None else c_x̂max
+        B, Hp, Hc, nu, ny, nxh = self.B, self.Hp, self.Hc, self.nu, self.ny, self.nxh
+
+        def rep(v, n, reps, name):
+            a = np.asarray(v, float)
+            if a.shape not in ((n,), (B, n)):
+                raise ValueError(f"{name} size must be ({n},)")
+            return np.tile(np.broadcast_to(a, (B, n)), reps)
+
+        def full(v, n, name):
+            a = np.asarray(v, float)
+            if a.shape not in ((n,), (B, n)):
+                raise ValueError(f"{name} size must be ({n},)")
+            return np.broadcast_to(a, (B, n)).copy()
+
+        new = dict(self._b)
+        if Umin is not None:
+            new["U0min"] = full(Umin, nu * Hp, "Umin") - self.Uop
+        elif umin is not None:
+            new["U0min"] = rep(umin, nu, Hp, "umin") - self.Uop
+        if Umax is not None:
+            new["U0max"] = full(Umax, nu * Hp, "Umax") - self.Uop
+        elif umax is not None:
+            new["U0max"] = rep(umax, nu, Hp, "umax") - self.Uop
+        if ΔUmin is not None:
+            new["DUmin"] = full(ΔUmin, nu * Hc, "ΔUmin")
+        elif Δumin is not None:
+            new["DUmin"] = rep(Δumin, nu, Hc, "Δumin")
+        if ΔUmax is not None:
+            new["DUmax"] = full(ΔUmax, nu * Hc, "ΔUmax")
+        elif Δumax is not None:
+            new["DUmax"] = rep(Δumax, nu, Hc, "Δumax")
+        if Ymin is not None:
+            new["Y0min"] = full(Ymin, ny * Hp, "Ymin") - self.Yop
+        elif ymin is not None:
+            new["Y0min"] = rep(ymin, ny, Hp, "ymin") - self.Yop
+        if Ymax is not None:
+            new["Y0max"] = full(Ymax, ny * Hp, "Ymax") - self.Yop
+        elif ymax is not None:
+            new["Y0max"] = rep(ymax, ny, Hp, "ymax") - self.Yop
+        if x̂min is not None:
+            new["x0min"] = full(x̂min, nxh, "x̂min") - self.xhop
+        if x̂max is not None:
+            new["x0max"] = full(x̂max, nxh, "x̂max") - self.xhop
+        ecr = dict(C_umin=(c_umin, nu, Hp), C_umax=(c_umax, nu, Hp), C_dumin=(c_Δumin, nu, Hc),
+                   C_dumax=(c_Δumax, nu, Hc), C_ymin=(c_ymin, ny, Hp), C_ymax=(c_ymax, ny, Hp),
+                   c_x0min=(c_x̂min, nxh, 1), c_x0max=(c_x̂max, nxh, 1))
+        if any(v[0] is not None for v in ecr.values()):
+            if self.neps != 1:
+                raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
+            if self.solved_once:
+                raise RuntimeError("Cannot set softness parameters after calling moveinput!")
+        for k, (v, n, reps) in ecr.items():
+            if v is not None:
+                a = rep(v, n, reps, k)
+                if np.any(a < 0):
+                    raise ValueError(f"{k} weights should be non-negative")
+                new[k] = a
+        if self.solved_once:
+            # src/controller/construct.jl:541-551: the ±Inf pattern is frozen after the first solve
+            for k in BOUND_FIELDS[:8]:
+                old_inf = np.isinf(self._b[k]) if self._b[k] is not None else True
+                new_inf = np.isinf(new[k]) if new[k] is not None else True
+                if np.any(old_inf != new_inf):
+                    raise RuntimeError("Cannot modify ±Inf constraints after calling moveinput!")
+        self._b = new
+        self.hd.set_bounds(**{k: v for k, v in new.items() if v is not None})
+        return self
+
+    # -- per-step ---------------------------------------------------------------------------
+    def initstate(self, u):
+        """controller part of `initstate!` (src/controller/execute.jl:9-13)."""
+        self.Z[:] = 0.0
+        self.lastu0 = np.broadcast_to(np.asarray(u, float), (self.B, self.nu)) - self.uop
+
+    def moveinput(self, xhat0, ry=None, d=None, *, lastu=None, Dhat=None, Rhaty=None, Rhatu=None,
+                  want_info=False):
+        """`moveinput!` for the whole batch (src/controller/execute.jl:59-80).
+
+        xhat0 (B,nx̂) is `estim.x̂0` (deviation); ry (B,ny)/(ny,), d (B,nd), `lastu`, `Rhaty`
+        (B,ny*Hp), `Rhatu` (B,nu*Hp), `Dhat` (B,nd*Hp) are engineering values like the reference.
+        Returns u (B,nu)."""
+        B, Hp = self.B, self.Hp
+        xhat0 = np.asarray(xhat0, float)
+        if xhat0.shape != (B, self.nxh):
+            raise ValueError(f"xhat0 size must be ({B},{self.nxh})")
+        bc = lambda v, n, name: self._bc(v, n, name)
+        ry = self.yop if ry is None else bc(ry, self.ny, "ry")
+        Rhaty = np.tile(ry, Hp) if Rhaty is None else bc(Rhaty, self.nY, "R̂y")
+        Rhatu = None if Rhatu is None else bc(Rhatu, self.nU, "R̂u")
+        lastu0 = self.lastu0 if lastu is None else bc(lastu, self.nu, "lastu") - self.uop
+        d0 = Dh0 = None
+        if self.nd > 0:
+            d = bc(d, self.nd, "d")
+            Dhat = np.tile(d, Hp) if Dhat is None else bc(Dhat, self.nd * Hp, "D̂")
+            d0, Dh0 = d - self.dop, Dhat - self.Dop
+        elif d is not None and np.size(d) != 0:
+            raise ValueError("d size must be (0,)")
+        out = self.hd.step(xhat0, lastu0, Rhaty - self.Yop, self.Z,
+                           Ru=None if Rhatu is None else Rhatu - self.Uop, d0=d0, Dhat0=Dh0,
+                           want_Yhat=want_info)
+        u0, self.status, self.iters = out[0], out[1], out[2]
+        self._Yhat0 = out[3] if want_info else None
+        self._lastu0_prev = lastu0
+        self.solved_once = True
+        nerr = int(np.sum(self.status == STATUS_ERROR))
+        nwarn = int(np.sum(self.status == STATUS_ITERATION_LIMIT))
+        if nerr:      # @error branch, src/controller/execute.jl:484-489
+            warnings.warn(f"MPC terminated without solution: returning last solution shifted "
+                          f"({nerr} of {B} controllers)", RuntimeWarning)
+        if nwarn:     # @warn branch, :491-496
+            warnings.warn(f"MPC termination status not OPTIMAL: keeping solution anyway "
+                          f"({nwarn} of {B} controllers)", RuntimeWarning)
+        self.lastu0 = u0.copy()                       # getinput!: lastu0 <- u - uop
+        return u0 + self.uop
+
+    __call__ = moveinput
+
+    def _bc(self, v, n, name):
+        a = np.asarray(v, float)
+        if a.shape == (n,):
+            a = np.broadcast_to(a, (self.B, n))
+        if a.shape != (self.B, n):
+            raise ValueError(f"{name} size must be ({n},)")       # DimensionMismatch
+        return a
+
+    def getinfo(self):
+        """Subset of `getinfo` (src/controller/execute.jl:145-198): ΔU, ϵ, u, U, Ŷ (needs
+        `moveinput(..., want_info=True)` for Ŷ)."""
+        nu, Hc = self.nu, self.Hc
+        DU = self.Z[:, :self.nDU]
+        blk = np.repeat(np.arange(Hc), self.nb)
+        cum = np.cumsum(DU.reshape(self.B, Hc, nu), axis=1)
+        U0 = cum[:, blk, :].reshape(self.B, -1) + np.tile(self._lastu0_prev, self.Hp)
+        info = {"ΔU": DU.copy(), "ϵ": self.Z[:, -1].copy() if self.neps else np.zeros(self.B),
+                "u": self.lastu0 + self.uop, "U": U0 + self.Uop}
+        if self._Yhat0 is not None:
+            info["Ŷ"] = self._Yhat0 + self.Yop
+        return info

@@ -1,0 +1,931 @@
+// mpcqp_bodies.h -- bodies of the three kernels of the batched LinMPC step, one QP per
+// wavefront.  Written against a tiny "wave" interface W (lane id, wave barrier, wave
+// reductions) so that the very same source is compiled (a) by hipcc for gfx950, where W maps to
+// s_barrier / DPP-shuffles, and (b) by g++ for tests/emu, where 64 host threads play the lanes.
+// (b) is test infrastructure to debug index arithmetic without a GPU; the product library only
+// ever contains (a).
+//
+//   K1 predmat_body  <-> init_predmat(::LinModel, ::SingleShooting)
+//                        /root/reference/src/controller/transcription.jl:115-194
+//   K2 hessian_body  <-> init_quadprog            src/controller/construct.jl:837-845
+//   K3 step_body     <-> initpred!                src/controller/execute.jl:247-277
+//                        linconstraint!           src/controller/transcription.jl:811-848
+//                        set_warmstart_mpc!       src/controller/transcription.jl:997-1007
+//                        optim_objective!         src/controller/execute.jl:466-505  (JuMP/OSQP
+//                          replaced by a dual-regularised Mehrotra predictor-corrector IPM on
+//                          the normal equations, Cholesky in LDS)
+//                        getinput!                src/controller/execute.jl:536-546
+//
+// Nothing of size (rows of A) x nZ is ever formed: E is block-Toeplitz in the step-response
+// blocks Σ_m = Ĉ S(m) B̂u (transcription.jl:134-139,156-165), Pu is a held cumulative sum
+// (construct.jl:797-806), hard ΔU bounds are variable bounds (construct.jl:1217-1229).
+#pragma once
+#include <math.h>
+
+#include "mpcqp_types.h"
+
+namespace mpcqp {
+
+// ------------------------------------------------------------------------------------------
+// LDS carve-up of one problem (all doubles unless stated).  Same function on host (to size the
+// dynamic LDS) and device.
+// ------------------------------------------------------------------------------------------
+struct Carve {
+    int S, Phi, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT;
+    int h, s, lam, rp, gd, pp; // row arrays
+    int jl, blk;               // int tables (offset in doubles, storage as int)
+    int total;                 // doubles
+};
+
+MPCQP_HD inline Carve make_carve(const Dims& d) {
+    Carve c;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
+    c.S = take(d.Hp * d.ny * d.nu);
+    c.Phi = take(d.npk);
+    c.invd = take(d.nZ);
+    c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
+    c.zlo = take(d.nZ); c.zhi = take(d.nZ); c.gt = take(d.nZ); c.rd = take(d.nZ);
+    c.F = take(d.nY);
+    for (int p = 0; p < NPAIR; ++p) {
+        bool on = (d.gmask >> (2 * p)) & 3u;
+        // pair Y's tA doubles as the E*v scratch, so it always exists
+        c.tA[p] = take((on || p == P_Y) ? d.cnt[p] : 0);
+        c.tB[p] = take((on && p != P_BOX) ? d.cnt[p] : 0);
+    }
+    c.ucum = take(d.nDU);
+    c.exT = take(((d.gmask >> (2 * P_X)) & 3u) ? d.Hc * d.nxh * d.nu : 0);
+    int M = d.rowoff[NGROUP];
+    c.h = take(M); c.s = take(M); c.lam = take(M); c.rp = take(M); c.gd = take(M); c.pp = take(M);
+    c.jl = take((d.Hc + 2) / 2 + 1);
+    c.blk = take((d.Hp + 1) / 2 + 1);
+    c.total = o;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// condensed problem resident in LDS + structured products with E, Pu, ex̂
+// ------------------------------------------------------------------------------------------
+template <class W>
+struct Qp {
+    W& w;
+    const Dims& d;
+    const Model& m;
+    const int b;        // problem index
+    double* sm;         // LDS base
+    Carve c;
+    int *jl, *blk;
+    double *S, *Phi;
+
+    MPCQP_HD Qp(W& w_, const Dims& d_, const Model& m_, int b_, double* sm_)
+        : w(w_), d(d_), m(m_), b(b_), sm(sm_), c(make_carve(d_)) {
+        jl = reinterpret_cast<int*>(sm + c.jl);
+        blk = reinterpret_cast<int*>(sm + c.blk);
+        S = sm + c.S;
+        Phi = sm + c.Phi;
+    }
+
+    MPCQP_HD bool pair_on(int p) const { return (d.gmask >> (2 * p)) & 3u; }
+    MPCQP_HD bool group_on(int g) const { return (d.gmask >> g) & 1u; }
+
+    MPCQP_HD void load_tables() {
+        const int ns = d.Hp * d.ny * d.nu;
+        const double* g = m.Stab + (size_t)b * ns;
+        for (int i = w.lane; i < ns; i += WAVE) S[i] = g[i];
+        for (int i = w.lane; i <= d.Hc; i += WAVE) jl[i] = m.jl[i];
+        for (int i = w.lane; i < d.Hp; i += WAVE) blk[i] = m.blk[i];
+        if (pair_on(P_X)) {
+            const int ne = d.Hc * d.nxh * d.nu;
+            const double* e = m.exT + (size_t)b * ne;
+            for (int i = w.lane; i < ne; i += WAVE) sm[c.exT + i] = e[i];
+        }
+        w.sync();
+    }
+
+    // E[(t,a),(j,c)]  (block-Toeplitz accessor)
+    MPCQP_HD double Eat(int t, int a, int j, int cc) const {
+        int dt = t - jl[j];
+        return dt >= 0 ? S[(dt * d.ny + a) * d.nu + cc] : 0.0;
+    }
+
+    // out[r] = sum_k E[r,k] v[k]   (r < nY; v has >= nDU entries)
+    MPCQP_HD void E_apply(const double* v, double* out) {
+        const int ny = d.ny, nu = d.nu;
+        for (int r = w.lane; r < d.nY; r += WAVE) {
+            int t = r / ny, a = r - t * ny;
+            double acc = 0.0;
+            for (int j = 0; j < d.Hc && jl[j] <= t; ++j) {
+                const double* Sb = S + ((t - jl[j]) * ny + a) * nu;
+                const double* vj = v + j * nu;
+                for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * vj[cc];
+            }
+            out[r] = acc;
+        }
+    }
+
+    // out[k] += sum_r E[r,k] wv[r]   (k < nDU)
+    MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0) {
+        const int ny = d.ny, nu = d.nu;
+        for (int k = w.lane; k < d.nDU; k += WAVE) {
+            int j = k / nu, cc = k - j * nu;
+            double acc = 0.0;
+            for (int t = jl[j]; t < d.Hp; ++t) {
+                const double* Sb = S + ((t - jl[j]) * ny) * nu + cc;
+                const double* wt = wv + t * ny;
+                for (int a = 0; a < ny; ++a) acc += Sb[a * nu] * wt[a];
+            }
+            out[k] += scale * acc;
+        }
+    }
+
+    // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU)
+    MPCQP_HD void EtDE_add(const double* dd, double* P, double scale = 1.0) {
+        const int ny = d.ny, nu = d.nu, nDU = d.nDU;
+        const int ntri = nDU * (nDU + 1) / 2;
+        for (int idx = w.lane; idx < ntri; idx += WAVE) {
+            // idx -> (i, i') with i >= i'
+            int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+            while (i * (i + 1) / 2 > idx) --i;
+            while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+            int ip = idx - i * (i + 1) / 2;
+            int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
+            int t0 = jl[j], off2 = jl[j] - jl[j2];       // j >= j2  =>  jl[j] >= jl[j2]
+            double acc = 0.0;
+            for (int t = t0; t < d.Hp; ++t) {
+                const double* S1 = S + ((t - t0) * ny) * nu + cc;
+                const double* S2 = S + ((t - t0 + off2) * ny) * nu + c2;
+                const double* dt = dd + t * ny;
+                for (int a = 0; a < ny; ++a) acc += S1[a * nu] * dt[a] * S2[a * nu];
+            }
+            P[idx] += scale * acc;
+        }
+    }
+
+    // ex̂[i,(j,c)]
+    MPCQP_HD double Xat(int i, int k) const {
+        int j = k / d.nu, cc = k - j * d.nu;
+        return sm[c.exT + (j * d.nxh + i) * d.nu + cc];
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// K1: prediction tables of one problem.  LDS: see predmat_lds_doubles().
+// ------------------------------------------------------------------------------------------
+MPCQP_HD inline int predmat_lds_doubles(const Dims& d) {
+    int nx = d.nxh;
+    return nx * nx * 3 + nx * d.nu * 2 + d.ny * nx * 3 + nx * 2 + nx * (d.nd > 0 ? d.nd : 1) * 2 + 8;
+}
+
+template <class W>
+MPCQP_HD void predmat_body(W& w, const Dims& d, const Model& m, int b, double* sm, bool terminal) {
+    const int nx = d.nxh, nu = d.nu, ny = d.ny, nd = d.nd, Hp = d.Hp;
+    double* A = sm;                         // A[i + nx*k]
+    double* T0 = A + nx * nx;               // matrix power ping
+    double* T1 = T0 + nx * nx;              // pong
+    double* W0 = T1 + nx * nx;              // S(m) B̂u ping  W[i + nx*c]
+    double* W1 = W0 + nx * nu;
+    double* Cm = W1 + nx * nu;              // Ĉ  C[a + ny*k]
+    double* P0 = Cm + ny * nx;              // Ĉ Â^t ping  P[a + ny*k]
+    double* P1 = P0 + ny * nx;
+    double* v0 = P1 + ny * nx;              // S(t) dop ping
+    double* v1 = v0 + nx;
+    double* X0 = v1 + nx;                   // Â^m B̂d ping  X[i + nx*e]
+    double* X1 = X0 + nx * (nd > 0 ? nd : 1);
+    const double* gA = m.Ahat + (size_t)b * nx * nx;
+    const double* gB = m.Bu + (size_t)b * nx * nu;
+    const double* gC = m.C + (size_t)b * ny * nx;
+    for (int i = w.lane; i < nx * nx; i += WAVE) A[i] = gA[i];
+    for (int i = w.lane; i < nx * nu; i += WAVE) W0[i] = gB[i];
+    for (int i = w.lane; i < ny * nx; i += WAVE) Cm[i] = gC[i];
+    for (int i = w.lane; i < nx; i += WAVE) v0[i] = m.dop ? m.dop[(size_t)b * nx + i] : 0.0;
+    if (nd > 0)
+        for (int i = w.lane; i < nx * nd; i += WAVE) X0[i] = m.Bd[(size_t)b * nx * nd + i];
+    w.sync();
+    // P0 = Ĉ Â
+    for (int i = w.lane; i < ny * nx; i += WAVE) {
+        int a = i % ny, k = i / ny;
+        double acc = 0.0;
+        for (int l = 0; l < nx; ++l) acc += Cm[a + ny * l] * A[l + nx * k];
+        P0[i] = acc;
+    }
+    if (terminal)
+        for (int i = w.lane; i < nx * nx; i += WAVE) T0[i] = A[i];
+    w.sync();
+    double* Stab = m.Stab + (size_t)b * Hp * ny * nu;
+    double* Ktab = m.Ktab + (size_t)b * nx * d.nY;
+    double* Bvec = m.Bvec + (size_t)b * d.nY;
+    double* Gd = nd > 0 ? m.Gdtab + (size_t)b * Hp * ny * nd : nullptr;
+    for (int t = 0; t < Hp; ++t) {
+        // --- emit tables of step t -------------------------------------------------------
+        for (int i = w.lane; i < ny * nu; i += WAVE) {          // Σ_t = Ĉ W_t
+            int a = i / nu, cc = i - a * nu;
+            double acc = 0.0;
+            for (int l = 0; l < nx; ++l) acc += Cm[a + ny * l] * W0[l + nx * cc];
+            Stab[(t * ny + a) * nu + cc] = acc;
+        }
+        for (int i = w.lane; i < ny * nx; i += WAVE) {          // K block t = Ĉ Â^{t+1}
+            int a = i % ny, k = i / ny;
+            Ktab[(size_t)k * d.nY + t * ny + a] = P0[i];
+        }
+        for (int a = w.lane; a < ny; a += WAVE) {               // B block t = Ĉ S(t) dop
+            double acc = 0.0;
+            for (int l = 0; l < nx; ++l) acc += Cm[a + ny * l] * v0[l];
+            Bvec[t * ny + a] = acc;
+        }
+        if (nd > 0)
+            for (int i = w.lane; i < ny * nd; i += WAVE) {      // Ĉ Â^t B̂d
+                int a = i / nd, e = i - a * nd;
+                double acc = 0.0;
+                for (int l = 0; l < nx; ++l) acc += Cm[a + ny * l] * X0[l + nx * e];
+                Gd[(t * ny + a) * nd + e] = acc;
+            }
+        if (terminal) {
+            // ex̂ block j = S(Hp - j_j - 1) B̂u = W_t when t == Hp - j_j - 1
+            for (int j = 0; j < d.Hc; ++j)
+                if (t == Hp - m.jl[j] - 1) {
+                    double* ex = m.exT + ((size_t)b * d.Hc + j) * nx * nu;
+                    for (int i = w.lane; i < nx * nu; i += WAVE) {
+                        int r = i / nu, cc = i - r * nu;
+                        ex[i] = W0[r + nx * cc];
+                    }
+                }
+            if (nd > 0) {
+                double* Xd = m.Xdtab + ((size_t)b * Hp + t) * nx * nd;
+                for (int i = w.lane; i < nx * nd; i += WAVE) {
+                    int r = i / nd, e = i - r * nd;
+                    Xd[i] = X0[r + nx * e];
+                }
+            }
+            if (t == Hp - 1) {
+                for (int i = w.lane; i < nx; i += WAVE) m.bxv[(size_t)b * nx + i] = v0[i];
+                // T0 holds Â^{t+1} = Â^Hp
+                for (int i = w.lane; i < nx * nx; i += WAVE) m.kxT[(size_t)b * nx * nx + i] = T0[i];
+            }
+        }
+        if (t == Hp - 1) break;
+        // --- advance recursions ----------------------------------------------------------
+        for (int i = w.lane; i < nx * nu; i += WAVE) {          // W_{t+1} = Â W_t + B̂u
+            int r = i % nx, cc = i / nx;
+            double acc = gB[i];
+            for (int l = 0; l < nx; ++l) acc += A[r + nx * l] * W0[l + nx * cc];
+            W1[i] = acc;
+        }
+        for (int i = w.lane; i < ny * nx; i += WAVE) {          // P_{t+1} = P_t Â
+            int a = i % ny, k = i / ny;
+            double acc = 0.0;
+            for (int l = 0; l < nx; ++l) acc += P0[a + ny * l] * A[l + nx * k];
+            P1[i] = acc;
+        }
+        for (int r = w.lane; r < nx; r += WAVE) {               // v_{t+1} = Â v_t + dop
+            double acc = m.dop ? m.dop[(size_t)b * nx + r] : 0.0;
+            for (int l = 0; l < nx; ++l) acc += A[r + nx * l] * v0[l];
+            v1[r] = acc;
+        }
+        if (nd > 0)
+            for (int i = w.lane; i < nx * nd; i += WAVE) {      // X_{t+1} = Â X_t
+                int r = i % nx, e = i / nx;
+                double acc = 0.0;
+                for (int l = 0; l < nx; ++l) acc += A[r + nx * l] * X0[l + nx * e];
+                X1[i] = acc;
+            }
+        if (terminal)
+            for (int i = w.lane; i < nx * nx; i += WAVE) {      // T_{t+1} = T_t Â
+                int r = i % nx, k = i / nx;
+                double acc = 0.0;
+                for (int l = 0; l < nx; ++l) acc += T0[r + nx * l] * A[l + nx * k];
+                T1[i] = acc;
+            }
+        w.sync();
+        { double* t_ = W0; W0 = W1; W1 = t_; }
+        { double* t_ = P0; P0 = P1; P1 = t_; }
+        { double* t_ = v0; v0 = v1; v1 = t_; }
+        { double* t_ = X0; X0 = X1; X1 = t_; }
+        { double* t_ = T0; T0 = T1; T1 = t_; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: H̃ = 2(Ẽ'MẼ + P̃Δu'ÑP̃Δu + P̃u'LP̃u), diagonal weights, packed lower triangle.
+// ------------------------------------------------------------------------------------------
+template <class W>
+MPCQP_HD void hessian_body(W& w, const Dims& d, const Model& m, int b, double* sm) {
+    Qp<W> qp(w, d, m, b, sm);
+    qp.load_tables();
+    double* P = qp.Phi;
+    double* tY = sm + qp.c.tA[P_Y];
+    for (int i = w.lane; i < d.npk; i += WAVE) P[i] = 0.0;
+    for (int i = w.lane; i < d.nY; i += WAVE) tY[i] = m.Mdiag[(size_t)b * d.nY + i];
+    w.sync();
+    qp.EtDE_add(tY, P, 2.0);                                    // 2 E'ME
+    w.sync();
+    const int nu = d.nu;
+    // 2 Pu'L Pu: entry ((j,c),(j',c)) = sum_{t >= j_max(j,j')} L[t,c]   (construct.jl:797-806)
+    const double* L = m.Ldiag + (size_t)b * d.nU;
+    const int ntri = d.nDU * (d.nDU + 1) / 2;
+    for (int idx = w.lane; idx < ntri; idx += WAVE) {
+        int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > idx) --i;
+        while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+        int ip = idx - i * (i + 1) / 2;
+        int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
+        double acc = 0.0;
+        if (cc == c2)
+            for (int t = qp.jl[j]; t < d.Hp; ++t) acc += L[t * nu + cc];
+        if (i == ip) acc += m.Ndiag[(size_t)b * d.nDU + i];     // 2 N
+        P[idx] += 2.0 * acc;
+    }
+    if (d.neps && w.lane == 0) P[pk(d.nZ - 1, d.nZ - 1)] = 2.0 * m.Cwt[b];    // Ñ = blkdiag(N, C)
+    w.sync();
+    double* H = m.Hpk + (size_t)b * d.npk;
+    for (int i = w.lane; i < d.npk; i += WAVE) H[i] = P[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: one control period of one controller.
+// ------------------------------------------------------------------------------------------
+template <class W>
+struct Step {
+    Qp<W>& qp;
+    W& w;
+    const Dims& d;
+    const Model& m;
+    const int b;
+    double* sm;
+    const Carve& c;
+    double *z, *dz, *q, *zlo, *zhi, *gt, *rd, *F, *h, *s, *lam, *rp, *gd, *pp, *invd, *Phi;
+    int mact;           // number of finite rows
+    double nh;          // 1 + max |h|
+    double delta;
+
+    MPCQP_HD Step(Qp<W>& qp_)
+        : qp(qp_), w(qp_.w), d(qp_.d), m(qp_.m), b(qp_.b), sm(qp_.sm), c(qp_.c) {
+        z = sm + c.z; dz = sm + c.dz; q = sm + c.q; zlo = sm + c.zlo; zhi = sm + c.zhi;
+        gt = sm + c.gt; rd = sm + c.rd; F = sm + c.F;
+        h = sm + c.h; s = sm + c.s; lam = sm + c.lam; rp = sm + c.rp; gd = sm + c.gd; pp = sm + c.pp;
+        invd = sm + c.invd; Phi = qp.Phi;
+        delta = d.dual_reg;
+    }
+
+    // softness coefficient of local row k of group g (reference defaults when pointer null)
+    MPCQP_HD double soft(int g, int k) const {
+        if (!d.neps) return 0.0;
+        const double* p = nullptr;
+        double def = 0.0;
+        switch (g) {
+            case 2 * P_U: p = m.C_umin; break;
+            case 2 * P_U + 1: p = m.C_umax; break;
+            case 2 * P_DU: p = m.C_dumin; break;
+            case 2 * P_DU + 1: p = m.C_dumax; break;
+            case 2 * P_Y: p = m.C_ymin; def = 1.0; break;
+            case 2 * P_Y + 1: p = m.C_ymax; def = 1.0; break;
+            case 2 * P_X: p = m.c_x0min; def = 1.0; break;
+            case 2 * P_X + 1: p = m.c_x0max; def = 1.0; break;
+            default: return 0.0;
+        }
+        return p ? p[(size_t)b * d.cnt[g >> 1] + k] : def;
+    }
+
+    template <class Fn>
+    MPCQP_HD void for_rows(Fn fn) {     // fn(row, group, local)
+        for (int g = 0; g < NGROUP; ++g) {
+            if (!qp.group_on(g)) continue;
+            const int n = d.cnt[g >> 1], off = d.rowoff[g];
+            for (int k = w.lane; k < n; k += WAVE) fn(off + k, g, k);
+        }
+    }
+
+    // ---- free response, gradient, right-hand sides (initpred!, linconstraint!) -------------
+    MPCQP_HD void build(const StepIO& io) {
+        const int nx = d.nxh, nu = d.nu, ny = d.ny, nd = d.nd, nY = d.nY;
+        const double* x0 = io.xhat0 + (size_t)b * nx;
+        const double* lu = io.lastu0 + (size_t)b * nu;
+        const double* K = m.Ktab + (size_t)b * nx * nY;
+        const double* Bv = m.Bvec + (size_t)b * nY;
+        // F = B + K x̂0 + V lastu0 (+ G d0 + J D̂0)           execute.jl:249-255
+        for (int r = w.lane; r < nY; r += WAVE) {
+            int t = r / ny, a = r - t * ny;
+            double acc = Bv[r];
+            for (int k = 0; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
+            const double* Sb = qp.S + (t * ny + a) * nu;        // V block t = Σ_t
+            for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * lu[cc];
+            if (nd > 0) {
+                const double* Gd = m.Gdtab + (size_t)b * d.Hp * ny * nd;
+                const double* dd0 = io.d0 + (size_t)b * nd;
+                const double* Dh = io.Dhat0 + (size_t)b * d.nD;
+                const double* Dd = m.Dd + (size_t)b * ny * nd;   // (ny,nd) col-major
+                for (int e = 0; e < nd; ++e) {
+                    acc += Gd[(t * ny + a) * nd + e] * dd0[e];          // G block t = Ĉ Â^t B̂d
+                    acc += Dd[a + ny * e] * Dh[t * nd + e];             // J diagonal block = D̂d
+                    for (int j = 0; j < t; ++j)                         // J[t, j] = G block t-j-1
+                        acc += Gd[((t - j - 1) * ny + a) * nd + e] * Dh[j * nd + e];
+                }
+            }
+            F[r] = acc;
+        }
+        w.sync();
+        // q̃ = 2[(M Ẽ)'(F - R̂y) + (L P̃u)'(Tu lastu0 - R̂u)]   execute.jl:262-275 (deviation form)
+        double* tY = sm + c.tA[P_Y];
+        const double* Md = m.Mdiag + (size_t)b * nY;
+        const bool rconst = d.flags & 1u;
+        for (int r = w.lane; r < nY; r += WAVE) {
+            double ry = rconst ? io.Ry[(size_t)b * ny + (r % ny)] : io.Ry[(size_t)b * nY + r];
+            tY[r] = Md[r] * (F[r] - ry);
+        }
+        for (int k = w.lane; k < d.nZ; k += WAVE) q[k] = 0.0;
+        w.sync();
+        qp.Et_apply_add(tY, q, 2.0);
+        const double* Ld = m.Ldiag + (size_t)b * d.nU;
+        for (int k = w.lane; k < d.nDU; k += WAVE) {
+            int j = k / nu, cc = k - j * nu;
+            double acc = 0.0;
+            for (int t = qp.jl[j]; t < d.Hp; ++t) {
+                double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cc] : 0.0;
+                acc += Ld[t * nu + cc] * (lu[cc] - ru);
+            }
+            q[k] += 2.0 * acc;       // same lane wrote q[k] in Et_apply_add
+        }
+        // variable bounds (init_boxconstraint_mpc, construct.jl:1209-1234)
+        for (int k = w.lane; k < d.nZ; k += WAVE) {
+            double lo = -INFINITY, hi = INFINITY;
+            if (k < d.nDU) {
+                if (m.DUmin && (!d.neps || !m.C_dumin || m.C_dumin[(size_t)b * d.nDU + k] == 0.0))
+                    lo = m.DUmin[(size_t)b * d.nDU + k];
+                if (m.DUmax && (!d.neps || !m.C_dumax || m.C_dumax[(size_t)b * d.nDU + k] == 0.0))
+                    hi = m.DUmax[(size_t)b * d.nDU + k];
+            } else {
+                lo = 0.0;            // ϵ >= 0
+            }
+            zlo[k] = lo; zhi[k] = hi;
+        }
+        w.sync();
+        // terminal free response fx̂ = bx̂ + kx̂ x̂0 + vx̂ lastu0 (+ gx̂ d0 + jx̂ D̂0)  transcription.jl:815-821
+        double* fx = sm + c.tB[P_X];       // parked here until the rows are initialised
+        if (qp.pair_on(P_X)) {
+            const double* kx = m.kxT + (size_t)b * nx * nx;
+            const double* ex0 = sm + c.exT;          // block j=0 is vx̂ = S(Hp-1) B̂u (j_0 = 0)
+            for (int i = w.lane; i < nx; i += WAVE) {
+                double acc = m.bxv[(size_t)b * nx + i];
+                for (int k = 0; k < nx; ++k) acc += kx[i + nx * k] * x0[k];
+                for (int cc = 0; cc < nu; ++cc) acc += ex0[i * nu + cc] * lu[cc];
+                if (nd > 0) {
+                    const double* Xd = m.Xdtab + (size_t)b * d.Hp * nx * nd;
+                    const double* dd0 = io.d0 + (size_t)b * nd;
+                    const double* Dh = io.Dhat0 + (size_t)b * d.nD;
+                    for (int e = 0; e < nd; ++e) {
+                        acc += Xd[((d.Hp - 1) * nx + i) * nd + e] * dd0[e];       // gx̂ = Â^{Hp-1} B̂d
+                        for (int j = 1; j < d.Hp; ++j)                            // jx̂ block j
+                            acc += Xd[((d.Hp - j - 1) * nx + i) * nd + e] * Dh[(j - 1) * nd + e];
+                    }
+                }
+                fx[i] = acc;
+            }
+            w.sync();
+        }
+        // b vector, finite rows only (linconstraint!, transcription.jl:824-842 and i_b :692-700)
+        int cntl = 0;
+        double hmax = 0.0;
+        for_rows([&](int row, int g, int k) {
+            double bound = INFINITY;
+            size_t o = (size_t)b * d.cnt[g >> 1] + k;
+            switch (g) {
+                case 0: bound = -zlo[k]; break;
+                case 1: bound = zhi[k]; break;
+                case 2 * P_U: if (m.U0min) bound = -m.U0min[o] + lu[k % nu]; break;
+                case 2 * P_U + 1: if (m.U0max) bound = m.U0max[o] - lu[k % nu]; break;
+                case 2 * P_DU:
+                    if (m.DUmin && m.C_dumin && m.C_dumin[o] != 0.0) bound = -m.DUmin[o];
+                    break;
+                case 2 * P_DU + 1:
+                    if (m.DUmax && m.C_dumax && m.C_dumax[o] != 0.0) bound = m.DUmax[o];
+                    break;
+                case 2 * P_Y: if (m.Y0min) bound = -m.Y0min[o] + F[k]; break;
+                case 2 * P_Y + 1: if (m.Y0max) bound = m.Y0max[o] - F[k]; break;
+                case 2 * P_X: if (m.x0min) bound = -m.x0min[o] + fx[k]; break;
+                case 2 * P_X + 1: if (m.x0max) bound = m.x0max[o] - fx[k]; break;
+            }
+            const bool ok = fabs(bound) < BIG && bound == bound;
+            h[row] = ok ? bound : 2.0 * BIG;
+            s[row] = 1.0;
+            lam[row] = ok ? 1.0 : 0.0;
+            pp[row] = 0.0;
+            if (ok) { ++cntl; hmax = fmax(hmax, fabs(bound)); }
+        });
+        mact = w.isum(cntl);
+        nh = 1.0 + w.maxv(hmax);
+        w.sync();
+    }
+
+    MPCQP_HD bool fin(int row) const { return h[row] < BIG; }
+
+    // ---- out = G v  (v in LDS, nZ entries; out is a row array) --------------------------------
+    MPCQP_HD void apply_G(const double* v, double* out) {
+        const int nu = d.nu;
+        double* ucum = sm + c.ucum;
+        double* tY = sm + c.tA[P_Y];
+        double* tX = sm + c.tA[P_X];
+        if (qp.pair_on(P_U))
+            for (int k = w.lane; k < d.nDU; k += WAVE) {
+                int j = k / nu, cc = k - j * nu;
+                double acc = 0.0;
+                for (int jj = 0; jj <= j; ++jj) acc += v[jj * nu + cc];
+                ucum[k] = acc;
+            }
+        if (qp.pair_on(P_Y)) qp.E_apply(v, tY);
+        if (qp.pair_on(P_X))
+            for (int i = w.lane; i < d.nxh; i += WAVE) {
+                double acc = 0.0;
+                for (int k = 0; k < d.nDU; ++k) acc += qp.Xat(i, k) * v[k];
+                tX[i] = acc;
+            }
+        w.sync();
+        const double e = d.neps ? v[d.nZ - 1] : 0.0;
+        for_rows([&](int row, int g, int k) {
+            if (!fin(row)) { out[row] = 0.0; return; }
+            double prim;
+            switch (g >> 1) {
+                case P_BOX: prim = v[k]; break;
+                case P_U: prim = ucum[qp.blk[k / nu] * nu + (k % nu)]; break;
+                case P_DU: prim = v[k]; break;
+                case P_Y: prim = tY[k]; break;
+                default: prim = tX[k]; break;
+            }
+            out[row] = ((g & 1) ? prim : -prim) - soft(g, k) * e;
+        });
+        w.sync();
+    }
+
+    // ---- gt = G' wv, wv(row) given by functor (only called on finite rows) --------------------
+    template <class Fn>
+    MPCQP_HD void apply_Gt(Fn wv) {
+        const int nu = d.nu;
+        // per pair: tA[k] = w_max - w_min ; eps accumulates -(c_min w_min + c_max w_max)
+        double eacc = 0.0;
+        for (int p = 0; p < NPAIR; ++p) {
+            if (!qp.pair_on(p)) continue;
+            double* tA = sm + c.tA[p];
+            const int n = d.cnt[p];
+            const bool gmin = qp.group_on(2 * p), gmax = qp.group_on(2 * p + 1);
+            for (int k = w.lane; k < n; k += WAVE) {
+                double wmin = 0.0, wmax = 0.0;
+                if (gmin && fin(d.rowoff[2 * p] + k)) wmin = wv(d.rowoff[2 * p] + k);
+                if (gmax && fin(d.rowoff[2 * p + 1] + k)) wmax = wv(d.rowoff[2 * p + 1] + k);
+                tA[k] = wmax - wmin;
+                if (p != P_BOX && d.neps)
+                    eacc -= soft(2 * p, k) * wmin + soft(2 * p + 1, k) * wmax;
+            }
+        }
+        if (!qp.pair_on(P_Y))       // tA[P_Y] is always allocated (scratch) but must read as 0
+            for (int k = w.lane; k < d.nY; k += WAVE) sm[c.tA[P_Y] + k] = 0.0;
+        eacc = w.sum(eacc);
+        w.sync();
+        for (int k = w.lane; k < d.nZ; k += WAVE) {
+            double acc = 0.0;
+            if (qp.pair_on(P_BOX)) acc += sm[c.tA[P_BOX] + k];
+            if (k < d.nDU) {
+                if (qp.pair_on(P_DU)) acc += sm[c.tA[P_DU] + k];
+                if (qp.pair_on(P_U)) {
+                    int j = k / nu, cc = k - j * nu;
+                    const double* tU = sm + c.tA[P_U];
+                    for (int t = qp.jl[j]; t < d.Hp; ++t) acc += tU[t * nu + cc];
+                }
+                if (qp.pair_on(P_X)) {
+                    const double* tX = sm + c.tA[P_X];
+                    for (int i = 0; i < d.nxh; ++i) acc += qp.Xat(i, k) * tX[i];
+                }
+            } else {
+                acc += eacc;
+            }
+            gt[k] = acc;
+        }
+        if (qp.pair_on(P_Y)) qp.Et_apply_add(sm + c.tA[P_Y], gt);   // same lane owns gt[k]
+        w.sync();
+    }
+
+    // ---- Phi = H̃ + G' diag(dd) G, dd(row) given by functor ------------------------------------
+    template <class Fn>
+    MPCQP_HD void form_phi(Fn dd) {
+        const int nu = d.nu, nDU = d.nDU, nZ = d.nZ;
+        const double* H = m.Hpk + (size_t)b * d.npk;
+        for (int i = w.lane; i < d.npk; i += WAVE) Phi[i] = H[i];
+        double ee = 0.0;
+        for (int p = 0; p < NPAIR; ++p) {
+            if (!qp.pair_on(p)) continue;
+            double* tA = sm + c.tA[p];
+            double* tB = sm + c.tB[p];
+            const int n = d.cnt[p];
+            const bool gmin = qp.group_on(2 * p), gmax = qp.group_on(2 * p + 1);
+            for (int k = w.lane; k < n; k += WAVE) {
+                double dmin = 0.0, dmax = 0.0;
+                if (gmin && fin(d.rowoff[2 * p] + k)) dmin = dd(d.rowoff[2 * p] + k);
+                if (gmax && fin(d.rowoff[2 * p + 1] + k)) dmax = dd(d.rowoff[2 * p + 1] + k);
+                tA[k] = dmin + dmax;
+                if (p != P_BOX) {
+                    double cmin = soft(2 * p, k), cmax = soft(2 * p + 1, k);
+                    tB[k] = cmin * dmin - cmax * dmax;
+                    ee += cmin * cmin * dmin + cmax * cmax * dmax;
+                }
+            }
+        }
+        ee = w.sum(ee);
+        w.sync();
+        // dense E' dY E
+        if (qp.pair_on(P_Y)) qp.EtDE_add(sm + c.tA[P_Y], Phi);
+        // structured parts: same idx->lane map as EtDE_add, so no barrier needed in between
+        const int ntri = nDU * (nDU + 1) / 2;
+        const bool onU = qp.pair_on(P_U), onX = qp.pair_on(P_X);
+        if (onU || onX)
+            for (int idx = w.lane; idx < ntri; idx += WAVE) {
+                int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+                while (i * (i + 1) / 2 > idx) --i;
+                while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+                int ip = idx - i * (i + 1) / 2;
+                double acc = 0.0;
+                if (onU) {
+                    int j = i / nu, cc = i - j * nu, c2 = ip % nu;
+                    if (cc == c2) {
+                        const double* tU = sm + c.tA[P_U];
+                        for (int t = qp.jl[j]; t < d.Hp; ++t) acc += tU[t * nu + cc];   // j >= j'
+                    }
+                }
+                if (onX) {
+                    const double* tX = sm + c.tA[P_X];
+                    for (int r = 0; r < d.nxh; ++r) acc += qp.Xat(r, i) * tX[r] * qp.Xat(r, ip);
+                }
+                Phi[idx] += acc;
+            }
+        w.sync();
+        for (int k = w.lane; k < nZ; k += WAVE) {
+            double acc = 0.0;
+            if (qp.pair_on(P_BOX)) acc += sm[c.tA[P_BOX] + k];
+            if (k < nDU && qp.pair_on(P_DU)) acc += sm[c.tA[P_DU] + k];
+            if (k == nZ - 1 && d.neps) acc += ee;
+            Phi[pk(k, k)] += acc;
+        }
+        // ϵ row: Phi[eps, k] += sum_pairs L_P' tB     (staged in dz, which is free here)
+        if (d.neps) {
+            double* st = dz;
+            for (int k = w.lane; k < nDU; k += WAVE) {
+                double acc = 0.0;
+                if (qp.pair_on(P_DU)) acc += sm[c.tB[P_DU] + k];
+                if (qp.pair_on(P_U)) {
+                    int j = k / nu, cc = k - j * nu;
+                    const double* tU = sm + c.tB[P_U];
+                    for (int t = qp.jl[j]; t < d.Hp; ++t) acc += tU[t * nu + cc];
+                }
+                if (qp.pair_on(P_X)) {
+                    const double* tX = sm + c.tB[P_X];
+                    for (int i = 0; i < d.nxh; ++i) acc += qp.Xat(i, k) * tX[i];
+                }
+                st[k] = acc;
+            }
+            if (qp.pair_on(P_Y)) qp.Et_apply_add(sm + c.tB[P_Y], st);   // same lane owns st[k]
+            for (int k = w.lane; k < nDU; k += WAVE) Phi[pk(nZ - 1, k)] += st[k];
+        }
+        w.sync();
+    }
+
+    // ---- in-place Cholesky of packed Phi (row-major lower), one row per lane, nZ <= 64 --------
+    // pivot guard: a non-positive pivot (float64 breakdown of the normal equations) freezes that
+    // coordinate for this Newton step instead of poisoning the factor with NaN.
+    MPCQP_HD void cholesky() {
+        const int n = d.nZ;
+        const int i = w.lane;
+        for (int k = 0; k < n; ++k) {
+            double v = 0.0;
+            if (i >= k && i < n) {
+                v = Phi[pk(i, k)];
+                const double* Li = Phi + pk(i, 0);
+                const double* Lk = Phi + pk(k, 0);
+                for (int j = 0; j < k; ++j) v -= Li[j] * Lk[j];
+            }
+            const double piv = w.bcast(v, k);
+            const double ref = fabs(Phi[pk(k, k)]);
+            w.sync();     // everyone has read its column-k inputs (incl. the old diagonal)
+            const bool bad = !(piv > 1e-14 * ref);
+            const double dd = bad ? 1e32 : sqrt(piv);
+            const double id = 1.0 / dd;
+            if (i == k) { Phi[pk(k, k)] = dd; invd[k] = id; }
+            else if (i > k && i < n) Phi[pk(i, k)] = bad ? 0.0 : v * id;
+            w.sync();
+        }
+    }
+
+    // ---- dz <- Phi^{-1} gt  (factor in Phi/invd) -----------------------------------------------
+    MPCQP_HD void solve_into_dz() {
+        const int n = d.nZ;
+        const int i = w.lane;
+        double r = (i < n) ? gt[i] : 0.0;
+        for (int k = 0; k < n; ++k) {                 // L y = r, column sweep
+            const double yk = w.bcast((i == k) ? r * invd[k] : 0.0, k);
+            if (i == k) r = yk;
+            else if (i > k && i < n) r -= Phi[pk(i, k)] * yk;
+        }
+        for (int k = n - 1; k >= 0; --k) {            // L' x = y, row sweep
+            const double xk = w.bcast((i == k) ? r * invd[k] : 0.0, k);
+            if (i == k) r = xk;
+            else if (i < k) r -= Phi[pk(k, i)] * xk;
+        }
+        if (i < n) dz[i] = r;
+        w.sync();
+    }
+
+    // ---- rd = H̃ z + q + G' lam ; returns |rd|_inf and the size of its terms --------------------
+    MPCQP_HD void dual_residual(double& rdn, double& nd_) {
+        const int n = d.nZ;
+        apply_Gt([&](int row) { return lam[row]; });
+        const double* H = m.Hpk + (size_t)b * d.npk;
+        double mx = 0.0, sc = 0.0;
+        for (int k = w.lane; k < n; k += WAVE) {
+            double hz = 0.0;
+            for (int j = 0; j < n; ++j) hz += H[k >= j ? pk(k, j) : pk(j, k)] * z[j];
+            const double r = hz + q[k] + gt[k];
+            rd[k] = r;
+            mx = fmax(mx, fabs(r));
+            sc = fmax(sc, fmax(fabs(q[k]), fmax(fabs(hz), fabs(gt[k]))));
+        }
+        rdn = w.maxv(mx);
+        nd_ = 1.0 + w.maxv(sc);
+        w.sync();
+    }
+
+    // Row part of one Newton step of the dual-regularised system (D~ = D w, w = 1/(1+δD)):
+    //   dl = -w rc/s + D~ (rp + G dz),   ds = -(rc + s dl)/lam
+    MPCQP_HD void row_step(int row, double rc, double& ds, double& dl) const {
+        const double D = lam[row] / s[row], ww = 1.0 / (1.0 + delta * D);
+        dl = -ww * rc / s[row] + D * ww * (rp[row] + gd[row]);
+        ds = -(rc + s[row] * dl) / lam[row];
+    }
+
+    // (H + G'D~G) dz = -rd + G'(w rc/s - D~ rp); then gd = G dz.  rc(row) given by functor.
+    template <class Fn>
+    MPCQP_HD void newton(Fn rc) {
+        apply_Gt([&](int row) {
+            const double D = lam[row] / s[row], ww = 1.0 / (1.0 + delta * D);
+            return ww * rc(row) / s[row] - D * ww * rp[row];
+        });
+        for (int k = w.lane; k < d.nZ; k += WAVE) gt[k] -= rd[k];
+        w.sync();
+        solve_into_dz();
+        apply_G(dz, gd);
+    }
+
+    MPCQP_HD void residuals(double& mu, double& rpn) {
+        apply_G(z, rp);
+        double musum = 0.0, rpmax = 0.0;
+        for_rows([&](int row, int, int) {
+            if (!fin(row)) return;
+            const double r = rp[row] + s[row] - h[row];
+            rp[row] = r;
+            rpmax = fmax(rpmax, fabs(r));
+            musum += s[row] * lam[row];
+        });
+        mu = w.sum(musum) / mact;
+        rpn = w.maxv(rpmax);
+        w.sync();
+    }
+
+    MPCQP_HD int run(const StepIO& io, int& iters_out) {
+        const int n = d.nZ;
+        // warm start: Z̃s = [Z̃prev[nu+1:nΔU]; 0; ϵprev]       transcription.jl:1001-1004
+        const double* Zg = io.Z + (size_t)b * n;
+        const bool cold = d.flags & 2u;
+        for (int k = w.lane; k < n; k += WAVE) {
+            double v = 0.0;
+            if (!cold) {
+                if (k < d.nDU - d.nu) v = Zg[k + d.nu];
+                else if (k >= d.nDU) v = Zg[k];
+            }
+            z[k] = v;
+        }
+        w.sync();
+        if (mact == 0) {
+            // no finite row at all: Z̃ = -H̃^{-1} q̃ (what ExplicitMPC computes, explicitmpc.jl:216)
+            form_phi([&](int) { return 0.0; });
+            cholesky();
+            for (int k = w.lane; k < n; k += WAVE) gt[k] = -q[k];
+            w.sync();
+            solve_into_dz();
+            for (int k = w.lane; k < n; k += WAVE) z[k] = dz[k];
+            w.sync();
+            iters_out = 0;
+            return ST_OPTIMAL;
+        }
+        // warm start kept in a register for the error path (nZ <= 64: one entry per lane)
+        const double zws = (w.lane < n) ? z[w.lane] : 0.0;
+        double mu, rpn, rdn, ndd;
+        // ---- starting point: affine step from (z, s=1, lam=1), then push into the interior ----
+        residuals(mu, rpn);
+        dual_residual(rdn, ndd);
+        form_phi([&](int row) { return lam[row] / s[row]; });
+        cholesky();
+        newton([&](int row) { return s[row] * lam[row]; });
+        for_rows([&](int row, int, int) {
+            if (!fin(row)) return;
+            double ds, dl;
+            row_step(row, s[row] * lam[row], ds, dl);
+            s[row] = fmax(fabs(s[row] + ds), 1.0);
+            lam[row] = fmax(fabs(lam[row] + dl), 1.0);
+        });
+        for (int k = w.lane; k < n; k += WAVE) z[k] += dz[k];
+        w.sync();
+        int status = ST_ITERATION_LIMIT;
+        int it = 0;
+        for (it = 0; it < d.max_iter; ++it) {
+            residuals(mu, rpn);
+            dual_residual(rdn, ndd);
+            if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
+            if (mu <= d.gap_tol && rdn <= d.res_tol * ndd && rpn <= d.res_tol * nh) {
+                status = ST_OPTIMAL;
+                break;
+            }
+            form_phi([&](int row) {
+                const double D = lam[row] / s[row];
+                return D / (1.0 + delta * D);
+            });
+            cholesky();
+            // predictor: rc = s lam
+            newton([&](int row) { return s[row] * lam[row]; });
+            double amin = 1.0;
+            for_rows([&](int row, int, int) {
+                if (!fin(row)) return;
+                double ds, dl;
+                row_step(row, s[row] * lam[row], ds, dl);
+                if (ds < 0.0) amin = fmin(amin, -s[row] / ds);
+                if (dl < 0.0) amin = fmin(amin, -lam[row] / dl);
+            });
+            const double aaff = w.minv(amin);
+            double mas = 0.0;
+            for_rows([&](int row, int, int) {
+                if (!fin(row)) return;
+                double ds, dl;
+                row_step(row, s[row] * lam[row], ds, dl);
+                mas += (s[row] + aaff * ds) * (lam[row] + aaff * dl);
+                pp[row] = ds * dl;
+            });
+            const double muaff = w.sum(mas) / mact;
+            double sig = muaff / mu;
+            sig = sig * sig * sig;
+            const double smu = sig * mu;
+            w.sync();
+            // corrector: rc = s lam + ds_aff dl_aff - sigma mu
+            newton([&](int row) { return s[row] * lam[row] + pp[row] - smu; });
+            amin = 1e300;
+            for_rows([&](int row, int, int) {
+                if (!fin(row)) return;
+                double ds, dl;
+                row_step(row, s[row] * lam[row] + pp[row] - smu, ds, dl);
+                if (ds < 0.0) amin = fmin(amin, -s[row] / ds);
+                if (dl < 0.0) amin = fmin(amin, -lam[row] / dl);
+            });
+            const double alpha = fmin(1.0, 0.99 * w.minv(amin));
+            for_rows([&](int row, int, int) {
+                if (!fin(row)) return;
+                double ds, dl;
+                row_step(row, s[row] * lam[row] + pp[row] - smu, ds, dl);
+                s[row] += alpha * ds;
+                lam[row] += alpha * dl;
+            });
+            for (int k = w.lane; k < n; k += WAVE) z[k] += alpha * dz[k];
+            w.sync();
+        }
+        // never primal-feasible (or NaN) => the reference's error branch (execute.jl:484-489)
+        if (status == ST_ITERATION_LIMIT && !(rpn <= 1e-6 * nh)) status = ST_ERROR;
+        if (status == ST_ERROR) {
+            if (w.lane < n) z[w.lane] = zws;          // mpc.Z̃ .= Z̃s   execute.jl:499-500
+            w.sync();
+        }
+        iters_out = it;
+        return status;
+    }
+
+    static constexpr int ST_OPTIMAL = 0, ST_ITERATION_LIMIT = 1, ST_ERROR = 2;
+};
+
+template <class W>
+MPCQP_HD void step_body(W& w, const Dims& d, const Model& m, const StepIO& io, int b, double* sm) {
+    Qp<W> qp(w, d, m, b, sm);
+    qp.load_tables();
+    Step<W> st(qp);
+    st.build(io);
+    if ((d.flags & 4u) && io.q_keep) {
+        for (int k = w.lane; k < d.nZ; k += WAVE) io.q_keep[(size_t)b * d.nZ + k] = st.q[k];
+        for (int r = w.lane; r < d.nY; r += WAVE) io.F_keep[(size_t)b * d.nY + r] = st.F[r];
+    }
+    int iters = 0;
+    int status = st.run(io, iters);
+    // outputs: Z̃, u0 = Z̃[1:nu] + lastu0 (getinput!), Ŷ0 = Ẽ Z̃ + F (predict!)
+    for (int k = w.lane; k < d.nZ; k += WAVE) io.Z[(size_t)b * d.nZ + k] = st.z[k];
+    for (int k = w.lane; k < d.nu; k += WAVE)
+        io.u0[(size_t)b * d.nu + k] = st.z[k] + io.lastu0[(size_t)b * d.nu + k];
+    if (io.Yhat0) {
+        double* tY = sm + st.c.tA[P_Y];
+        qp.E_apply(st.z, tY);
+        for (int r = w.lane; r < d.nY; r += WAVE) io.Yhat0[(size_t)b * d.nY + r] = tY[r] + st.F[r];
+    }
+    if (w.lane == 0) {
+        io.status[b] = status;
+        if (io.iters) io.iters[b] = iters;
+    }
+}
+
+}  // namespace mpcqp

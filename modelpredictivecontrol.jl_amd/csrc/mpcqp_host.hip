@@ -1,0 +1,476 @@
+// mpcqp_host.hip -- C-ABI of include/mpcqp.h: handle, device residency, launches.
+// There is deliberately NO CPU fallback in this library: every compute entry point needs a HIP
+// device and fails with MPCQP_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpcqp.h"
+#include "mpcqp_launch.h"
+
+using namespace mpcqp;
+
+static thread_local std::string g_hip_err;
+
+#define HIPCHK(expr)                                                                 \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+            return MPCQP_ERR_DEVICE;                                                 \
+        }                                                                            \
+    } while (0)
+
+struct DBuf {                      // owned device array of doubles (or ints)
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct mpcqp_handle_s {
+    Dims d{};
+    Model m{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
+    bool step_timed = false, cond_timed = false;
+    bool have_model = false, have_weights = false, terminal_built = false;
+    std::vector<int> nb, jl, blk;
+    std::vector<void*> owned;
+    // model / weights / bounds storage
+    DBuf Ahat, Bu, C, Bd, Dd, dop, Mdiag, Ndiag, Ldiag, Cwt;
+    DBuf bnd[16];
+    // staging for the host-pointer step
+    DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
+    DBuf keep_q, keep_F;
+};
+
+static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return MPCQP_OK;
+    void* p = nullptr;
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? MPCQP_ERR_NOMEM : MPCQP_ERR_DEVICE;
+    }
+    h->owned.push_back(p);
+    b.p = p;
+    b.bytes = bytes;
+    return MPCQP_OK;
+}
+
+static int upload(mpcqp_handle h, DBuf& b, const void* src, size_t bytes) {
+    int rc = dev_alloc(h, b, bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return MPCQP_OK;
+}
+
+extern "C" {
+
+const char* mpcqp_version(void) { return "mpcqp 0.1.0 (gfx950)"; }
+
+const char* mpcqp_strerror(int code) {
+    switch (code) {
+        case MPCQP_OK: return "ok";
+        case MPCQP_ERR_NULL: return "required pointer is NULL";
+        case MPCQP_ERR_DIMS: return "dimension mismatch";
+        case MPCQP_ERR_ARG: return "illegal argument value";
+        case MPCQP_ERR_UNSUPPORTED: return "configuration not supported by this build";
+        case MPCQP_ERR_ORDER: return "model, weights must be set before step";
+        case MPCQP_ERR_DEVICE: return "HIP runtime error (see mpcqp_last_hip_error)";
+        case MPCQP_ERR_NOMEM: return "out of device memory";
+        default: return "unknown error code";
+    }
+}
+
+const char* mpcqp_last_hip_error(void) { return g_hip_err.c_str(); }
+
+static void layout_rows(mpcqp_handle h) {
+    Dims& d = h->d;
+    d.cnt[P_BOX] = d.nZ; d.cnt[P_U] = d.nU; d.cnt[P_DU] = d.nDU; d.cnt[P_Y] = d.nY; d.cnt[P_X] = d.nxh;
+    int o = 0;
+    for (int g = 0; g < NGROUP; ++g) {
+        d.rowoff[g] = o;
+        if ((d.gmask >> g) & 1u) o += d.cnt[g >> 1];
+    }
+    d.rowoff[NGROUP] = o;
+}
+
+int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
+    if (!in || !out) return MPCQP_ERR_NULL;
+    *out = nullptr;
+    if (in->batch < 1 || in->nxhat < 1 || in->nu < 1 || in->ny < 1 || in->nd < 0) return MPCQP_ERR_ARG;
+    // validate_weights, src/controller/construct.jl:99-103
+    if (in->Hp < 1 || in->Hc < 1 || in->Hc > in->Hp) return MPCQP_ERR_ARG;
+    if (in->neps != 0 && in->neps != 1) return MPCQP_ERR_ARG;
+    std::vector<int> nb(in->Hc, 1);
+    if (in->nb) {
+        int sum = 0;
+        for (int i = 0; i < in->Hc; ++i) {
+            if (in->nb[i] < 1) return MPCQP_ERR_ARG;   // move_blocking, construct.jl:632
+            nb[i] = in->nb[i];
+            sum += nb[i];
+        }
+        if (sum != in->Hp) return MPCQP_ERR_DIMS;
+    } else {
+        nb[in->Hc - 1] = in->Hp - in->Hc + 1;          // construct.jl:653-660
+    }
+    const int nZ = in->nu * in->Hc + in->neps;
+    if (nZ > WAVE) return MPCQP_ERR_UNSUPPORTED;       // one Cholesky row per lane
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (in->device < 0 || in->device >= ndev) return MPCQP_ERR_ARG;
+    HIPCHK(hipSetDevice(in->device));
+    mpcqp_handle h = new (std::nothrow) mpcqp_handle_s();
+    if (!h) return MPCQP_ERR_NOMEM;
+    Dims& d = h->d;
+    d.B = in->batch; d.nxh = in->nxhat; d.nu = in->nu; d.ny = in->ny; d.nd = in->nd;
+    d.Hp = in->Hp; d.Hc = in->Hc; d.neps = in->neps;
+    d.nZ = nZ; d.nDU = in->nu * in->Hc; d.nU = in->nu * in->Hp; d.nY = in->ny * in->Hp;
+    d.nD = in->nd * in->Hp;
+    d.npk = nZ * (nZ + 1) / 2;
+    d.flags = in->flags;
+    d.max_iter = in->max_iter > 0 ? in->max_iter : 60;
+    d.gap_tol = in->gap_tol > 0 ? in->gap_tol : 1e-12;
+    d.res_tol = in->res_tol > 0 ? in->res_tol : 1e-9;
+    d.dual_reg = in->dual_reg > 0 ? in->dual_reg : 1e-12;
+    d.gmask = d.neps ? 1u : 0u;                        // ϵ >= 0 is always there
+    layout_rows(h);
+    h->device = in->device;
+    h->nb = nb;
+    h->jl.assign(d.Hc + 1, 0);
+    for (int i = 0; i < d.Hc; ++i) h->jl[i + 1] = h->jl[i] + nb[i];
+    h->blk.assign(d.Hp, 0);
+    for (int i = 0; i < d.Hc; ++i)
+        for (int t = h->jl[i]; t < h->jl[i + 1]; ++t) h->blk[t] = i;
+    int rc = MPCQP_OK;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_s0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_s1);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_c0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_c1);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("stream/event create: ") + hipGetErrorString(e);
+        rc = MPCQP_ERR_DEVICE;
+    }
+    auto mk = [&](size_t n) -> double* {
+        if (rc) return nullptr;
+        DBuf b;
+        rc = dev_alloc(h, b, n * sizeof(double));
+        return (double*)b.p;
+    };
+    const size_t B = d.B;
+    h->m.Stab = mk(B * d.Hp * d.ny * d.nu);
+    h->m.Ktab = mk(B * d.nxh * d.nY);
+    h->m.Bvec = mk(B * d.nY);
+    h->m.Hpk = mk(B * d.npk);
+    if (d.nd > 0) h->m.Gdtab = mk(B * d.Hp * d.ny * d.nd);
+    if (!rc) {
+        DBuf bj, bb;
+        rc = dev_alloc(h, bj, (d.Hc + 1) * sizeof(int));
+        if (!rc) rc = dev_alloc(h, bb, d.Hp * sizeof(int));
+        if (!rc) {
+            hipError_t e1 = hipMemcpy(bj.p, h->jl.data(), (d.Hc + 1) * sizeof(int), hipMemcpyHostToDevice);
+            hipError_t e2 = hipMemcpy(bb.p, h->blk.data(), d.Hp * sizeof(int), hipMemcpyHostToDevice);
+            if (e1 != hipSuccess || e2 != hipSuccess) { g_hip_err = "hipMemcpy(jl/blk)"; rc = MPCQP_ERR_DEVICE; }
+            h->m.jl = (const int*)bj.p;
+            h->m.blk = (const int*)bb.p;
+        }
+    }
+    if (rc) { mpcqp_destroy(h); return rc; }
+    *out = h;
+    return MPCQP_OK;
+}
+
+int mpcqp_destroy(mpcqp_handle h) {
+    if (!h) return MPCQP_ERR_NULL;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->ev_s0) (void)hipEventDestroy(h->ev_s0);
+    if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
+    if (h->ev_c0) (void)hipEventDestroy(h->ev_c0);
+    if (h->ev_c1) (void)hipEventDestroy(h->ev_c1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MPCQP_OK;
+}
+
+int mpcqp_get_sizes(mpcqp_handle h, mpcqp_sizes* out) {
+    if (!h || !out) return MPCQP_ERR_NULL;
+    out->nZ = h->d.nZ; out->nDU = h->d.nDU; out->nU = h->d.nU; out->nY = h->d.nY; out->nD = h->d.nD;
+    return MPCQP_OK;
+}
+
+static bool terminal_on(const Dims& d) { return (d.gmask >> (2 * P_X)) & 3u; }
+
+static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
+    const Dims& d = h->d;
+    if (!h->have_model) return MPCQP_OK;
+    const bool term = terminal_on(d);
+    if (term && !h->m.exT) {
+        DBuf a, b, c, x;
+        int rc = dev_alloc(h, a, (size_t)d.B * d.Hc * d.nxh * d.nu * sizeof(double));
+        if (!rc) rc = dev_alloc(h, b, (size_t)d.B * d.nxh * d.nxh * sizeof(double));
+        if (!rc) rc = dev_alloc(h, c, (size_t)d.B * d.nxh * sizeof(double));
+        if (!rc && d.nd > 0) rc = dev_alloc(h, x, (size_t)d.B * d.Hp * d.nxh * d.nd * sizeof(double));
+        if (rc) return rc;
+        h->m.exT = (double*)a.p; h->m.kxT = (double*)b.p; h->m.bxv = (double*)c.p;
+        h->m.Xdtab = d.nd > 0 ? (double*)x.p : nullptr;
+    }
+    if (timed) HIPCHK(hipEventRecord(h->ev_c0, st));
+    HIPCHK(launch_predmat(d, h->m, term, st));
+    h->terminal_built = term;
+    if (h->have_weights) HIPCHK(launch_hessian(d, h->m, st));
+    if (timed) { HIPCHK(hipEventRecord(h->ev_c1, st)); h->cond_timed = true; }
+    return MPCQP_OK;
+}
+
+int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const double* C,
+                    const double* Bd, const double* Dd, const double* dop) {
+    if (!h || !Ahat || !Bu || !C) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    if (d.nd > 0 && (!Bd || !Dd)) return MPCQP_ERR_NULL;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = d.B, sz = sizeof(double);
+    int rc = upload(h, h->Ahat, Ahat, B * d.nxh * d.nxh * sz);
+    if (!rc) rc = upload(h, h->Bu, Bu, B * d.nxh * d.nu * sz);
+    if (!rc) rc = upload(h, h->C, C, B * d.ny * d.nxh * sz);
+    if (!rc && d.nd > 0) rc = upload(h, h->Bd, Bd, B * d.nxh * d.nd * sz);
+    if (!rc && d.nd > 0) rc = upload(h, h->Dd, Dd, B * d.ny * d.nd * sz);
+    if (!rc && dop) rc = upload(h, h->dop, dop, B * d.nxh * sz);
+    if (rc) return rc;
+    h->m.Ahat = (const double*)h->Ahat.p; h->m.Bu = (const double*)h->Bu.p;
+    h->m.C = (const double*)h->C.p;
+    h->m.Bd = d.nd > 0 ? (const double*)h->Bd.p : nullptr;
+    h->m.Dd = d.nd > 0 ? (const double*)h->Dd.p : nullptr;
+    h->m.dop = dop ? (const double*)h->dop.p : nullptr;
+    h->have_model = true;
+    rc = condense(h, h->stream, true);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
+                      const double* Ldiag, const double* Cwt) {
+    if (!h || !Mdiag || !Ndiag || !Ldiag) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    if (d.neps && !Cwt) return MPCQP_ERR_NULL;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = d.B, sz = sizeof(double);
+    int rc = upload(h, h->Mdiag, Mdiag, B * d.nY * sz);
+    if (!rc) rc = upload(h, h->Ndiag, Ndiag, B * d.nDU * sz);
+    if (!rc) rc = upload(h, h->Ldiag, Ldiag, B * d.nU * sz);
+    if (!rc && d.neps) rc = upload(h, h->Cwt, Cwt, B * sz);
+    if (rc) return rc;
+    h->m.Mdiag = (const double*)h->Mdiag.p; h->m.Ndiag = (const double*)h->Ndiag.p;
+    h->m.Ldiag = (const double*)h->Ldiag.p;
+    h->m.Cwt = d.neps ? (const double*)h->Cwt.p : nullptr;
+    h->have_weights = true;
+    if (h->have_model) {
+        HIPCHK(launch_hessian(d, h->m, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
+    if (!h || !bin) return MPCQP_ERR_NULL;
+    Dims& d = h->d;
+    if (!d.neps && (bin->C_umin || bin->C_umax || bin->C_dumin || bin->C_dumax || bin->C_ymin ||
+                    bin->C_ymax || bin->c_x0min || bin->c_x0max))
+        return MPCQP_ERR_ARG;   // "Cwt must be finite to set softness parameters", construct.jl:441
+    HIPCHK(hipSetDevice(h->device));
+    const double* src[16] = {bin->U0min, bin->U0max, bin->DUmin, bin->DUmax, bin->Y0min, bin->Y0max,
+                             bin->x0min, bin->x0max, bin->C_umin, bin->C_umax, bin->C_dumin,
+                             bin->C_dumax, bin->C_ymin, bin->C_ymax, bin->c_x0min, bin->c_x0max};
+    const int len[16] = {d.nU, d.nU, d.nDU, d.nDU, d.nY, d.nY, d.nxh, d.nxh,
+                         d.nU, d.nU, d.nDU, d.nDU, d.nY, d.nY, d.nxh, d.nxh};
+    const double* dev[16];
+    for (int i = 0; i < 16; ++i) {
+        dev[i] = nullptr;
+        if (!src[i]) continue;
+        int rc = upload(h, h->bnd[i], src[i], (size_t)d.B * len[i] * sizeof(double));
+        if (rc) return rc;
+        dev[i] = (const double*)h->bnd[i].p;
+    }
+    Model& m = h->m;
+    m.U0min = dev[0]; m.U0max = dev[1]; m.DUmin = dev[2]; m.DUmax = dev[3];
+    m.Y0min = dev[4]; m.Y0max = dev[5]; m.x0min = dev[6]; m.x0max = dev[7];
+    m.C_umin = dev[8]; m.C_umax = dev[9]; m.C_dumin = dev[10]; m.C_dumax = dev[11];
+    m.C_ymin = dev[12]; m.C_ymax = dev[13]; m.c_x0min = dev[14]; m.c_x0max = dev[15];
+    uint32_t g = 0;
+    if (d.neps || m.DUmin) g |= 1u << 0;                 // box lower (ϵ >= 0, hard ΔUmin)
+    if (m.DUmax) g |= 1u << 1;                           // box upper
+    if (m.U0min) g |= 1u << (2 * P_U);
+    if (m.U0max) g |= 1u << (2 * P_U + 1);
+    if (d.neps && m.DUmin && m.C_dumin) g |= 1u << (2 * P_DU);
+    if (d.neps && m.DUmax && m.C_dumax) g |= 1u << (2 * P_DU + 1);
+    if (m.Y0min) g |= 1u << (2 * P_Y);
+    if (m.Y0max) g |= 1u << (2 * P_Y + 1);
+    if (m.x0min) g |= 1u << (2 * P_X);
+    if (m.x0max) g |= 1u << (2 * P_X + 1);
+    d.gmask = g;
+    layout_rows(h);
+    if (terminal_on(d) && !h->terminal_built && h->have_model) {
+        int rc = condense(h, h->stream, false);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
+                      const double* Ry, const double* Ru, const double* d0, const double* Dhat0,
+                      double* Ztilde, double* u0, int32_t* status, int32_t* iters,
+                      double* Yhat0, void* stream) {
+    if (!h || !xhat0 || !lastu0 || !Ry || !Ztilde || !u0 || !status) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
+    if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
+    if (step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    StepIO io{};
+    io.xhat0 = xhat0; io.lastu0 = lastu0; io.Ry = Ry; io.Ru = Ru; io.d0 = d0; io.Dhat0 = Dhat0;
+    io.Z = Ztilde; io.u0 = u0; io.Yhat0 = Yhat0; io.status = status; io.iters = iters;
+    if (d.flags & MPCQP_FLAG_KEEP_QP) {
+        int rc = dev_alloc(h, h->keep_q, (size_t)d.B * d.nZ * sizeof(double));
+        if (!rc) rc = dev_alloc(h, h->keep_F, (size_t)d.B * d.nY * sizeof(double));
+        if (rc) return rc;
+        io.q_keep = (double*)h->keep_q.p;
+        io.F_keep = (double*)h->keep_F.p;
+    }
+    HIPCHK(hipEventRecord(h->ev_s0, st));
+    HIPCHK(launch_step(d, h->m, io, st));
+    HIPCHK(hipEventRecord(h->ev_s1, st));
+    h->step_timed = true;
+    return MPCQP_OK;
+}
+
+int mpcqp_step(mpcqp_handle h, const double* xhat0, const double* lastu0, const double* Ry,
+               const double* Ru, const double* d0, const double* Dhat0, double* Ztilde,
+               double* u0, int32_t* status, int32_t* iters, double* Yhat0) {
+    if (!h || !xhat0 || !lastu0 || !Ry || !Ztilde || !u0 || !status) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = d.B, sz = sizeof(double);
+    const size_t nry = (d.flags & MPCQP_FLAG_RY_CONSTANT) ? d.ny : d.nY;
+    int rc = upload(h, h->s_x, xhat0, B * d.nxh * sz);
+    if (!rc) rc = upload(h, h->s_lu, lastu0, B * d.nu * sz);
+    if (!rc) rc = upload(h, h->s_ry, Ry, B * nry * sz);
+    if (!rc && Ru) rc = upload(h, h->s_ru, Ru, B * d.nU * sz);
+    if (!rc && d.nd > 0) rc = upload(h, h->s_d0, d0, B * d.nd * sz);
+    if (!rc && d.nd > 0) rc = upload(h, h->s_dh, Dhat0, B * d.nD * sz);
+    if (!rc) rc = upload(h, h->s_Z, Ztilde, B * d.nZ * sz);
+    if (!rc) rc = dev_alloc(h, h->s_u0, B * d.nu * sz);
+    if (!rc) rc = dev_alloc(h, h->s_st, B * sizeof(int32_t));
+    if (!rc) rc = dev_alloc(h, h->s_it, B * sizeof(int32_t));
+    if (!rc && Yhat0) rc = dev_alloc(h, h->s_yh, B * d.nY * sz);
+    if (rc) return rc;
+    rc = mpcqp_step_device(h, (const double*)h->s_x.p, (const double*)h->s_lu.p,
+                           (const double*)h->s_ry.p, Ru ? (const double*)h->s_ru.p : nullptr,
+                           d.nd > 0 ? (const double*)h->s_d0.p : nullptr,
+                           d.nd > 0 ? (const double*)h->s_dh.p : nullptr, (double*)h->s_Z.p,
+                           (double*)h->s_u0.p, (int32_t*)h->s_st.p, (int32_t*)h->s_it.p,
+                           Yhat0 ? (double*)h->s_yh.p : nullptr, h->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(Ztilde, h->s_Z.p, B * d.nZ * sz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(u0, h->s_u0.p, B * d.nu * sz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(status, h->s_st.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIPCHK(hipMemcpyAsync(iters, h->s_it.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (Yhat0) HIPCHK(hipMemcpyAsync(Yhat0, h->s_yh.p, B * d.nY * sz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_recondense_device(mpcqp_handle h, void* stream) {
+    if (!h) return MPCQP_ERR_NULL;
+    if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
+    HIPCHK(hipSetDevice(h->device));
+    return condense(h, (hipStream_t)stream, true);
+}
+
+int mpcqp_get(mpcqp_handle h, int which, double* out) {
+    if (!h || !out) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t B = d.B;
+    auto fetch = [&](const void* src, size_t n, std::vector<double>& tmp) -> int {
+        tmp.resize(n);
+        HIPCHK(hipMemcpy(tmp.data(), src, n * sizeof(double), hipMemcpyDeviceToHost));
+        return MPCQP_OK;
+    };
+    std::vector<double> tmp;
+    switch (which) {
+        case MPCQP_GET_HESSIAN: {
+            if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
+            int rc = fetch(h->m.Hpk, B * d.npk, tmp);
+            if (rc) return rc;
+            for (size_t b = 0; b < B; ++b)
+                for (int i = 0; i < d.nZ; ++i)
+                    for (int j = 0; j <= i; ++j) {
+                        double v = tmp[b * d.npk + pk(i, j)];
+                        out[b * d.nZ * d.nZ + i + (size_t)d.nZ * j] = v;
+                        out[b * d.nZ * d.nZ + j + (size_t)d.nZ * i] = v;
+                    }
+            return MPCQP_OK;
+        }
+        case MPCQP_GET_STEPRESP: {
+            if (!h->have_model) return MPCQP_ERR_ORDER;
+            int rc = fetch(h->m.Stab, B * d.Hp * d.ny * d.nu, tmp);
+            if (rc) return rc;
+            for (size_t b = 0; b < B; ++b)
+                for (int mm = 0; mm < d.Hp; ++mm)
+                    for (int a = 0; a < d.ny; ++a)
+                        for (int c = 0; c < d.nu; ++c)
+                            out[((b * d.Hp + mm) * d.nu + c) * d.ny + a] =
+                                tmp[((b * d.Hp + mm) * d.ny + a) * d.nu + c];
+            return MPCQP_OK;
+        }
+        case MPCQP_GET_KMAT:
+            if (!h->have_model) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->m.Ktab, B * d.nxh * d.nY * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        case MPCQP_GET_BVEC:
+            if (!h->have_model) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->m.Bvec, B * d.nY * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        case MPCQP_GET_QTILDE:
+            if (!h->keep_q.p) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->keep_q.p, B * d.nZ * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        case MPCQP_GET_FVEC:
+            if (!h->keep_F.p) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->keep_F.p, B * d.nY * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        default:
+            return MPCQP_ERR_ARG;
+    }
+}
+
+static double elapsed(hipEvent_t a, hipEvent_t b, bool timed) {
+    if (!timed) return -1.0;
+    if (hipEventSynchronize(b) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+double mpcqp_last_step_ms(mpcqp_handle h) {
+    return h ? elapsed(h->ev_s0, h->ev_s1, h->step_timed) : -1.0;
+}
+
+double mpcqp_last_condense_ms(mpcqp_handle h) {
+    return h ? elapsed(h->ev_c0, h->ev_c1, h->cond_timed) : -1.0;
+}
+
+}  // extern "C"

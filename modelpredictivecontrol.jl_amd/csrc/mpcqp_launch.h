@@ -1,0 +1,12 @@
+// mpcqp_launch.h -- host-side launch entry points of the kernels in mpcqp_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mpcqp_types.h"
+
+namespace mpcqp {
+hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStream_t st);
+hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st);
+hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
+size_t step_lds_bytes(const Dims& d);
+}  // namespace mpcqp

@@ -1,0 +1,75 @@
+// mpcqp_types.h -- plain-old-data shared by the HIP kernels and the host library.
+//
+// Row groups of the inequality system A Z̃ <= b of one LinMPC, in the reference's order
+// (init_matconstraint_mpc, src/controller/transcription.jl:686-703) with the variable bounds
+// Z̃min/Z̃max (init_boxconstraint_mpc, src/controller/construct.jl:1209-1234) put first:
+//   pair 0  box   : -z_k <= -Z̃min_k            |  z_k <= Z̃max_k                (k < nZ)
+//   pair 1  U     : -Pu ΔU - C_umin ϵ <= ...     |  Pu ΔU - C_umax ϵ <= ...       (nU rows)
+//   pair 2  ΔU    : soft ΔU rows only (hard ones are the box)                    (nDU rows)
+//   pair 3  Ŷ     : -E ΔU - C_ymin ϵ <= ...      |  E ΔU - C_ymax ϵ <= ...        (nY rows)
+//   pair 4  x̂end : -ex̂ ΔU - c_x̂min ϵ <= ...     |  ex̂ ΔU - c_x̂max ϵ <= ...      (nx̂ rows)
+// group id = 2*pair + (0 = min rows, 1 = max rows).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MPCQP_HD __host__ __device__
+#else
+#define MPCQP_HD
+#endif
+
+namespace mpcqp {
+
+enum { P_BOX = 0, P_U = 1, P_DU = 2, P_Y = 3, P_X = 4, NPAIR = 5, NGROUP = 10 };
+
+constexpr int WAVE = 64;          // gfx950 wavefront
+constexpr double BIG = 1e300;     // |h| >= BIG  <=>  row absent (bound was +-Inf)
+
+struct Dims {
+    int B, nxh, nu, ny, nd, Hp, Hc, neps;
+    int nZ, nDU, nU, nY, nD;
+    int npk;                 // nZ*(nZ+1)/2  (packed lower triangle)
+    uint32_t gmask;          // bit g set <=> row group g may hold finite rows (handle level)
+    int rowoff[NGROUP + 1];  // first row of group g in the per-problem row arrays (inactive: empty)
+    int cnt[NPAIR];          // primitives per pair: nZ, nU, nDU, nY, nxh
+    int max_iter;
+    double gap_tol, res_tol, dual_reg;
+    uint32_t flags;
+};
+
+// device-resident, per-handle data (all problem-major; "col-major inside a problem" where the
+// ABI exposes it, internal tables in whatever order the kernels like)
+struct Model {
+    // inputs of set_model (ABI layout)
+    const double *Ahat, *Bu, *C, *Bd, *Dd, *dop;     // dop = f̂op - x̂op, may be null
+    // K1 outputs
+    double* Stab;    // [B][Hp][ny][nu]   Σ_m = Ĉ S(m) B̂u
+    double* Ktab;    // [B][nxh][nY]      K, column-major (nY fastest)
+    double* Bvec;    // [B][nY]
+    double* Gdtab;   // [B][Hp][ny][nd]   Ĉ Â^m B̂d                     (nd > 0)
+    double* exT;     // [B][Hc][nxh][nu]  ex̂ block j = S(Hp-j_j-1) B̂u   (terminal rows)
+    double* kxT;     // [B][nxh][nxh]     Â^Hp, column-major              (terminal rows)
+    double* bxv;     // [B][nxh]          S(Hp-1)(f̂op - x̂op)
+    double* Xdtab;   // [B][Hp][nxh][nd]  Â^m B̂d                        (terminal rows, nd > 0)
+    // K2 output
+    double* Hpk;     // [B][npk]          H̃, packed lower triangle row-major
+    // weights
+    const double *Mdiag, *Ndiag, *Ldiag, *Cwt;
+    // bounds + softness (null = group absent / default softness)
+    const double *U0min, *U0max, *DUmin, *DUmax, *Y0min, *Y0max, *x0min, *x0max;
+    const double *C_umin, *C_umax, *C_dumin, *C_dumax, *C_ymin, *C_ymax, *c_x0min, *c_x0max;
+    // horizon tables
+    const int* jl;   // [Hc+1] block starts j_l (move_blocking, construct.jl:597-660)
+    const int* blk;  // [Hp]   index of the block that holds step t
+};
+
+struct StepIO {
+    const double *xhat0, *lastu0, *Ry, *Ru, *d0, *Dhat0;
+    double *Z, *u0, *Yhat0;
+    int32_t *status, *iters;
+    double *q_keep, *F_keep;   // optional (MPCQP_FLAG_KEEP_QP)
+};
+
+MPCQP_HD inline int pk(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
+
+}  // namespace mpcqp

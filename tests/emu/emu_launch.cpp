@@ -1,0 +1,88 @@
+// TEST INFRASTRUCTURE ONLY: runs the kernel bodies of csrc/mpcqp_bodies.h on the CPU, one host
+// thread per lane of a 64-wide "wavefront", problems one after the other.  See fakehip/.
+#include <barrier>
+#include <thread>
+#include <vector>
+
+#include "mpcqp_bodies.h"
+#include "mpcqp_launch.h"
+
+namespace mpcqp {
+
+struct EmuShared {
+    std::barrier<> bar{WAVE};
+    double xd[WAVE];
+    int xi[WAVE];
+};
+
+struct EmuWave {
+    int lane;
+    EmuShared* sh;
+    void sync() { sh->bar.arrive_and_wait(); }
+    double sum(double v) {
+        sh->xd[lane] = v; sync();
+        double s = 0.0;
+        for (int i = 0; i < WAVE; ++i) s += sh->xd[i];
+        sync();
+        return s;
+    }
+    double minv(double v) {
+        sh->xd[lane] = v; sync();
+        double s = sh->xd[0];
+        for (int i = 1; i < WAVE; ++i) s = fmin(s, sh->xd[i]);
+        sync();
+        return s;
+    }
+    double maxv(double v) {
+        sh->xd[lane] = v; sync();
+        double s = sh->xd[0];
+        for (int i = 1; i < WAVE; ++i) s = fmax(s, sh->xd[i]);
+        sync();
+        return s;
+    }
+    int isum(int v) {
+        sh->xi[lane] = v; sync();
+        int s = 0;
+        for (int i = 0; i < WAVE; ++i) s += sh->xi[i];
+        sync();
+        return s;
+    }
+    double bcast(double v, int src) {
+        sh->xd[lane] = v; sync();
+        double s = sh->xd[src];
+        sync();
+        return s;
+    }
+};
+
+template <class F>
+static void run_waves(int B, size_t lds_doubles, F body) {
+    std::vector<double> smem(lds_doubles + 16, 0.0);
+    EmuShared sh;
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < WAVE; ++lane)
+        th.emplace_back([&, lane] {
+            EmuWave w{lane, &sh};
+            for (int b = 0; b < B; ++b) {
+                body(w, b, smem.data());
+                w.sync();
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStream_t) {
+    run_waves(d.B, predmat_lds_doubles(d), [&](EmuWave& w, int b, double* sm) { predmat_body(w, d, m, b, sm, terminal); });
+    return hipSuccess;
+}
+hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
+    run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { hessian_body(w, d, m, b, sm); });
+    return hipSuccess;
+}
+hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
+    run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { step_body(w, d, m, io, b, sm); });
+    return hipSuccess;
+}
+size_t step_lds_bytes(const Dims& d) { return (size_t)make_carve(d).total * sizeof(double); }
+
+}  // namespace mpcqp

@@ -1,0 +1,35 @@
+// TEST INFRASTRUCTURE ONLY.  A stand-in for the handful of HIP runtime calls the host side of
+// libmpcqp makes, so that csrc/mpcqp_host.hip + the kernel bodies can be compiled by g++ into
+// tests/emu/libmpcqp_emu.so and exercised on a CPU-only box (64 host threads play the lanes of a
+// wavefront).  It exists to debug index arithmetic without a GPU; it is not reachable from the
+// product package, which only loads lib/libmpcqp.so.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+typedef void* hipStream_t;
+struct fake_event { std::chrono::steady_clock::time_point t; };
+typedef fake_event* hipEvent_t;
+enum { hipStreamNonBlocking = 1 };
+
+inline const char* hipGetErrorString(hipError_t) { return "fake-hip error"; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new fake_event(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
