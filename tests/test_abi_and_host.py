@@ -1,0 +1,126 @@
+"""CPU-side checks: the HIP library loads and exports every symbol include/mpcqp.h declares (no
+compute call -- that needs a GPU), and the host-side mirror validates arguments like the
+reference.  The kernel bodies are additionally exercised on the CPU through the wave emulator of
+tests/emu (test infrastructure: 64 host threads play the lanes) to check index arithmetic; the
+GPU parity tests are in test_gpu_parity.py."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import mpcqp
+from mpcqp import synth
+from oracle import condense as cd, estim as es
+from tests.parity_util import make_oracle, oracle_batch, rel_err, run_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mpcqp.h")).read()
+    declared = set(re.findall(r"\b(mpcqp_[a-z_]+)\s*\(", hdr))
+    assert declared == set(mpcqp.EXPORTS)
+    lib = ctypes.CDLL(mpcqp.DEFAULT_LIB)          # fails loudly if the HIP build is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in ctypes.c_char_p(ctypes.cast(lib.mpcqp_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()).value
+
+
+def test_library_is_a_gfx950_code_object():
+    out = subprocess.run(["strings", "-a", mpcqp.DEFAULT_LIB], capture_output=True, text=True).stdout
+    assert "gfx950" in out and "k_step" in out
+
+
+def test_no_cpu_fallback_when_library_missing(tmp_path):
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        mpcqp.api.load_library(str(tmp_path / "absent.so"))
+
+
+def test_move_blocking_matches_reference_rules():
+    assert mpcqp.move_blocking(10, 3) == [1, 1, 8]
+    assert mpcqp.move_blocking(10, [1, 2, 3, 6, 7]) == [1, 2, 3, 4]
+    assert mpcqp.move_blocking(10, [1, 2]) == [1, 2, 7]
+    with pytest.raises(ValueError):
+        mpcqp.move_blocking(10, [1, 0, 2])
+
+
+@pytest.fixture(scope="session")
+def emulib():
+    d = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", d])
+    lib = mpcqp.api.load_library(os.path.join(d, "libmpcqp_emu.so"))
+    yield lib
+    mpcqp.api._lib = None
+
+
+def _small_case(nd=0, terminal=False, seed=0):
+    rng = np.random.default_rng(seed)
+    A = np.diag([0.8, 0.5]); Bu = rng.standard_normal((2, 1)); C = rng.standard_normal((1, 2))
+    Bd = rng.standard_normal((2, nd)); Dd = rng.standard_normal((1, nd))
+    model = es.LinModelOracle(A, Bu, C, Bd, Dd).setop(uop=[0.5], yop=[2.0], dop=np.full(nd, 0.3))
+    kf = es.SteadyKalmanFilterOracle(model)
+    kw = dict(Hp=6, Hc=[1, 2], Lwt=[0.05])
+    orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, uop=model.uop, yop=model.yop,
+                          dop=model.dop, xhop=kf.xhop, fhop=kf.fhop, **kw)
+    return kf, orc, kw, model
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("nd,terminal", [(0, False), (1, False), (0, True), (1, True)])
+def test_kernel_bodies_on_cpu_emulator(nd, terminal, emulib):
+    kf, orc, kw, model = _small_case(nd, terminal)
+    B = 2
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd) if nd else None,
+                            rep(kf.Dhd) if nd else None, uop=model.uop, yop=model.yop, dop=model.dop,
+                            xhop=kf.xhop, fhop=kf.fhop, lib=emulib, **kw)
+    con = dict(umin=[0.0], umax=[1.2], ymax=[2.4], c_umax=[0.3])
+    orc.setconstraint(dumin=[-0.4], c_dumin=[0.2], dumax=[0.35], **con)
+    gpu.setconstraint(Δumin=[-0.4], c_Δumin=[0.2], Δumax=[0.35], **con)
+    if terminal:
+        orc.setconstraint(xhatmin=[-0.2, -np.inf, -np.inf], xhatmax=[0.25, np.inf, np.inf])
+        gpu.setconstraint(x̂min=[-0.2, -np.inf, -np.inf], x̂max=[0.25, np.inf, np.inf])
+    x0 = np.array([0.4, -0.3, 0.2])
+    d = [0.5] if nd else None
+    Dhat = 0.3 + 0.1 * np.arange(6) if nd else None
+    gpu.initstate([0.6]); orc.lastu0 = np.array([0.1])
+    for k in range(2):                               # second step exercises the warm-start shift
+        ug = gpu.moveinput(np.tile(x0, (B, 1)), [3.0], d, Dhat=Dhat, want_info=True)
+        uo = orc.moveinput(x0, [3.0], d, Dhat=Dhat)
+        assert np.all(gpu.status == 0)
+        assert np.abs(gpu.Z[1] - orc.Zt).max() <= 1e-6 * max(1.0, np.abs(orc.Zt).max())
+        assert np.abs(ug[0] - uo).max() <= 1e-6
+        assert np.abs(gpu.getinfo()["Ŷ"][0] - orc.getinfo()["Ŷ"]).max() <= 1e-6
+        assert np.abs(gpu.getinfo()["U"][0] - orc.getinfo()["U"]).max() <= 1e-6
+
+
+@pytest.mark.slow
+def test_host_argument_validation(emulib):
+    kf, orc, kw, model = _small_case()
+    rep = lambda a: np.broadcast_to(a, (2,) + a.shape).copy()
+    mk = lambda **k: mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), lib=emulib, **{**kw, **k})
+    with pytest.raises(ValueError, match="Hp should be"):
+        mk(Hp=0)
+    with pytest.raises(ValueError, match="nonnegative"):
+        mk(Mwt=[-1.0])
+    with pytest.raises(ValueError, match="Cwt weight"):
+        mk(Cwt=-1.0)
+    mpc = mk(Cwt=np.inf)
+    with pytest.raises(ValueError, match="Cwt must be finite"):
+        mpc.setconstraint(c_umin=[0.1])                  # construct.jl:441
+    with pytest.raises(ValueError, match="size must be"):
+        mpc.setconstraint(umin=[0.0, 1.0])               # DimensionMismatch, construct.jl:357
+    with pytest.raises(ValueError, match="size must be"):
+        mpc.moveinput(np.zeros((2, 3)), [0.0, 0.0, 0.0])  # test/3...:152
+    with pytest.raises(ValueError, match="size must be"):
+        mpc.moveinput(np.zeros((2, 3)), [0.0], Rhaty=np.zeros(7))
+    mpc = mk()
+    mpc.setconstraint(umax=[1.0])
+    mpc.moveinput(np.zeros((2, 3)), [2.0])
+    with pytest.raises(RuntimeError, match="softness"):
+        mpc.setconstraint(c_umax=[0.1])                  # construct.jl:443
+    with pytest.raises(RuntimeError, match="Inf"):
+        mpc.setconstraint(umax=[np.inf])                 # construct.jl:549-551
