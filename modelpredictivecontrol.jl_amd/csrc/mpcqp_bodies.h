@@ -27,18 +27,57 @@
 namespace mpcqp {
 
 // ------------------------------------------------------------------------------------------
-// LDS carve-up of one problem (all doubles unless stated).  Same function on host (to size the
-// dynamic LDS) and device.
+// Compile-time dimensions: same member names as the runtime `Dims`, so the bodies below are
+// written once against a dims policy DM.  Specialised kernels (mpcqp_dispatch.h) give the
+// compiler constant trip counts everywhere and let the per-row IPM state live in registers.
+// Restrictions of a specialisation: nd = 0, default move blocking nb = [1,..,1,Hp-Hc+1].
 // ------------------------------------------------------------------------------------------
+template <int NU, int NY, int NXH, int HP, int HC, int NEPS, unsigned GMASK>
+struct StaticDims {
+    static constexpr bool is_static = true;
+    static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS, nd = 0;
+    static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP, nD = 0;
+    static constexpr int npk = nZ * (nZ + 1) / 2;
+    static constexpr uint32_t gmask = GMASK;
+    static constexpr int default_nb = 1;
+    int B, max_iter;
+    double gap_tol, res_tol, dual_reg;
+    uint32_t flags;
+    MPCQP_HD static constexpr int cnt(int p) {
+        return p == P_BOX ? nZ : p == P_U ? nU : p == P_DU ? nDU : p == P_Y ? nY : nxh;
+    }
+    MPCQP_HD static constexpr int rowoff(int g) {
+        int o = 0;
+        for (int i = 0; i < g; ++i)
+            if ((GMASK >> i) & 1u) o += cnt(i >> 1);
+        return o;
+    }
+    MPCQP_HD static constexpr int nrows() { return rowoff(NGROUP); }
+    MPCQP_HD explicit StaticDims(const Dims& d)
+        : B(d.B), max_iter(d.max_iter), gap_tol(d.gap_tol), res_tol(d.res_tol),
+          dual_reg(d.dual_reg), flags(d.flags) {}
+    static bool matches(const Dims& d) {
+        return d.nu == NU && d.ny == NY && d.nxh == NXH && d.Hp == HP && d.Hc == HC &&
+               d.neps == NEPS && d.gmask == GMASK && d.nd == 0 && d.default_nb == 1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// LDS carve-up of one problem (all doubles unless stated).  Same function on host (to size the
+// dynamic LDS) and device.  Row arrays exist only for runtime dims (registers otherwise).
+// ------------------------------------------------------------------------------------------
+constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs
+
 struct Carve {
     int S, Phi, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT;
-    int h, s, lam, rp, gd, pp; // row arrays
+    int rows[NROWARR];
     int jl, blk;               // int tables (offset in doubles, storage as int)
     int total;                 // doubles
 };
 
-MPCQP_HD inline Carve make_carve(const Dims& d) {
-    Carve c;
+template <class DM>
+MPCQP_HD inline Carve make_carve(const DM& d) {
+    Carve c{};
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
     c.S = take(d.Hp * d.ny * d.nu);
@@ -47,18 +86,20 @@ MPCQP_HD inline Carve make_carve(const Dims& d) {
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
     c.zlo = take(d.nZ); c.zhi = take(d.nZ); c.gt = take(d.nZ); c.rd = take(d.nZ);
     c.F = take(d.nY);
+    MPCQP_UNROLL
     for (int p = 0; p < NPAIR; ++p) {
-        bool on = (d.gmask >> (2 * p)) & 3u;
+        const bool on = (d.gmask >> (2 * p)) & 3u;
         // pair Y's tA doubles as the E*v scratch, so it always exists
-        c.tA[p] = take((on || p == P_Y) ? d.cnt[p] : 0);
-        c.tB[p] = take((on && p != P_BOX) ? d.cnt[p] : 0);
+        c.tA[p] = take((on || p == P_Y) ? d.cnt(p) : 0);
+        c.tB[p] = take((on && p != P_BOX) ? d.cnt(p) : 0);
     }
     c.ucum = take(d.nDU);
     c.exT = take(((d.gmask >> (2 * P_X)) & 3u) ? d.Hc * d.nxh * d.nu : 0);
-    int M = d.rowoff[NGROUP];
-    c.h = take(M); c.s = take(M); c.lam = take(M); c.rp = take(M); c.gd = take(M); c.pp = take(M);
-    c.jl = take((d.Hc + 2) / 2 + 1);
-    c.blk = take((d.Hp + 1) / 2 + 1);
+    const int M = DM::is_static ? 0 : d.nrows();
+    MPCQP_UNROLL
+    for (int a = 0; a < NROWARR; ++a) c.rows[a] = take(M);
+    c.jl = take(DM::is_static ? 0 : (d.Hc + 2) / 2 + 1);
+    c.blk = take(DM::is_static ? 0 : (d.Hp + 1) / 2 + 1);
     c.total = o;
     return c;
 }
@@ -66,34 +107,39 @@ MPCQP_HD inline Carve make_carve(const Dims& d) {
 // ------------------------------------------------------------------------------------------
 // condensed problem resident in LDS + structured products with E, Pu, ex̂
 // ------------------------------------------------------------------------------------------
-template <class W>
+template <class W, class DM>
 struct Qp {
     W& w;
-    const Dims& d;
+    const DM& d;
     const Model& m;
     const int b;        // problem index
     double* sm;         // LDS base
     Carve c;
-    int *jl, *blk;
+    int *jlt, *blkt;
     double *S, *Phi;
 
-    MPCQP_HD Qp(W& w_, const Dims& d_, const Model& m_, int b_, double* sm_)
+    MPCQP_HD Qp(W& w_, const DM& d_, const Model& m_, int b_, double* sm_)
         : w(w_), d(d_), m(m_), b(b_), sm(sm_), c(make_carve(d_)) {
-        jl = reinterpret_cast<int*>(sm + c.jl);
-        blk = reinterpret_cast<int*>(sm + c.blk);
+        jlt = reinterpret_cast<int*>(sm + c.jl);
+        blkt = reinterpret_cast<int*>(sm + c.blk);
         S = sm + c.S;
         Phi = sm + c.Phi;
     }
 
     MPCQP_HD bool pair_on(int p) const { return (d.gmask >> (2 * p)) & 3u; }
     MPCQP_HD bool group_on(int g) const { return (d.gmask >> g) & 1u; }
+    // move blocking tables: j_l and the block that holds step t
+    MPCQP_HD int jl(int j) const { return d.default_nb ? j : jlt[j]; }
+    MPCQP_HD int blk(int t) const { return d.default_nb ? (t < d.Hc - 1 ? t : d.Hc - 1) : blkt[t]; }
 
     MPCQP_HD void load_tables() {
         const int ns = d.Hp * d.ny * d.nu;
         const double* g = m.Stab + (size_t)b * ns;
         for (int i = w.lane; i < ns; i += WAVE) S[i] = g[i];
-        for (int i = w.lane; i <= d.Hc; i += WAVE) jl[i] = m.jl[i];
-        for (int i = w.lane; i < d.Hp; i += WAVE) blk[i] = m.blk[i];
+        if (!DM::is_static) {
+            for (int i = w.lane; i <= d.Hc; i += WAVE) jlt[i] = m.jl[i];
+            for (int i = w.lane; i < d.Hp; i += WAVE) blkt[i] = m.blk[i];
+        }
         if (pair_on(P_X)) {
             const int ne = d.Hc * d.nxh * d.nu;
             const double* e = m.exT + (size_t)b * ne;
@@ -102,20 +148,14 @@ struct Qp {
         w.sync();
     }
 
-    // E[(t,a),(j,c)]  (block-Toeplitz accessor)
-    MPCQP_HD double Eat(int t, int a, int j, int cc) const {
-        int dt = t - jl[j];
-        return dt >= 0 ? S[(dt * d.ny + a) * d.nu + cc] : 0.0;
-    }
-
     // out[r] = sum_k E[r,k] v[k]   (r < nY; v has >= nDU entries)
     MPCQP_HD void E_apply(const double* v, double* out) {
         const int ny = d.ny, nu = d.nu;
         for (int r = w.lane; r < d.nY; r += WAVE) {
-            int t = r / ny, a = r - t * ny;
+            const int t = r / ny, a = r - t * ny;
             double acc = 0.0;
-            for (int j = 0; j < d.Hc && jl[j] <= t; ++j) {
-                const double* Sb = S + ((t - jl[j]) * ny + a) * nu;
+            for (int j = 0; j < d.Hc && jl(j) <= t; ++j) {
+                const double* Sb = S + ((t - jl(j)) * ny + a) * nu;
                 const double* vj = v + j * nu;
                 for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * vj[cc];
             }
@@ -123,14 +163,14 @@ struct Qp {
         }
     }
 
-    // out[k] += sum_r E[r,k] wv[r]   (k < nDU)
+    // out[k] += scale * sum_r E[r,k] wv[r]   (k < nDU)
     MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0) {
         const int ny = d.ny, nu = d.nu;
         for (int k = w.lane; k < d.nDU; k += WAVE) {
-            int j = k / nu, cc = k - j * nu;
+            const int j = k / nu, cc = k - j * nu;
             double acc = 0.0;
-            for (int t = jl[j]; t < d.Hp; ++t) {
-                const double* Sb = S + ((t - jl[j]) * ny) * nu + cc;
+            for (int t = jl(j); t < d.Hp; ++t) {
+                const double* Sb = S + ((t - jl(j)) * ny) * nu + cc;
                 const double* wt = wv + t * ny;
                 for (int a = 0; a < ny; ++a) acc += Sb[a * nu] * wt[a];
             }
@@ -138,18 +178,23 @@ struct Qp {
         }
     }
 
+    // idx (packed lower triangle of the ΔU block) -> (i, i'), i >= i'
+    MPCQP_HD static void unpack_idx(int idx, int& i, int& ip) {
+        i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > idx) --i;
+        while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+        ip = idx - i * (i + 1) / 2;
+    }
+
     // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU)
     MPCQP_HD void EtDE_add(const double* dd, double* P, double scale = 1.0) {
         const int ny = d.ny, nu = d.nu, nDU = d.nDU;
         const int ntri = nDU * (nDU + 1) / 2;
         for (int idx = w.lane; idx < ntri; idx += WAVE) {
-            // idx -> (i, i') with i >= i'
-            int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-            while (i * (i + 1) / 2 > idx) --i;
-            while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-            int ip = idx - i * (i + 1) / 2;
-            int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
-            int t0 = jl[j], off2 = jl[j] - jl[j2];       // j >= j2  =>  jl[j] >= jl[j2]
+            int i, ip;
+            unpack_idx(idx, i, ip);
+            const int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
+            const int t0 = jl(j), off2 = jl(j) - jl(j2);       // j >= j2  =>  jl[j] >= jl[j2]
             double acc = 0.0;
             for (int t = t0; t < d.Hp; ++t) {
                 const double* S1 = S + ((t - t0) * ny) * nu + cc;
@@ -163,7 +208,7 @@ struct Qp {
 
     // ex̂[i,(j,c)]
     MPCQP_HD double Xat(int i, int k) const {
-        int j = k / d.nu, cc = k - j * d.nu;
+        const int j = k / d.nu, cc = k - j * d.nu;
         return sm[c.exT + (j * d.nxh + i) * d.nu + cc];
     }
 };
@@ -309,7 +354,7 @@ MPCQP_HD void predmat_body(W& w, const Dims& d, const Model& m, int b, double* s
 // ------------------------------------------------------------------------------------------
 template <class W>
 MPCQP_HD void hessian_body(W& w, const Dims& d, const Model& m, int b, double* sm) {
-    Qp<W> qp(w, d, m, b, sm);
+    Qp<W, Dims> qp(w, d, m, b, sm);
     qp.load_tables();
     double* P = qp.Phi;
     double* tY = sm + qp.c.tA[P_Y];
@@ -323,14 +368,13 @@ MPCQP_HD void hessian_body(W& w, const Dims& d, const Model& m, int b, double* s
     const double* L = m.Ldiag + (size_t)b * d.nU;
     const int ntri = d.nDU * (d.nDU + 1) / 2;
     for (int idx = w.lane; idx < ntri; idx += WAVE) {
-        int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-        while (i * (i + 1) / 2 > idx) --i;
-        while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-        int ip = idx - i * (i + 1) / 2;
+        int i, ip;
+        Qp<W, Dims>::unpack_idx(idx, i, ip);
         int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
+        (void)j2;
         double acc = 0.0;
         if (cc == c2)
-            for (int t = qp.jl[j]; t < d.Hp; ++t) acc += L[t * nu + cc];
+            for (int t = qp.jl(j); t < d.Hp; ++t) acc += L[t * nu + cc];
         if (i == ip) acc += m.Ndiag[(size_t)b * d.nDU + i];     // 2 N
         P[idx] += 2.0 * acc;
     }
@@ -341,33 +385,79 @@ MPCQP_HD void hessian_body(W& w, const Dims& d, const Model& m, int b, double* s
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-row interior-point state.  A row (group g, local index k) is owned by lane k % 64, and so
+// is primitive k of its pair: every access to row state is lane-local.  Runtime dims keep the
+// arrays in LDS; compile-time dims keep them in registers (slots resolved by full unrolling).
+// ------------------------------------------------------------------------------------------
+struct Row {
+    double &h, &s, &lam, &rp, &gd, &pp, &cs;
+};
+
+template <class DM, bool STATIC = DM::is_static>
+struct RowStore;
+
+template <class DM>
+struct RowStore<DM, false> {
+    double* a[NROWARR];
+    const DM& d;
+    int lane;
+    MPCQP_HD RowStore(const DM& d_, double* sm, const Carve& c, int lane_) : d(d_), lane(lane_) {
+        for (int i = 0; i < NROWARR; ++i) a[i] = sm + c.rows[i];
+    }
+    MPCQP_HD int qmax(int g) const { return (d.cnt(g >> 1) + WAVE - 1) / WAVE; }
+    MPCQP_HD Row at(int g, int q) {
+        const int r = d.rowoff(g) + lane + WAVE * q;
+        return Row{a[0][r], a[1][r], a[2][r], a[3][r], a[4][r], a[5][r], a[6][r]};
+    }
+};
+
+template <class DM>
+struct RowStore<DM, true> {
+    MPCQP_HD static constexpr int qmax(int g) { return (DM::cnt(g >> 1) + WAVE - 1) / WAVE; }
+    MPCQP_HD static constexpr int slotoff(int g) {
+        int o = 0;
+        for (int i = 0; i < g; ++i)
+            if ((DM::gmask >> i) & 1u) o += qmax(i);
+        return o;
+    }
+    static constexpr int NSLOT = slotoff(NGROUP) > 0 ? slotoff(NGROUP) : 1;
+    double a[NROWARR][NSLOT];
+    MPCQP_HD RowStore(const DM&, double*, const Carve&, int) {}
+    MPCQP_HD Row at(int g, int q) {
+        const int r = slotoff(g) + q;
+        return Row{a[0][r], a[1][r], a[2][r], a[3][r], a[4][r], a[5][r], a[6][r]};
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // K3: one control period of one controller.
 // ------------------------------------------------------------------------------------------
-template <class W>
+template <class W, class DM>
 struct Step {
-    Qp<W>& qp;
+    Qp<W, DM>& qp;
     W& w;
-    const Dims& d;
+    const DM& d;
     const Model& m;
     const int b;
     double* sm;
     const Carve& c;
-    double *z, *dz, *q, *zlo, *zhi, *gt, *rd, *F, *h, *s, *lam, *rp, *gd, *pp, *invd, *Phi;
+    RowStore<DM> rows;
+    double *z, *dz, *q, *zlo, *zhi, *gt, *rd, *F, *invd, *Phi;
     int mact;           // number of finite rows
     double nh;          // 1 + max |h|
     double delta;
 
-    MPCQP_HD Step(Qp<W>& qp_)
-        : qp(qp_), w(qp_.w), d(qp_.d), m(qp_.m), b(qp_.b), sm(qp_.sm), c(qp_.c) {
+    MPCQP_HD Step(Qp<W, DM>& qp_)
+        : qp(qp_), w(qp_.w), d(qp_.d), m(qp_.m), b(qp_.b), sm(qp_.sm), c(qp_.c),
+          rows(qp_.d, qp_.sm, qp_.c, qp_.w.lane) {
         z = sm + c.z; dz = sm + c.dz; q = sm + c.q; zlo = sm + c.zlo; zhi = sm + c.zhi;
         gt = sm + c.gt; rd = sm + c.rd; F = sm + c.F;
-        h = sm + c.h; s = sm + c.s; lam = sm + c.lam; rp = sm + c.rp; gd = sm + c.gd; pp = sm + c.pp;
         invd = sm + c.invd; Phi = qp.Phi;
         delta = d.dual_reg;
     }
 
-    // softness coefficient of local row k of group g (reference defaults when pointer null)
-    MPCQP_HD double soft(int g, int k) const {
+    // reference default softness: 0 for u and Δu, 1 for y and x̂end (construct.jl:909-913)
+    MPCQP_HD double soft_init(int g, int k) const {
         if (!d.neps) return 0.0;
         const double* p = nullptr;
         double def = 0.0;
@@ -382,17 +472,55 @@ struct Step {
             case 2 * P_X + 1: p = m.c_x0max; def = 1.0; break;
             default: return 0.0;
         }
-        return p ? p[(size_t)b * d.cnt[g >> 1] + k] : def;
+        return p ? p[(size_t)b * d.cnt(g >> 1) + k] : def;
     }
 
+    // fn(group, local index, Row&) for every row owned by this lane
     template <class Fn>
-    MPCQP_HD void for_rows(Fn fn) {     // fn(row, group, local)
+    MPCQP_HD void for_rows(Fn fn) {
+        MPCQP_UNROLL
         for (int g = 0; g < NGROUP; ++g) {
             if (!qp.group_on(g)) continue;
-            const int n = d.cnt[g >> 1], off = d.rowoff[g];
-            for (int k = w.lane; k < n; k += WAVE) fn(off + k, g, k);
+            const int n = d.cnt(g >> 1);
+            MPCQP_UNROLL
+            for (int qq = 0; qq < rows.qmax(g); ++qq) {
+                const int k = w.lane + WAVE * qq;
+                if (k < n) {
+                    Row r = rows.at(g, qq);
+                    fn(g, k, r);
+                }
+            }
         }
     }
+
+    // fn(pair, k, rmin*, rmax*) for every primitive owned by this lane (null = group off)
+    template <class Fn>
+    MPCQP_HD void for_pairs(Fn fn) {
+        MPCQP_UNROLL
+        for (int p = 0; p < NPAIR; ++p) {
+            if (!qp.pair_on(p)) continue;
+            const int n = d.cnt(p);
+            const bool gmin = qp.group_on(2 * p), gmax = qp.group_on(2 * p + 1);
+            MPCQP_UNROLL
+            for (int qq = 0; qq < rows.qmax(2 * p); ++qq) {
+                const int k = w.lane + WAVE * qq;
+                if (k < n) {
+                    if (gmin && gmax) {
+                        Row r0 = rows.at(2 * p, qq), r1 = rows.at(2 * p + 1, qq);
+                        fn(p, k, &r0, &r1);
+                    } else if (gmin) {
+                        Row r0 = rows.at(2 * p, qq);
+                        fn(p, k, &r0, (Row*)nullptr);
+                    } else {
+                        Row r1 = rows.at(2 * p + 1, qq);
+                        fn(p, k, (Row*)nullptr, &r1);
+                    }
+                }
+            }
+        }
+    }
+
+    MPCQP_HD static bool fin(const Row& r) { return r.h < BIG; }
 
     // ---- free response, gradient, right-hand sides (initpred!, linconstraint!) -------------
     MPCQP_HD void build(const StepIO& io) {
@@ -403,7 +531,7 @@ struct Step {
         const double* Bv = m.Bvec + (size_t)b * nY;
         // F = B + K x̂0 + V lastu0 (+ G d0 + J D̂0)           execute.jl:249-255
         for (int r = w.lane; r < nY; r += WAVE) {
-            int t = r / ny, a = r - t * ny;
+            const int t = r / ny, a = r - t * ny;
             double acc = Bv[r];
             for (int k = 0; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
             const double* Sb = qp.S + (t * ny + a) * nu;        // V block t = Σ_t
@@ -428,7 +556,7 @@ struct Step {
         const double* Md = m.Mdiag + (size_t)b * nY;
         const bool rconst = d.flags & 1u;
         for (int r = w.lane; r < nY; r += WAVE) {
-            double ry = rconst ? io.Ry[(size_t)b * ny + (r % ny)] : io.Ry[(size_t)b * nY + r];
+            const double ry = rconst ? io.Ry[(size_t)b * ny + (r % ny)] : io.Ry[(size_t)b * nY + r];
             tY[r] = Md[r] * (F[r] - ry);
         }
         for (int k = w.lane; k < d.nZ; k += WAVE) q[k] = 0.0;
@@ -436,10 +564,10 @@ struct Step {
         qp.Et_apply_add(tY, q, 2.0);
         const double* Ld = m.Ldiag + (size_t)b * d.nU;
         for (int k = w.lane; k < d.nDU; k += WAVE) {
-            int j = k / nu, cc = k - j * nu;
+            const int j = k / nu, cc = k - j * nu;
             double acc = 0.0;
-            for (int t = qp.jl[j]; t < d.Hp; ++t) {
-                double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cc] : 0.0;
+            for (int t = qp.jl(j); t < d.Hp; ++t) {
+                const double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cc] : 0.0;
                 acc += Ld[t * nu + cc] * (lu[cc] - ru);
             }
             q[k] += 2.0 * acc;       // same lane wrote q[k] in Et_apply_add
@@ -484,9 +612,9 @@ struct Step {
         // b vector, finite rows only (linconstraint!, transcription.jl:824-842 and i_b :692-700)
         int cntl = 0;
         double hmax = 0.0;
-        for_rows([&](int row, int g, int k) {
+        for_rows([&](int g, int k, Row& r) {
             double bound = INFINITY;
-            size_t o = (size_t)b * d.cnt[g >> 1] + k;
+            const size_t o = (size_t)b * d.cnt(g >> 1) + k;
             switch (g) {
                 case 0: bound = -zlo[k]; break;
                 case 1: bound = zhi[k]; break;
@@ -504,10 +632,11 @@ struct Step {
                 case 2 * P_X + 1: if (m.x0max) bound = m.x0max[o] - fx[k]; break;
             }
             const bool ok = fabs(bound) < BIG && bound == bound;
-            h[row] = ok ? bound : 2.0 * BIG;
-            s[row] = 1.0;
-            lam[row] = ok ? 1.0 : 0.0;
-            pp[row] = 0.0;
+            r.h = ok ? bound : 2.0 * BIG;
+            r.s = 1.0;
+            r.lam = ok ? 1.0 : 0.0;
+            r.rp = 0.0; r.gd = 0.0; r.pp = 0.0;
+            r.cs = soft_init(g, k);
             if (ok) { ++cntl; hmax = fmax(hmax, fabs(bound)); }
         });
         mact = w.isum(cntl);
@@ -515,67 +644,65 @@ struct Step {
         w.sync();
     }
 
-    MPCQP_HD bool fin(int row) const { return h[row] < BIG; }
-
-    // ---- out = G v  (v in LDS, nZ entries; out is a row array) --------------------------------
-    MPCQP_HD void apply_G(const double* v, double* out) {
+    // ---- primitives of G v: ucum (held cumulative sum), tY = E v, tX = ex̂ v ------------------
+    MPCQP_HD void primitives(const double* v) {
         const int nu = d.nu;
-        double* ucum = sm + c.ucum;
-        double* tY = sm + c.tA[P_Y];
-        double* tX = sm + c.tA[P_X];
-        if (qp.pair_on(P_U))
+        if (qp.pair_on(P_U)) {
+            double* ucum = sm + c.ucum;
             for (int k = w.lane; k < d.nDU; k += WAVE) {
-                int j = k / nu, cc = k - j * nu;
+                const int j = k / nu, cc = k - j * nu;
                 double acc = 0.0;
                 for (int jj = 0; jj <= j; ++jj) acc += v[jj * nu + cc];
                 ucum[k] = acc;
             }
-        if (qp.pair_on(P_Y)) qp.E_apply(v, tY);
-        if (qp.pair_on(P_X))
+        }
+        if (qp.pair_on(P_Y)) qp.E_apply(v, sm + c.tA[P_Y]);
+        if (qp.pair_on(P_X)) {
+            double* tX = sm + c.tA[P_X];
             for (int i = w.lane; i < d.nxh; i += WAVE) {
                 double acc = 0.0;
                 for (int k = 0; k < d.nDU; ++k) acc += qp.Xat(i, k) * v[k];
                 tX[i] = acc;
             }
-        w.sync();
-        const double e = d.neps ? v[d.nZ - 1] : 0.0;
-        for_rows([&](int row, int g, int k) {
-            if (!fin(row)) { out[row] = 0.0; return; }
-            double prim;
-            switch (g >> 1) {
-                case P_BOX: prim = v[k]; break;
-                case P_U: prim = ucum[qp.blk[k / nu] * nu + (k % nu)]; break;
-                case P_DU: prim = v[k]; break;
-                case P_Y: prim = tY[k]; break;
-                default: prim = tX[k]; break;
-            }
-            out[row] = ((g & 1) ? prim : -prim) - soft(g, k) * e;
-        });
+        }
         w.sync();
     }
 
-    // ---- gt = G' wv, wv(row) given by functor (only called on finite rows) --------------------
+    MPCQP_HD double prim(int p, int k, const double* v) const {
+        switch (p) {
+            case P_BOX: return v[k];
+            case P_U: return sm[c.ucum + qp.blk(k / d.nu) * d.nu + (k % d.nu)];
+            case P_DU: return v[k];
+            case P_Y: return sm[c.tA[P_Y] + k];
+            default: return sm[c.tA[P_X] + k];
+        }
+    }
+
+    // ---- fn(Row&, (G v)[row]) for every finite row -------------------------------------------
+    template <class Fn>
+    MPCQP_HD void apply_G(const double* v, Fn fn) {
+        primitives(v);
+        const double e = d.neps ? v[d.nZ - 1] : 0.0;
+        for_rows([&](int g, int k, Row& r) {
+            if (!fin(r)) return;
+            const double pv = prim(g >> 1, k, v);
+            fn(r, ((g & 1) ? pv : -pv) - r.cs * e);
+        });
+        w.sync();    // tA[P_Y]/ucum are reused by the next product
+    }
+
+    // ---- gt = G' wv, wv(Row&) evaluated on finite rows ---------------------------------------
     template <class Fn>
     MPCQP_HD void apply_Gt(Fn wv) {
         const int nu = d.nu;
         // per pair: tA[k] = w_max - w_min ; eps accumulates -(c_min w_min + c_max w_max)
         double eacc = 0.0;
-        for (int p = 0; p < NPAIR; ++p) {
-            if (!qp.pair_on(p)) continue;
-            double* tA = sm + c.tA[p];
-            const int n = d.cnt[p];
-            const bool gmin = qp.group_on(2 * p), gmax = qp.group_on(2 * p + 1);
-            for (int k = w.lane; k < n; k += WAVE) {
-                double wmin = 0.0, wmax = 0.0;
-                if (gmin && fin(d.rowoff[2 * p] + k)) wmin = wv(d.rowoff[2 * p] + k);
-                if (gmax && fin(d.rowoff[2 * p + 1] + k)) wmax = wv(d.rowoff[2 * p + 1] + k);
-                tA[k] = wmax - wmin;
-                if (p != P_BOX && d.neps)
-                    eacc -= soft(2 * p, k) * wmin + soft(2 * p + 1, k) * wmax;
-            }
-        }
-        if (!qp.pair_on(P_Y))       // tA[P_Y] is always allocated (scratch) but must read as 0
-            for (int k = w.lane; k < d.nY; k += WAVE) sm[c.tA[P_Y] + k] = 0.0;
+        for_pairs([&](int p, int k, Row* r0, Row* r1) {
+            double wmin = 0.0, wmax = 0.0;
+            if (r0 && fin(*r0)) { wmin = wv(*r0); eacc -= r0->cs * wmin; }
+            if (r1 && fin(*r1)) { wmax = wv(*r1); eacc -= r1->cs * wmax; }
+            sm[c.tA[p] + k] = wmax - wmin;
+        });
         eacc = w.sum(eacc);
         w.sync();
         for (int k = w.lane; k < d.nZ; k += WAVE) {
@@ -584,9 +711,9 @@ struct Step {
             if (k < d.nDU) {
                 if (qp.pair_on(P_DU)) acc += sm[c.tA[P_DU] + k];
                 if (qp.pair_on(P_U)) {
-                    int j = k / nu, cc = k - j * nu;
+                    const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tA[P_U];
-                    for (int t = qp.jl[j]; t < d.Hp; ++t) acc += tU[t * nu + cc];
+                    for (int t = qp.jl(j); t < d.Hp; ++t) acc += tU[t * nu + cc];
                 }
                 if (qp.pair_on(P_X)) {
                     const double* tX = sm + c.tA[P_X];
@@ -601,31 +728,28 @@ struct Step {
         w.sync();
     }
 
-    // ---- Phi = H̃ + G' diag(dd) G, dd(row) given by functor ------------------------------------
-    template <class Fn>
-    MPCQP_HD void form_phi(Fn dd) {
-        const int nu = d.nu, nDU = d.nDU, nZ = d.nZ;
+    // ---- Phi <- H̃ (global -> LDS), hz = H̃ z per lane ----------------------------------------
+    MPCQP_HD void load_H() {
         const double* H = m.Hpk + (size_t)b * d.npk;
         for (int i = w.lane; i < d.npk; i += WAVE) Phi[i] = H[i];
+        w.sync();
+    }
+
+    // ---- Phi += G' diag(dd) G, dd(Row&) evaluated on finite rows ------------------------------
+    template <class Fn>
+    MPCQP_HD void add_GtDG(Fn dd) {
+        const int nu = d.nu, nDU = d.nDU, nZ = d.nZ;
         double ee = 0.0;
-        for (int p = 0; p < NPAIR; ++p) {
-            if (!qp.pair_on(p)) continue;
-            double* tA = sm + c.tA[p];
-            double* tB = sm + c.tB[p];
-            const int n = d.cnt[p];
-            const bool gmin = qp.group_on(2 * p), gmax = qp.group_on(2 * p + 1);
-            for (int k = w.lane; k < n; k += WAVE) {
-                double dmin = 0.0, dmax = 0.0;
-                if (gmin && fin(d.rowoff[2 * p] + k)) dmin = dd(d.rowoff[2 * p] + k);
-                if (gmax && fin(d.rowoff[2 * p + 1] + k)) dmax = dd(d.rowoff[2 * p + 1] + k);
-                tA[k] = dmin + dmax;
-                if (p != P_BOX) {
-                    double cmin = soft(2 * p, k), cmax = soft(2 * p + 1, k);
-                    tB[k] = cmin * dmin - cmax * dmax;
-                    ee += cmin * cmin * dmin + cmax * cmax * dmax;
-                }
+        for_pairs([&](int p, int k, Row* r0, Row* r1) {
+            double dmin = 0.0, dmax = 0.0, cmin = 0.0, cmax = 0.0;
+            if (r0 && fin(*r0)) { dmin = dd(*r0); cmin = r0->cs; }
+            if (r1 && fin(*r1)) { dmax = dd(*r1); cmax = r1->cs; }
+            sm[c.tA[p] + k] = dmin + dmax;
+            if (p != P_BOX) {
+                sm[c.tB[p] + k] = cmin * dmin - cmax * dmax;
+                ee += cmin * cmin * dmin + cmax * cmax * dmax;
             }
-        }
+        });
         ee = w.sum(ee);
         w.sync();
         // dense E' dY E
@@ -635,16 +759,14 @@ struct Step {
         const bool onU = qp.pair_on(P_U), onX = qp.pair_on(P_X);
         if (onU || onX)
             for (int idx = w.lane; idx < ntri; idx += WAVE) {
-                int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                while (i * (i + 1) / 2 > idx) --i;
-                while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-                int ip = idx - i * (i + 1) / 2;
+                int i, ip;
+                Qp<W, DM>::unpack_idx(idx, i, ip);
                 double acc = 0.0;
                 if (onU) {
-                    int j = i / nu, cc = i - j * nu, c2 = ip % nu;
+                    const int j = i / nu, cc = i - j * nu, c2 = ip % nu;
                     if (cc == c2) {
                         const double* tU = sm + c.tA[P_U];
-                        for (int t = qp.jl[j]; t < d.Hp; ++t) acc += tU[t * nu + cc];   // j >= j'
+                        for (int t = qp.jl(j); t < d.Hp; ++t) acc += tU[t * nu + cc];   // j >= j'
                     }
                 }
                 if (onX) {
@@ -668,9 +790,9 @@ struct Step {
                 double acc = 0.0;
                 if (qp.pair_on(P_DU)) acc += sm[c.tB[P_DU] + k];
                 if (qp.pair_on(P_U)) {
-                    int j = k / nu, cc = k - j * nu;
+                    const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tB[P_U];
-                    for (int t = qp.jl[j]; t < d.Hp; ++t) acc += tU[t * nu + cc];
+                    for (int t = qp.jl(j); t < d.Hp; ++t) acc += tU[t * nu + cc];
                 }
                 if (qp.pair_on(P_X)) {
                     const double* tX = sm + c.tB[P_X];
@@ -729,15 +851,24 @@ struct Step {
         w.sync();
     }
 
-    // ---- rd = H̃ z + q + G' lam ; returns |rd|_inf and the size of its terms --------------------
-    MPCQP_HD void dual_residual(double& rdn, double& nd_) {
+    // ---- rp, mu ; then rd = H̃ z + q + G' lam with H̃ freshly staged in Phi ---------------------
+    MPCQP_HD void residuals(double& mu, double& rpn, double& rdn, double& nd_) {
         const int n = d.nZ;
-        apply_Gt([&](int row) { return lam[row]; });
-        const double* H = m.Hpk + (size_t)b * d.npk;
+        double musum = 0.0, rpmax = 0.0;
+        apply_G(z, [&](Row& r, double gz) {
+            const double v = gz + r.s - r.h;
+            r.rp = v;
+            rpmax = fmax(rpmax, fabs(v));
+            musum += r.s * r.lam;
+        });
+        mu = w.sum(musum) / mact;
+        rpn = w.maxv(rpmax);
+        apply_Gt([&](Row& r) { return r.lam; });
+        load_H();
         double mx = 0.0, sc = 0.0;
         for (int k = w.lane; k < n; k += WAVE) {
             double hz = 0.0;
-            for (int j = 0; j < n; ++j) hz += H[k >= j ? pk(k, j) : pk(j, k)] * z[j];
+            for (int j = 0; j < n; ++j) hz += Phi[k >= j ? pk(k, j) : pk(j, k)] * z[j];
             const double r = hz + q[k] + gt[k];
             rd[k] = r;
             mx = fmax(mx, fabs(r));
@@ -750,38 +881,23 @@ struct Step {
 
     // Row part of one Newton step of the dual-regularised system (D~ = D w, w = 1/(1+δD)):
     //   dl = -w rc/s + D~ (rp + G dz),   ds = -(rc + s dl)/lam
-    MPCQP_HD void row_step(int row, double rc, double& ds, double& dl) const {
-        const double D = lam[row] / s[row], ww = 1.0 / (1.0 + delta * D);
-        dl = -ww * rc / s[row] + D * ww * (rp[row] + gd[row]);
-        ds = -(rc + s[row] * dl) / lam[row];
+    MPCQP_HD void row_step(const Row& r, double rc, double& ds, double& dl) const {
+        const double D = r.lam / r.s, ww = 1.0 / (1.0 + delta * D);
+        dl = -ww * rc / r.s + D * ww * (r.rp + r.gd);
+        ds = -(rc + r.s * dl) / r.lam;
     }
 
-    // (H + G'D~G) dz = -rd + G'(w rc/s - D~ rp); then gd = G dz.  rc(row) given by functor.
+    // (H + G'D~G) dz = -rd + G'(w rc/s - D~ rp); then gd = G dz.  rc(Row&) given by functor.
     template <class Fn>
     MPCQP_HD void newton(Fn rc) {
-        apply_Gt([&](int row) {
-            const double D = lam[row] / s[row], ww = 1.0 / (1.0 + delta * D);
-            return ww * rc(row) / s[row] - D * ww * rp[row];
+        apply_Gt([&](Row& r) {
+            const double D = r.lam / r.s, ww = 1.0 / (1.0 + delta * D);
+            return ww * rc(r) / r.s - D * ww * r.rp;
         });
         for (int k = w.lane; k < d.nZ; k += WAVE) gt[k] -= rd[k];
         w.sync();
         solve_into_dz();
-        apply_G(dz, gd);
-    }
-
-    MPCQP_HD void residuals(double& mu, double& rpn) {
-        apply_G(z, rp);
-        double musum = 0.0, rpmax = 0.0;
-        for_rows([&](int row, int, int) {
-            if (!fin(row)) return;
-            const double r = rp[row] + s[row] - h[row];
-            rp[row] = r;
-            rpmax = fmax(rpmax, fabs(r));
-            musum += s[row] * lam[row];
-        });
-        mu = w.sum(musum) / mact;
-        rpn = w.maxv(rpmax);
-        w.sync();
+        apply_G(dz, [&](Row& r, double g) { r.gd = g; });
     }
 
     MPCQP_HD int run(const StepIO& io, int& iters_out) {
@@ -800,7 +916,7 @@ struct Step {
         w.sync();
         if (mact == 0) {
             // no finite row at all: Z̃ = -H̃^{-1} q̃ (what ExplicitMPC computes, explicitmpc.jl:216)
-            form_phi([&](int) { return 0.0; });
+            load_H();
             cholesky();
             for (int k = w.lane; k < n; k += WAVE) gt[k] = -q[k];
             w.sync();
@@ -814,76 +930,73 @@ struct Step {
         const double zws = (w.lane < n) ? z[w.lane] : 0.0;
         double mu, rpn, rdn, ndd;
         // ---- starting point: affine step from (z, s=1, lam=1), then push into the interior ----
-        residuals(mu, rpn);
-        dual_residual(rdn, ndd);
-        form_phi([&](int row) { return lam[row] / s[row]; });
+        residuals(mu, rpn, rdn, ndd);
+        add_GtDG([&](Row& r) { return r.lam / r.s; });
         cholesky();
-        newton([&](int row) { return s[row] * lam[row]; });
-        for_rows([&](int row, int, int) {
-            if (!fin(row)) return;
+        newton([&](Row& r) { return r.s * r.lam; });
+        for_rows([&](int, int, Row& r) {
+            if (!fin(r)) return;
             double ds, dl;
-            row_step(row, s[row] * lam[row], ds, dl);
-            s[row] = fmax(fabs(s[row] + ds), 1.0);
-            lam[row] = fmax(fabs(lam[row] + dl), 1.0);
+            row_step(r, r.s * r.lam, ds, dl);
+            r.s = fmax(fabs(r.s + ds), 1.0);
+            r.lam = fmax(fabs(r.lam + dl), 1.0);
         });
         for (int k = w.lane; k < n; k += WAVE) z[k] += dz[k];
         w.sync();
         int status = ST_ITERATION_LIMIT;
         int it = 0;
         for (it = 0; it < d.max_iter; ++it) {
-            residuals(mu, rpn);
-            dual_residual(rdn, ndd);
+            residuals(mu, rpn, rdn, ndd);
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
             if (mu <= d.gap_tol && rdn <= d.res_tol * ndd && rpn <= d.res_tol * nh) {
                 status = ST_OPTIMAL;
                 break;
             }
-            form_phi([&](int row) {
-                const double D = lam[row] / s[row];
+            add_GtDG([&](Row& r) {
+                const double D = r.lam / r.s;
                 return D / (1.0 + delta * D);
             });
             cholesky();
             // predictor: rc = s lam
-            newton([&](int row) { return s[row] * lam[row]; });
+            newton([&](Row& r) { return r.s * r.lam; });
             double amin = 1.0;
-            for_rows([&](int row, int, int) {
-                if (!fin(row)) return;
+            for_rows([&](int, int, Row& r) {
+                if (!fin(r)) return;
                 double ds, dl;
-                row_step(row, s[row] * lam[row], ds, dl);
-                if (ds < 0.0) amin = fmin(amin, -s[row] / ds);
-                if (dl < 0.0) amin = fmin(amin, -lam[row] / dl);
+                row_step(r, r.s * r.lam, ds, dl);
+                if (ds < 0.0) amin = fmin(amin, -r.s / ds);
+                if (dl < 0.0) amin = fmin(amin, -r.lam / dl);
+                r.pp = ds * dl;
             });
             const double aaff = w.minv(amin);
             double mas = 0.0;
-            for_rows([&](int row, int, int) {
-                if (!fin(row)) return;
+            for_rows([&](int, int, Row& r) {
+                if (!fin(r)) return;
                 double ds, dl;
-                row_step(row, s[row] * lam[row], ds, dl);
-                mas += (s[row] + aaff * ds) * (lam[row] + aaff * dl);
-                pp[row] = ds * dl;
+                row_step(r, r.s * r.lam, ds, dl);
+                mas += (r.s + aaff * ds) * (r.lam + aaff * dl);
             });
             const double muaff = w.sum(mas) / mact;
             double sig = muaff / mu;
             sig = sig * sig * sig;
             const double smu = sig * mu;
-            w.sync();
             // corrector: rc = s lam + ds_aff dl_aff - sigma mu
-            newton([&](int row) { return s[row] * lam[row] + pp[row] - smu; });
+            newton([&](Row& r) { return r.s * r.lam + r.pp - smu; });
             amin = 1e300;
-            for_rows([&](int row, int, int) {
-                if (!fin(row)) return;
+            for_rows([&](int, int, Row& r) {
+                if (!fin(r)) return;
                 double ds, dl;
-                row_step(row, s[row] * lam[row] + pp[row] - smu, ds, dl);
-                if (ds < 0.0) amin = fmin(amin, -s[row] / ds);
-                if (dl < 0.0) amin = fmin(amin, -lam[row] / dl);
+                row_step(r, r.s * r.lam + r.pp - smu, ds, dl);
+                if (ds < 0.0) amin = fmin(amin, -r.s / ds);
+                if (dl < 0.0) amin = fmin(amin, -r.lam / dl);
             });
             const double alpha = fmin(1.0, 0.99 * w.minv(amin));
-            for_rows([&](int row, int, int) {
-                if (!fin(row)) return;
+            for_rows([&](int, int, Row& r) {
+                if (!fin(r)) return;
                 double ds, dl;
-                row_step(row, s[row] * lam[row] + pp[row] - smu, ds, dl);
-                s[row] += alpha * ds;
-                lam[row] += alpha * dl;
+                row_step(r, r.s * r.lam + r.pp - smu, ds, dl);
+                r.s += alpha * ds;
+                r.lam += alpha * dl;
             });
             for (int k = w.lane; k < n; k += WAVE) z[k] += alpha * dz[k];
             w.sync();
@@ -901,18 +1014,18 @@ struct Step {
     static constexpr int ST_OPTIMAL = 0, ST_ITERATION_LIMIT = 1, ST_ERROR = 2;
 };
 
-template <class W>
-MPCQP_HD void step_body(W& w, const Dims& d, const Model& m, const StepIO& io, int b, double* sm) {
-    Qp<W> qp(w, d, m, b, sm);
+template <class W, class DM>
+MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int b, double* sm) {
+    Qp<W, DM> qp(w, d, m, b, sm);
     qp.load_tables();
-    Step<W> st(qp);
+    Step<W, DM> st(qp);
     st.build(io);
     if ((d.flags & 4u) && io.q_keep) {
         for (int k = w.lane; k < d.nZ; k += WAVE) io.q_keep[(size_t)b * d.nZ + k] = st.q[k];
         for (int r = w.lane; r < d.nY; r += WAVE) io.F_keep[(size_t)b * d.nY + r] = st.F[r];
     }
     int iters = 0;
-    int status = st.run(io, iters);
+    const int status = st.run(io, iters);
     // outputs: Z̃, u0 = Z̃[1:nu] + lastu0 (getinput!), Ŷ0 = Ẽ Z̃ + F (predict!)
     for (int k = w.lane; k < d.nZ; k += WAVE) io.Z[(size_t)b * d.nZ + k] = st.z[k];
     for (int k = w.lane; k < d.nu; k += WAVE)

@@ -91,13 +91,13 @@ const char* mpcqp_last_hip_error(void) { return g_hip_err.c_str(); }
 
 static void layout_rows(mpcqp_handle h) {
     Dims& d = h->d;
-    d.cnt[P_BOX] = d.nZ; d.cnt[P_U] = d.nU; d.cnt[P_DU] = d.nDU; d.cnt[P_Y] = d.nY; d.cnt[P_X] = d.nxh;
+    d.cnt_[P_BOX] = d.nZ; d.cnt_[P_U] = d.nU; d.cnt_[P_DU] = d.nDU; d.cnt_[P_Y] = d.nY; d.cnt_[P_X] = d.nxh;
     int o = 0;
     for (int g = 0; g < NGROUP; ++g) {
-        d.rowoff[g] = o;
-        if ((d.gmask >> g) & 1u) o += d.cnt[g >> 1];
+        d.rowoff_[g] = o;
+        if ((d.gmask >> g) & 1u) o += d.cnt_[g >> 1];
     }
-    d.rowoff[NGROUP] = o;
+    d.rowoff_[NGROUP] = o;
 }
 
 int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
@@ -142,6 +142,9 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     layout_rows(h);
     h->device = in->device;
     h->nb = nb;
+    d.default_nb = 1;
+    for (int i = 0; i < d.Hc; ++i)
+        if (nb[i] != (i == d.Hc - 1 ? d.Hp - d.Hc + 1 : 1)) d.default_nb = 0;
     h->jl.assign(d.Hc + 1, 0);
     for (int i = 0; i < d.Hc; ++i) h->jl[i + 1] = h->jl[i] + nb[i];
     h->blk.assign(d.Hp, 0);

@@ -3,7 +3,10 @@
 // tile, residual/row state) staged in LDS.  Bodies: mpcqp_bodies.h.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mpcqp_bodies.h"
+#include "mpcqp_dispatch.h"
 #include "mpcqp_launch.h"
 
 namespace mpcqp {
@@ -51,6 +54,14 @@ __global__ __launch_bounds__(64) void k_step(Dims d, Model m, StepIO io) {
     step_body(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
 }
 
+// specialised on compile-time dimensions (mpcqp_dispatch.h)
+template <class SD>
+__global__ __launch_bounds__(64) void k_step_s(Dims d, Model m, StepIO io) {
+    DevWave w{(int)threadIdx.x};
+    const SD sd(d);
+    step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem);
+}
+
 // ---- launchers (host) ------------------------------------------------------------------------
 static hipError_t ensure_lds(const void* fn, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
@@ -73,7 +84,27 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
     return hipGetLastError();
 }
 
+static bool force_generic() {
+    static const bool f = [] { const char* e = getenv("MPCQP_FORCE_GENERIC"); return e && e[0] == '1'; }();
+    return f;
+}
+
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
+    if (!force_generic()) {
+#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                        \
+        {                                                                                       \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                               \
+            if (SD::matches(d)) {                                                               \
+                const size_t lds_s = (size_t)make_carve(SD(d)).total * sizeof(double);          \
+                hipError_t e = ensure_lds((const void*)k_step_s<SD>, lds_s);                    \
+                if (e != hipSuccess) return e;                                                  \
+                hipLaunchKernelGGL(k_step_s<SD>, dim3(d.B), dim3(WAVE), lds_s, st, d, m, io);   \
+                return hipGetLastError();                                                       \
+            }                                                                                   \
+        }
+        MPCQP_SPECIALIZATIONS(X)
+#undef X
+    }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_step, lds);
     if (e != hipSuccess) return e;

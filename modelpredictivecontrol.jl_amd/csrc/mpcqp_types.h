@@ -14,8 +14,10 @@
 
 #if defined(__HIPCC__)
 #define MPCQP_HD __host__ __device__
+#define MPCQP_UNROLL _Pragma("unroll")
 #else
 #define MPCQP_HD
+#define MPCQP_UNROLL
 #endif
 
 namespace mpcqp {
@@ -25,16 +27,23 @@ enum { P_BOX = 0, P_U = 1, P_DU = 2, P_Y = 3, P_X = 4, NPAIR = 5, NGROUP = 10 };
 constexpr int WAVE = 64;          // gfx950 wavefront
 constexpr double BIG = 1e300;     // |h| >= BIG  <=>  row absent (bound was +-Inf)
 
+// Runtime dimensions (the generic kernels read these; the specialised kernels take the same
+// values as template constants, see StaticDims in mpcqp_bodies.h).
 struct Dims {
     int B, nxh, nu, ny, nd, Hp, Hc, neps;
     int nZ, nDU, nU, nY, nD;
     int npk;                 // nZ*(nZ+1)/2  (packed lower triangle)
     uint32_t gmask;          // bit g set <=> row group g may hold finite rows (handle level)
-    int rowoff[NGROUP + 1];  // first row of group g in the per-problem row arrays (inactive: empty)
-    int cnt[NPAIR];          // primitives per pair: nZ, nU, nDU, nY, nxh
+    int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
+    int cnt_[NPAIR];         // primitives per pair: nZ, nU, nDU, nY, nxh
+    int default_nb;          // 1 iff nb = [1,..,1,Hp-Hc+1]
     int max_iter;
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
+    static constexpr bool is_static = false;
+    MPCQP_HD int cnt(int p) const { return cnt_[p]; }
+    MPCQP_HD int rowoff(int g) const { return rowoff_[g]; }
+    MPCQP_HD int nrows() const { return rowoff_[NGROUP]; }
 };
 
 // device-resident, per-handle data (all problem-major; "col-major inside a problem" where the

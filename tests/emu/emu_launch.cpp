@@ -4,7 +4,10 @@
 #include <thread>
 #include <vector>
 
+#include <cstdlib>
+
 #include "mpcqp_bodies.h"
+#include "mpcqp_dispatch.h"
 #include "mpcqp_launch.h"
 
 namespace mpcqp {
@@ -80,6 +83,21 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
     return hipSuccess;
 }
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
+    const char* fg = getenv("MPCQP_FORCE_GENERIC");
+    if (!(fg && fg[0] == '1')) {
+#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                       \
+        {                                                                                      \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                              \
+            if (SD::matches(d)) {                                                              \
+                const SD sd(d);                                                                \
+                run_waves(d.B, make_carve(sd).total, [&](EmuWave& w, int b, double* sm) {      \
+                    step_body(w, sd, m, io, b, sm); });                                        \
+                return hipSuccess;                                                             \
+            }                                                                                  \
+        }
+        MPCQP_SPECIALIZATIONS(X)
+#undef X
+    }
     run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { step_body(w, d, m, io, b, sm); });
     return hipSuccess;
 }
