@@ -38,13 +38,16 @@ struct StaticDims {
     static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS, nd = 0;
     static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP, nD = 0;
     static constexpr int npk = nZ * (nZ + 1) / 2;
+    // LDS stride of one Σ_m block: padded so the MFMA operand reads of E'DE (64 lanes = 4 block
+    // columns x NY*NU entries) fall in distinct bank groups (see DESIGN.md "LDS layout")
+    static constexpr int sp = (NY * NU) % 16 == 0 ? NY * NU + 8 : NY * NU;
     static constexpr uint32_t gmask = GMASK;
     static constexpr int default_nb = 1;
     int B, max_iter;
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
     MPCQP_HD static constexpr int cnt(int p) {
-        return p == P_BOX ? nZ : p == P_U ? nU : p == P_DU ? nDU : p == P_Y ? nY : nxh;
+        return p == P_BOX ? nZ : p == P_U ? nDU : p == P_DU ? nDU : p == P_Y ? nY : nxh;
     }
     MPCQP_HD static constexpr int rowoff(int g) {
         int o = 0;
@@ -56,17 +59,18 @@ struct StaticDims {
     MPCQP_HD explicit StaticDims(const Dims& d)
         : B(d.B), max_iter(d.max_iter), gap_tol(d.gap_tol), res_tol(d.res_tol),
           dual_reg(d.dual_reg), flags(d.flags) {}
-    static bool matches(const Dims& d) {
+    static bool matches_dims(const Dims& d) {
         return d.nu == NU && d.ny == NY && d.nxh == NXH && d.Hp == HP && d.Hc == HC &&
-               d.neps == NEPS && d.gmask == GMASK && d.nd == 0 && d.default_nb == 1;
+               d.neps == NEPS && d.nd == 0 && d.default_nb == 1;
     }
+    static bool matches(const Dims& d) { return matches_dims(d) && d.gmask == GMASK; }
 };
 
 // ------------------------------------------------------------------------------------------
 // LDS carve-up of one problem (all doubles unless stated).  Same function on host (to size the
 // dynamic LDS) and device.  Row arrays exist only for runtime dims (registers otherwise).
 // ------------------------------------------------------------------------------------------
-constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs
+constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs (cs only stored with runtime dims)
 
 struct Carve {
     int S, Phi, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT;
@@ -76,11 +80,17 @@ struct Carve {
 };
 
 template <class DM>
+MPCQP_HD inline int stride_S(const DM& d) {
+    if constexpr (DM::is_static) return DM::sp;
+    else return d.ny * d.nu;
+}
+
+template <class DM>
 MPCQP_HD inline Carve make_carve(const DM& d) {
     Carve c{};
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
-    c.S = take(d.Hp * d.ny * d.nu);
+    c.S = take(d.Hp * stride_S(d));
     c.Phi = take(d.npk);
     c.invd = take(d.nZ);
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
@@ -117,9 +127,10 @@ struct Qp {
     Carve c;
     int *jlt, *blkt;
     double *S, *Phi;
+    int sp;             // LDS stride of one Σ_m block (>= ny*nu)
 
     MPCQP_HD Qp(W& w_, const DM& d_, const Model& m_, int b_, double* sm_)
-        : w(w_), d(d_), m(m_), b(b_), sm(sm_), c(make_carve(d_)) {
+        : w(w_), d(d_), m(m_), b(b_), sm(sm_), c(make_carve(d_)), sp(stride_S(d_)) {
         jlt = reinterpret_cast<int*>(sm + c.jl);
         blkt = reinterpret_cast<int*>(sm + c.blk);
         S = sm + c.S;
@@ -133,9 +144,9 @@ struct Qp {
     MPCQP_HD int blk(int t) const { return d.default_nb ? (t < d.Hc - 1 ? t : d.Hc - 1) : blkt[t]; }
 
     MPCQP_HD void load_tables() {
-        const int ns = d.Hp * d.ny * d.nu;
+        const int nb_ = d.ny * d.nu, ns = d.Hp * nb_;
         const double* g = m.Stab + (size_t)b * ns;
-        for (int i = w.lane; i < ns; i += WAVE) S[i] = g[i];
+        for (int i = w.lane; i < ns; i += WAVE) S[(i / nb_) * sp + (i % nb_)] = g[i];
         if (!DM::is_static) {
             for (int i = w.lane; i <= d.Hc; i += WAVE) jlt[i] = m.jl[i];
             for (int i = w.lane; i < d.Hp; i += WAVE) blkt[i] = m.blk[i];
@@ -154,8 +165,9 @@ struct Qp {
         for (int r = w.lane; r < d.nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
             double acc = 0.0;
+            MPCQP_NOUNROLL
             for (int j = 0; j < d.Hc && jl(j) <= t; ++j) {
-                const double* Sb = S + ((t - jl(j)) * ny + a) * nu;
+                const double* Sb = S + (t - jl(j)) * sp + a * nu;
                 const double* vj = v + j * nu;
                 for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * vj[cc];
             }
@@ -169,8 +181,9 @@ struct Qp {
         for (int k = w.lane; k < d.nDU; k += WAVE) {
             const int j = k / nu, cc = k - j * nu;
             double acc = 0.0;
+            MPCQP_UNROLL4
             for (int t = jl(j); t < d.Hp; ++t) {
-                const double* Sb = S + ((t - jl(j)) * ny) * nu + cc;
+                const double* Sb = S + (t - jl(j)) * sp + cc;
                 const double* wt = wv + t * ny;
                 for (int a = 0; a < ny; ++a) acc += Sb[a * nu] * wt[a];
             }
@@ -186,8 +199,73 @@ struct Qp {
         ip = idx - i * (i + 1) / 2;
     }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    // E' diag(dd) E on the matrix cores: the one genuine contraction of the path
+    // (nDU x nY x nDU).  v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k][j = lane&15],
+    // D[row = (lane>>4) + 4 reg][col = lane&15].  K runs over the rows r = (t, a) of E four at a
+    // time; the 16-wide tiles run over the ΔU index; E is never formed -- operands come straight
+    // from the block-Toeplitz table, and tiles whose block columns start after step t are skipped.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ void EtDE_add_mfma(const double* dd, double* P, double scale) {
+        constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp;
+        constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
+        const int li = w.lane & 15, lk = w.lane >> 4;
+        int offI[NT], jI[NT];
+        MPCQP_UNROLL
+        for (int I = 0; I < NT; ++I) {
+            const int i = 16 * I + li;
+            const int j = i / NU, cc = i - j * NU;
+            jI[I] = i < NDU ? j : (1 << 20);           // padding columns never become valid
+            offI[I] = -j * SP + cc;
+        }
+        // one pass per tile row I (accumulators of row I only: keeps the register budget at
+        // two waves per SIMD); the K loop starts at the first step that reaches block column 16 I / NU
+        MPCQP_UNROLL
+        for (int I = 0; I < NT; ++I) {
+            v4d acc[NT];
+            MPCQP_UNROLL
+            for (int J = 0; J <= I; ++J) acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
+            const int kk0 = (((16 * I) / NU) * NY) / 4;    // first K step with t >= jmin(I)
+            MPCQP_NOUNROLL
+            for (int kk = kk0; kk < NK; ++kk) {
+                const int r = 4 * kk + lk;
+                const bool rok = r < NYR;
+                const int rr = rok ? r : 0;
+                const int t = rr / NY, a = rr - t * NY;
+                const double dv = rok ? dd[rr] : 0.0;
+                const int base = t * SP + a * NU;
+                double e[NT];
+                MPCQP_UNROLL
+                for (int J = 0; J <= I; ++J) {
+                    const bool ok = rok && t >= jI[J];
+                    const double sv = S[ok ? base + offI[J] : 0];
+                    e[J] = ok ? sv : 0.0;
+                }
+                const double ad = e[I] * dv;
+                MPCQP_UNROLL
+                for (int J = 0; J <= I; ++J)
+                    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[J], 0, 0, 0);
+            }
+            MPCQP_UNROLL
+            for (int J = 0; J <= I; ++J) {
+                MPCQP_UNROLL
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = 16 * I + lk + 4 * reg, ip = 16 * J + li;
+                    if (i < NDU && ip < NDU && ip <= i) P[pk(i, ip)] += scale * acc[J][reg];
+                }
+            }
+        }
+    }
+#endif
+
     // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU)
     MPCQP_HD void EtDE_add(const double* dd, double* P, double scale = 1.0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) {
+            EtDE_add_mfma(dd, P, scale);
+            return;
+        }
+#endif
         const int ny = d.ny, nu = d.nu, nDU = d.nDU;
         const int ntri = nDU * (nDU + 1) / 2;
         for (int idx = w.lane; idx < ntri; idx += WAVE) {
@@ -197,8 +275,8 @@ struct Qp {
             const int t0 = jl(j), off2 = jl(j) - jl(j2);       // j >= j2  =>  jl[j] >= jl[j2]
             double acc = 0.0;
             for (int t = t0; t < d.Hp; ++t) {
-                const double* S1 = S + ((t - t0) * ny) * nu + cc;
-                const double* S2 = S + ((t - t0 + off2) * ny) * nu + c2;
+                const double* S1 = S + (t - t0) * sp + cc;
+                const double* S2 = S + (t - t0 + off2) * sp + c2;
                 const double* dt = dd + t * ny;
                 for (int a = 0; a < ny; ++a) acc += S1[a * nu] * dt[a] * S2[a * nu];
             }
@@ -352,9 +430,9 @@ MPCQP_HD void predmat_body(W& w, const Dims& d, const Model& m, int b, double* s
 // ------------------------------------------------------------------------------------------
 // K2: H̃ = 2(Ẽ'MẼ + P̃Δu'ÑP̃Δu + P̃u'LP̃u), diagonal weights, packed lower triangle.
 // ------------------------------------------------------------------------------------------
-template <class W>
-MPCQP_HD void hessian_body(W& w, const Dims& d, const Model& m, int b, double* sm) {
-    Qp<W, Dims> qp(w, d, m, b, sm);
+template <class W, class DM>
+MPCQP_HD void hessian_body(W& w, const DM& d, const Model& m, int b, double* sm) {
+    Qp<W, DM> qp(w, d, m, b, sm);
     qp.load_tables();
     double* P = qp.Phi;
     double* tY = sm + qp.c.tA[P_Y];
@@ -369,7 +447,7 @@ MPCQP_HD void hessian_body(W& w, const Dims& d, const Model& m, int b, double* s
     const int ntri = d.nDU * (d.nDU + 1) / 2;
     for (int idx = w.lane; idx < ntri; idx += WAVE) {
         int i, ip;
-        Qp<W, Dims>::unpack_idx(idx, i, ip);
+        Qp<W, DM>::unpack_idx(idx, i, ip);
         int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
         (void)j2;
         double acc = 0.0;
@@ -390,7 +468,8 @@ MPCQP_HD void hessian_body(W& w, const Dims& d, const Model& m, int b, double* s
 // arrays in LDS; compile-time dims keep them in registers (slots resolved by full unrolling).
 // ------------------------------------------------------------------------------------------
 struct Row {
-    double &h, &s, &lam, &rp, &gd, &pp, &cs;
+    double &h, &s, &lam, &rp, &gd, &pp;
+    double cs;       // softness of the row (stored with runtime dims, re-derived otherwise)
 };
 
 template <class DM, bool STATIC = DM::is_static>
@@ -409,6 +488,8 @@ struct RowStore<DM, false> {
         const int r = d.rowoff(g) + lane + WAVE * q;
         return Row{a[0][r], a[1][r], a[2][r], a[3][r], a[4][r], a[5][r], a[6][r]};
     }
+    MPCQP_HD void set_cs(int g, int q, double v) { a[6][d.rowoff(g) + lane + WAVE * q] = v; }
+    static constexpr bool stores_cs = true;
 };
 
 template <class DM>
@@ -421,12 +502,14 @@ struct RowStore<DM, true> {
         return o;
     }
     static constexpr int NSLOT = slotoff(NGROUP) > 0 ? slotoff(NGROUP) : 1;
-    double a[NROWARR][NSLOT];
+    double a[NROWARR - 1][NSLOT];
     MPCQP_HD RowStore(const DM&, double*, const Carve&, int) {}
     MPCQP_HD Row at(int g, int q) {
         const int r = slotoff(g) + q;
-        return Row{a[0][r], a[1][r], a[2][r], a[3][r], a[4][r], a[5][r], a[6][r]};
+        return Row{a[0][r], a[1][r], a[2][r], a[3][r], a[4][r], a[5][r], 0.0};
     }
+    MPCQP_HD void set_cs(int, int, double) {}
+    static constexpr bool stores_cs = false;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -472,7 +555,12 @@ struct Step {
             case 2 * P_X + 1: p = m.c_x0max; def = 1.0; break;
             default: return 0.0;
         }
-        return p ? p[(size_t)b * d.cnt(g >> 1) + k] : def;
+        if (!p) return def;
+        if ((g >> 1) == P_U) {       // one row per (block, channel): softness of the block's first step
+            const int j = k / d.nu, cc = k - j * d.nu;
+            return p[(size_t)b * d.nU + qp.jl(j) * d.nu + cc];
+        }
+        return p[(size_t)b * d.cnt(g >> 1) + k];
     }
 
     // fn(group, local index, Row&) for every row owned by this lane
@@ -487,8 +575,10 @@ struct Step {
                 const int k = w.lane + WAVE * qq;
                 if (k < n) {
                     Row r = rows.at(g, qq);
+                    if (!RowStore<DM>::stores_cs) r.cs = soft_init(g, k);
                     fn(g, k, r);
                 }
+                MPCQP_SCHED_FENCE();
             }
         }
     }
@@ -505,17 +595,22 @@ struct Step {
             for (int qq = 0; qq < rows.qmax(2 * p); ++qq) {
                 const int k = w.lane + WAVE * qq;
                 if (k < n) {
+                    const bool live = !RowStore<DM>::stores_cs;
                     if (gmin && gmax) {
                         Row r0 = rows.at(2 * p, qq), r1 = rows.at(2 * p + 1, qq);
+                        if (live) { r0.cs = soft_init(2 * p, k); r1.cs = soft_init(2 * p + 1, k); }
                         fn(p, k, &r0, &r1);
                     } else if (gmin) {
                         Row r0 = rows.at(2 * p, qq);
+                        if (live) r0.cs = soft_init(2 * p, k);
                         fn(p, k, &r0, (Row*)nullptr);
                     } else {
                         Row r1 = rows.at(2 * p + 1, qq);
+                        if (live) r1.cs = soft_init(2 * p + 1, k);
                         fn(p, k, (Row*)nullptr, &r1);
                     }
                 }
+                MPCQP_SCHED_FENCE();
             }
         }
     }
@@ -533,8 +628,9 @@ struct Step {
         for (int r = w.lane; r < nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
             double acc = Bv[r];
+            MPCQP_UNROLL4
             for (int k = 0; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
-            const double* Sb = qp.S + (t * ny + a) * nu;        // V block t = Σ_t
+            const double* Sb = qp.S + t * qp.sp + a * nu;       // V block t = Σ_t
             for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * lu[cc];
             if (nd > 0) {
                 const double* Gd = m.Gdtab + (size_t)b * d.Hp * ny * nd;
@@ -618,8 +714,24 @@ struct Step {
             switch (g) {
                 case 0: bound = -zlo[k]; break;
                 case 1: bound = zhi[k]; break;
-                case 2 * P_U: if (m.U0min) bound = -m.U0min[o] + lu[k % nu]; break;
-                case 2 * P_U + 1: if (m.U0max) bound = m.U0max[o] - lu[k % nu]; break;
+                case 2 * P_U:
+                case 2 * P_U + 1: {
+                    // every step of a move-blocking interval has the same row of Pu
+                    // (construct.jl:797-806): only its tightest bound can be active, so the
+                    // interval contributes ONE row (same feasible set as the reference's nb_j rows)
+                    const double* bd = (g & 1) ? m.U0max : m.U0min;
+                    if (bd) {
+                        const int j = k / nu, cc = k - j * nu;
+                        const int t1 = (j + 1 < d.Hc) ? qp.jl(j + 1) : d.Hp;
+                        double v = (g & 1) ? INFINITY : -INFINITY;
+                        for (int t = qp.jl(j); t < t1; ++t) {
+                            const double x = bd[(size_t)b * d.nU + t * nu + cc];
+                            v = (g & 1) ? fmin(v, x) : fmax(v, x);
+                        }
+                        bound = (g & 1) ? v - lu[cc] : -v + lu[cc];
+                    }
+                    break;
+                }
                 case 2 * P_DU:
                     if (m.DUmin && m.C_dumin && m.C_dumin[o] != 0.0) bound = -m.DUmin[o];
                     break;
@@ -636,7 +748,7 @@ struct Step {
             r.s = 1.0;
             r.lam = ok ? 1.0 : 0.0;
             r.rp = 0.0; r.gd = 0.0; r.pp = 0.0;
-            r.cs = soft_init(g, k);
+            rows.set_cs(g, k / WAVE, soft_init(g, k));
             if (ok) { ++cntl; hmax = fmax(hmax, fabs(bound)); }
         });
         mact = w.isum(cntl);
@@ -652,6 +764,7 @@ struct Step {
             for (int k = w.lane; k < d.nDU; k += WAVE) {
                 const int j = k / nu, cc = k - j * nu;
                 double acc = 0.0;
+                MPCQP_UNROLL4
                 for (int jj = 0; jj <= j; ++jj) acc += v[jj * nu + cc];
                 ucum[k] = acc;
             }
@@ -671,7 +784,7 @@ struct Step {
     MPCQP_HD double prim(int p, int k, const double* v) const {
         switch (p) {
             case P_BOX: return v[k];
-            case P_U: return sm[c.ucum + qp.blk(k / d.nu) * d.nu + (k % d.nu)];
+            case P_U: return sm[c.ucum + k];
             case P_DU: return v[k];
             case P_Y: return sm[c.tA[P_Y] + k];
             default: return sm[c.tA[P_X] + k];
@@ -713,7 +826,7 @@ struct Step {
                 if (qp.pair_on(P_U)) {
                     const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tA[P_U];
-                    for (int t = qp.jl(j); t < d.Hp; ++t) acc += tU[t * nu + cc];
+                    for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];
                 }
                 if (qp.pair_on(P_X)) {
                     const double* tX = sm + c.tA[P_X];
@@ -753,8 +866,11 @@ struct Step {
         ee = w.sum(ee);
         w.sync();
         // dense E' dY E
-        if (qp.pair_on(P_Y)) qp.EtDE_add(sm + c.tA[P_Y], Phi);
-        // structured parts: same idx->lane map as EtDE_add, so no barrier needed in between
+        if (qp.pair_on(P_Y)) {
+            qp.EtDE_add(sm + c.tA[P_Y], Phi);
+            w.sync();      // the MFMA write-back uses a different entry->lane map than the loop below
+        }
+        // structured parts
         const int ntri = nDU * (nDU + 1) / 2;
         const bool onU = qp.pair_on(P_U), onX = qp.pair_on(P_X);
         if (onU || onX)
@@ -766,7 +882,7 @@ struct Step {
                     const int j = i / nu, cc = i - j * nu, c2 = ip % nu;
                     if (cc == c2) {
                         const double* tU = sm + c.tA[P_U];
-                        for (int t = qp.jl(j); t < d.Hp; ++t) acc += tU[t * nu + cc];   // j >= j'
+                        for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];      // j >= j'
                     }
                 }
                 if (onX) {
@@ -792,7 +908,7 @@ struct Step {
                 if (qp.pair_on(P_U)) {
                     const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tB[P_U];
-                    for (int t = qp.jl(j); t < d.Hp; ++t) acc += tU[t * nu + cc];
+                    for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];
                 }
                 if (qp.pair_on(P_X)) {
                     const double* tX = sm + c.tB[P_X];
@@ -812,12 +928,14 @@ struct Step {
     MPCQP_HD void cholesky() {
         const int n = d.nZ;
         const int i = w.lane;
+        MPCQP_NOUNROLL
         for (int k = 0; k < n; ++k) {
             double v = 0.0;
             if (i >= k && i < n) {
                 v = Phi[pk(i, k)];
                 const double* Li = Phi + pk(i, 0);
                 const double* Lk = Phi + pk(k, 0);
+                MPCQP_UNROLL4
                 for (int j = 0; j < k; ++j) v -= Li[j] * Lk[j];
             }
             const double piv = w.bcast(v, k);
@@ -837,11 +955,13 @@ struct Step {
         const int n = d.nZ;
         const int i = w.lane;
         double r = (i < n) ? gt[i] : 0.0;
+        MPCQP_NOUNROLL
         for (int k = 0; k < n; ++k) {                 // L y = r, column sweep
             const double yk = w.bcast((i == k) ? r * invd[k] : 0.0, k);
             if (i == k) r = yk;
             else if (i > k && i < n) r -= Phi[pk(i, k)] * yk;
         }
+        MPCQP_NOUNROLL
         for (int k = n - 1; k >= 0; --k) {            // L' x = y, row sweep
             const double xk = w.bcast((i == k) ? r * invd[k] : 0.0, k);
             if (i == k) r = xk;
@@ -868,6 +988,7 @@ struct Step {
         double mx = 0.0, sc = 0.0;
         for (int k = w.lane; k < n; k += WAVE) {
             double hz = 0.0;
+            MPCQP_UNROLL4
             for (int j = 0; j < n; ++j) hz += Phi[k >= j ? pk(k, j) : pk(j, k)] * z[j];
             const double r = hz + q[k] + gt[k];
             rd[k] = r;

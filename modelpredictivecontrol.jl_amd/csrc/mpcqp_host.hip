@@ -91,7 +91,7 @@ const char* mpcqp_last_hip_error(void) { return g_hip_err.c_str(); }
 
 static void layout_rows(mpcqp_handle h) {
     Dims& d = h->d;
-    d.cnt_[P_BOX] = d.nZ; d.cnt_[P_U] = d.nU; d.cnt_[P_DU] = d.nDU; d.cnt_[P_Y] = d.nY; d.cnt_[P_X] = d.nxh;
+    d.cnt_[P_BOX] = d.nZ; d.cnt_[P_U] = d.nDU; d.cnt_[P_DU] = d.nDU; d.cnt_[P_Y] = d.nY; d.cnt_[P_X] = d.nxh;
     int o = 0;
     for (int g = 0; g < NGROUP; ++g) {
         d.rowoff_[g] = o;
@@ -288,6 +288,19 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
     if (!d.neps && (bin->C_umin || bin->C_umax || bin->C_dumin || bin->C_dumax || bin->C_ymin ||
                     bin->C_ymax || bin->c_x0min || bin->c_x0max))
         return MPCQP_ERR_ARG;   // "Cwt must be finite to set softness parameters", construct.jl:441
+    // U rows of one move-blocking interval are merged into their tightest one (mpcqp_bodies.h);
+    // exact as long as the softness of those rows is the same -- true for every `c_umin`/`c_umax`
+    // keyword of setconstraint! (repeated per channel); a C_umin/C_umax vector that varies inside
+    // an interval is not supported by this build.
+    for (const double* cu : {bin->C_umin, bin->C_umax}) {
+        if (!cu) continue;
+        for (size_t b = 0; b < (size_t)d.B; ++b)
+            for (int j = 0; j < d.Hc; ++j)
+                for (int t = h->jl[j] + 1; t < h->jl[j + 1]; ++t)
+                    for (int c = 0; c < d.nu; ++c)
+                        if (cu[b * d.nU + t * d.nu + c] != cu[b * d.nU + h->jl[j] * d.nu + c])
+                            return MPCQP_ERR_UNSUPPORTED;
+    }
     HIPCHK(hipSetDevice(h->device));
     const double* src[16] = {bin->U0min, bin->U0max, bin->DUmin, bin->DUmax, bin->Y0min, bin->Y0max,
                              bin->x0min, bin->x0max, bin->C_umin, bin->C_umax, bin->C_dumin,

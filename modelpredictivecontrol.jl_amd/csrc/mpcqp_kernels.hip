@@ -54,9 +54,16 @@ __global__ __launch_bounds__(64) void k_step(Dims d, Model m, StepIO io) {
     step_body(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
 }
 
+template <class SD>
+__global__ __launch_bounds__(64) void k_hessian_s(Dims d, Model m) {
+    DevWave w{(int)threadIdx.x};
+    const SD sd(d);
+    hessian_body(w, sd, m, (int)blockIdx.x, mpcqp_smem);
+}
+
 // specialised on compile-time dimensions (mpcqp_dispatch.h)
 template <class SD>
-__global__ __launch_bounds__(64) void k_step_s(Dims d, Model m, StepIO io) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_step_s(Dims d, Model m, StepIO io) {
     DevWave w{(int)threadIdx.x};
     const SD sd(d);
     step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem);
@@ -76,7 +83,24 @@ hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStrea
     return hipGetLastError();
 }
 
+static bool force_generic();
+
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
+    if (!force_generic()) {
+#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                        \
+        {                                                                                       \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                               \
+            if (SD::matches_dims(d)) {                                                          \
+                const size_t lds_s = (size_t)make_carve(SD(d)).total * sizeof(double);          \
+                hipError_t e = ensure_lds((const void*)k_hessian_s<SD>, lds_s);                 \
+                if (e != hipSuccess) return e;                                                  \
+                hipLaunchKernelGGL(k_hessian_s<SD>, dim3(d.B), dim3(WAVE), lds_s, st, d, m);    \
+                return hipGetLastError();                                                       \
+            }                                                                                   \
+        }
+        MPCQP_SPECIALIZATIONS(X)
+#undef X
+    }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_hessian, lds);
     if (e != hipSuccess) return e;

@@ -4,7 +4,8 @@
 // (init_matconstraint_mpc, src/controller/transcription.jl:686-703) with the variable bounds
 // Z̃min/Z̃max (init_boxconstraint_mpc, src/controller/construct.jl:1209-1234) put first:
 //   pair 0  box   : -z_k <= -Z̃min_k            |  z_k <= Z̃max_k                (k < nZ)
-//   pair 1  U     : -Pu ΔU - C_umin ϵ <= ...     |  Pu ΔU - C_umax ϵ <= ...       (nU rows)
+//   pair 1  U     : -Pu ΔU - C_umin ϵ <= ...     |  Pu ΔU - C_umax ϵ <= ...       (nDU rows: the nb_j
+//                   identical rows of a move-blocking interval are merged into their tightest one)
 //   pair 2  ΔU    : soft ΔU rows only (hard ones are the box)                    (nDU rows)
 //   pair 3  Ŷ     : -E ΔU - C_ymin ϵ <= ...      |  E ΔU - C_ymax ϵ <= ...        (nY rows)
 //   pair 4  x̂end : -ex̂ ΔU - c_x̂min ϵ <= ...     |  ex̂ ΔU - c_x̂max ϵ <= ...      (nx̂ rows)
@@ -15,9 +16,21 @@
 #if defined(__HIPCC__)
 #define MPCQP_HD __host__ __device__
 #define MPCQP_UNROLL _Pragma("unroll")
+#define MPCQP_UNROLL4 _Pragma("unroll 4")
+#define MPCQP_NOUNROLL _Pragma("nounroll")
+#if defined(__HIP_DEVICE_COMPILE__)
+// stop the instruction scheduler from interleaving the (fully unrolled) per-slot row updates:
+// their temporaries would otherwise be live all at once and cost a wave of occupancy
+#define MPCQP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
+#define MPCQP_SCHED_FENCE() ((void)0)
+#endif
+#else
+#define MPCQP_SCHED_FENCE() ((void)0)
 #define MPCQP_HD
 #define MPCQP_UNROLL
+#define MPCQP_UNROLL4
+#define MPCQP_NOUNROLL
 #endif
 
 namespace mpcqp {
@@ -35,7 +48,7 @@ struct Dims {
     int npk;                 // nZ*(nZ+1)/2  (packed lower triangle)
     uint32_t gmask;          // bit g set <=> row group g may hold finite rows (handle level)
     int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
-    int cnt_[NPAIR];         // primitives per pair: nZ, nU, nDU, nY, nxh
+    int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh
     int default_nb;          // 1 iff nb = [1,..,1,Hp-Hc+1]
     int max_iter;
     double gap_tol, res_tol, dual_reg;

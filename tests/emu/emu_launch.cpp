@@ -79,6 +79,21 @@ hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStrea
     return hipSuccess;
 }
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
+    const char* fg = getenv("MPCQP_FORCE_GENERIC");
+    if (!(fg && fg[0] == '1')) {
+#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                       \
+        {                                                                                      \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                              \
+            if (SD::matches_dims(d)) {                                                         \
+                const SD sd(d);                                                                \
+                run_waves(d.B, make_carve(sd).total, [&](EmuWave& w, int b, double* sm) {      \
+                    hessian_body(w, sd, m, b, sm); });                                         \
+                return hipSuccess;                                                             \
+            }                                                                                  \
+        }
+        MPCQP_SPECIALIZATIONS(X)
+#undef X
+    }
     run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { hessian_body(w, d, m, b, sm); });
     return hipSuccess;
 }
