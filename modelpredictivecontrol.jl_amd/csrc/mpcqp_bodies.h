@@ -24,7 +24,29 @@
 
 #include "mpcqp_types.h"
 
+#if defined(MPCQP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define MPCQP_TIC() const long long tic_ = clock64()
+#define MPCQP_TOC(i) prof_[i] += (double)(clock64() - tic_)
+#else
+#define MPCQP_TIC() ((void)0)
+#define MPCQP_TOC(i) ((void)0)
+#endif
+
 namespace mpcqp {
+
+// 1/x for the per-row interior-point algebra.  Device: v_rcp_f64 + two Newton steps (a full
+// IEEE f64 division is ~4x the instructions and the IPM does not need correctly rounded
+// quotients); host (emulator): plain division.
+MPCQP_HD inline double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------
 // Compile-time dimensions: same member names as the runtime `Dims`, so the bodies below are
@@ -164,30 +186,41 @@ struct Qp {
         const int ny = d.ny, nu = d.nu;
         for (int r = w.lane; r < d.nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
-            double acc = 0.0;
-            MPCQP_NOUNROLL
-            for (int j = 0; j < d.Hc && jl(j) <= t; ++j) {
+            // block columns j with jl(j) <= t; default blocking: j = 0..min(t, Hc-1)
+            int jn = d.Hc;
+            if (d.default_nb) jn = t + 1 < d.Hc ? t + 1 : d.Hc;
+            double acc0 = 0.0, acc1 = 0.0;
+            MPCQP_UNROLL4
+            for (int j = 0; j < jn; ++j) {
+                if (!d.default_nb && jl(j) > t) break;
                 const double* Sb = S + (t - jl(j)) * sp + a * nu;
                 const double* vj = v + j * nu;
-                for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * vj[cc];
+                int cc = 0;
+                for (; cc + 1 < nu; cc += 2) { acc0 += Sb[cc] * vj[cc]; acc1 += Sb[cc + 1] * vj[cc + 1]; }
+                if (cc < nu) acc0 += Sb[cc] * vj[cc];
             }
-            out[r] = acc;
+            out[r] = acc0 + acc1;
         }
     }
 
-    // out[k] += scale * sum_r E[r,k] wv[r]   (k < nDU)
+    // out[k] += scale * sum_r E[r,k] wv[r]   (k < nDU).  The t loop is wave-uniform (lanes of
+    // later block columns just start contributing later), so wv[t,a] is a broadcast LDS read.
     MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0) {
         const int ny = d.ny, nu = d.nu;
         for (int k = w.lane; k < d.nDU; k += WAVE) {
-            const int j = k / nu, cc = k - j * nu;
-            double acc = 0.0;
+            const int j = k / nu, cc = k - j * nu, t0 = jl(j);
+            const double* Sk = S + cc - t0 * sp;
+            double acc0 = 0.0, acc1 = 0.0;
             MPCQP_UNROLL4
-            for (int t = jl(j); t < d.Hp; ++t) {
-                const double* Sb = S + (t - jl(j)) * sp + cc;
+            for (int t = 0; t < d.Hp; ++t) {
+                if (t < t0) continue;
+                const double* Sb = Sk + t * sp;
                 const double* wt = wv + t * ny;
-                for (int a = 0; a < ny; ++a) acc += Sb[a * nu] * wt[a];
+                int a = 0;
+                for (; a + 1 < ny; a += 2) { acc0 += Sb[a * nu] * wt[a]; acc1 += Sb[(a + 1) * nu] * wt[a + 1]; }
+                if (a < ny) acc0 += Sb[a * nu] * wt[a];
             }
-            out[k] += scale * acc;
+            out[k] += scale * (acc0 + acc1);
         }
     }
 
@@ -206,7 +239,7 @@ struct Qp {
     // time; the 16-wide tiles run over the ΔU index; E is never formed -- operands come straight
     // from the block-Toeplitz table, and tiles whose block columns start after step t are skipped.
     typedef double v4d __attribute__((ext_vector_type(4)));
-    __device__ __forceinline__ void EtDE_add_mfma(const double* dd, double* P, double scale) {
+    __device__ __forceinline__ void EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb) {
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp;
         constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
         const int li = w.lane & 15, lk = w.lane >> 4;
@@ -225,8 +258,12 @@ struct Qp {
             v4d acc[NT];
             MPCQP_UNROLL
             for (int J = 0; J <= I; ++J) acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
-            const int kk0 = (((16 * I) / NU) * NY) / 4;    // first K step with t >= jmin(I)
-            MPCQP_NOUNROLL
+            // ϵ row (index NDU, when present): row NDU of Phi is sum_r tb[r] E[r,:], i.e. the same
+            // contraction with A operand tb instead of E*dd -- rides in its tile row for free
+            constexpr int IE = NDU / 16, LE = NDU % 16;
+            const bool erow = DM::neps && tb != nullptr && I == IE;
+            const int kk0 = erow ? 0 : (((16 * I) / NU) * NY) / 4;    // first K step with t >= jmin(I)
+            _Pragma("unroll 2")
             for (int kk = kk0; kk < NK; ++kk) {
                 const int r = 4 * kk + lk;
                 const bool rok = r < NYR;
@@ -241,7 +278,8 @@ struct Qp {
                     const double sv = S[ok ? base + offI[J] : 0];
                     e[J] = ok ? sv : 0.0;
                 }
-                const double ad = e[I] * dv;
+                double ad = e[I] * dv;
+                if (erow && li == LE) ad = rok ? tb[rr] : 0.0;
                 MPCQP_UNROLL
                 for (int J = 0; J <= I; ++J)
                     acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[J], 0, 0, 0);
@@ -251,19 +289,22 @@ struct Qp {
                 MPCQP_UNROLL
                 for (int reg = 0; reg < 4; ++reg) {
                     const int i = 16 * I + lk + 4 * reg, ip = 16 * J + li;
-                    if (i < NDU && ip < NDU && ip <= i) P[pk(i, ip)] += scale * acc[J][reg];
+                    if (ip < NDU && ((i < NDU && ip <= i) || (erow && i == NDU)))
+                        P[pk(i, ip)] += scale * acc[J][reg];
                 }
             }
         }
     }
 #endif
 
-    // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU)
-    MPCQP_HD void EtDE_add(const double* dd, double* P, double scale = 1.0) {
+    // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU).  When `tb` is given
+    // and the matrix-core path runs, the ϵ row P[pk(nDU, i')] += sum_r tb[r] E[r,i'] is added too
+    // and true is returned; otherwise the caller adds it (Et_apply_add).
+    MPCQP_HD bool EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (DM::is_static) {
-            EtDE_add_mfma(dd, P, scale);
-            return;
+            EtDE_add_mfma(dd, P, scale, tb);
+            return tb != nullptr && DM::neps;
         }
 #endif
         const int ny = d.ny, nu = d.nu, nDU = d.nDU;
@@ -282,6 +323,7 @@ struct Qp {
             }
             P[idx] += scale * acc;
         }
+        return false;
     }
 
     // ex̂[i,(j,c)]
@@ -529,6 +571,8 @@ struct Step {
     int mact;           // number of finite rows
     double nh;          // 1 + max |h|
     double delta;
+    double prof_[16] = {0};   // phase cycle counters (profiling builds)
+    double myinvd = 0.0;      // 1/L[lane][lane] of the current factor
 
     MPCQP_HD Step(Qp<W, DM>& qp_)
         : qp(qp_), w(qp_.w), d(qp_.d), m(qp_.m), b(qp_.b), sm(qp_.sm), c(qp_.c),
@@ -794,6 +838,7 @@ struct Step {
     // ---- fn(Row&, (G v)[row]) for every finite row -------------------------------------------
     template <class Fn>
     MPCQP_HD void apply_G(const double* v, Fn fn) {
+        MPCQP_TIC();
         primitives(v);
         const double e = d.neps ? v[d.nZ - 1] : 0.0;
         for_rows([&](int g, int k, Row& r) {
@@ -802,11 +847,13 @@ struct Step {
             fn(r, ((g & 1) ? pv : -pv) - r.cs * e);
         });
         w.sync();    // tA[P_Y]/ucum are reused by the next product
+        MPCQP_TOC(0);
     }
 
     // ---- gt = G' wv, wv(Row&) evaluated on finite rows ---------------------------------------
     template <class Fn>
     MPCQP_HD void apply_Gt(Fn wv) {
+        MPCQP_TIC();
         const int nu = d.nu;
         // per pair: tA[k] = w_max - w_min ; eps accumulates -(c_min w_min + c_max w_max)
         double eacc = 0.0;
@@ -839,6 +886,7 @@ struct Step {
         }
         if (qp.pair_on(P_Y)) qp.Et_apply_add(sm + c.tA[P_Y], gt);   // same lane owns gt[k]
         w.sync();
+        MPCQP_TOC(1);
     }
 
     // ---- Phi <- H̃ (global -> LDS), hz = H̃ z per lane ----------------------------------------
@@ -851,6 +899,7 @@ struct Step {
     // ---- Phi += G' diag(dd) G, dd(Row&) evaluated on finite rows ------------------------------
     template <class Fn>
     MPCQP_HD void add_GtDG(Fn dd) {
+        MPCQP_TIC();
         const int nu = d.nu, nDU = d.nDU, nZ = d.nZ;
         double ee = 0.0;
         for_pairs([&](int p, int k, Row* r0, Row* r1) {
@@ -865,32 +914,41 @@ struct Step {
         });
         ee = w.sum(ee);
         w.sync();
-        // dense E' dY E
+        MPCQP_TOC(3);
+        // dense E' dY E (+ the ϵ row of the Ŷ rows on the matrix-core path)
+        bool eps_y_done = false;
         if (qp.pair_on(P_Y)) {
-            qp.EtDE_add(sm + c.tA[P_Y], Phi);
-            w.sync();      // the MFMA write-back uses a different entry->lane map than the loop below
+            MPCQP_TIC();
+            eps_y_done = qp.EtDE_add(sm + c.tA[P_Y], Phi, 1.0, d.neps ? sm + c.tB[P_Y] : nullptr);
+            w.sync();      // the MFMA write-back uses its own entry->lane map
+            MPCQP_TOC(4);
         }
-        // structured parts
-        const int ntri = nDU * (nDU + 1) / 2;
-        const bool onU = qp.pair_on(P_U), onX = qp.pair_on(P_X);
-        if (onU || onX)
+        const long long tic5_ = clock64_();
+        // U rows: Pu' dU Pu has entry ((j,c),(j',c)) = sum_{jj >= max(j,j')} dU[jj,c]: lane (j,c)
+        // forms its suffix sum once and adds it along its own row of the lower triangle
+        if (qp.pair_on(P_U)) {
+            const double* tU = sm + c.tA[P_U];
+            for (int k = w.lane; k < nDU; k += WAVE) {
+                const int j = k / nu, cc = k - j * nu;
+                double suf = 0.0;
+                MPCQP_UNROLL4
+                for (int jj = j; jj < d.Hc; ++jj) suf += tU[jj * nu + cc];
+                MPCQP_UNROLL4
+                for (int j2 = 0; j2 <= j; ++j2) Phi[pk(k, j2 * nu + cc)] += suf;
+            }
+        }
+        if (qp.pair_on(P_X)) {
+            w.sync();
+            const int ntri = nDU * (nDU + 1) / 2;
+            const double* tX = sm + c.tA[P_X];
             for (int idx = w.lane; idx < ntri; idx += WAVE) {
                 int i, ip;
                 Qp<W, DM>::unpack_idx(idx, i, ip);
                 double acc = 0.0;
-                if (onU) {
-                    const int j = i / nu, cc = i - j * nu, c2 = ip % nu;
-                    if (cc == c2) {
-                        const double* tU = sm + c.tA[P_U];
-                        for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];      // j >= j'
-                    }
-                }
-                if (onX) {
-                    const double* tX = sm + c.tA[P_X];
-                    for (int r = 0; r < d.nxh; ++r) acc += qp.Xat(r, i) * tX[r] * qp.Xat(r, ip);
-                }
+                for (int r = 0; r < d.nxh; ++r) acc += qp.Xat(r, i) * tX[r] * qp.Xat(r, ip);
                 Phi[idx] += acc;
             }
+        }
         w.sync();
         for (int k = w.lane; k < nZ; k += WAVE) {
             double acc = 0.0;
@@ -908,6 +966,7 @@ struct Step {
                 if (qp.pair_on(P_U)) {
                     const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tB[P_U];
+                    MPCQP_UNROLL4
                     for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];
                 }
                 if (qp.pair_on(P_X)) {
@@ -916,59 +975,117 @@ struct Step {
                 }
                 st[k] = acc;
             }
-            if (qp.pair_on(P_Y)) qp.Et_apply_add(sm + c.tB[P_Y], st);   // same lane owns st[k]
+            if (qp.pair_on(P_Y) && !eps_y_done) qp.Et_apply_add(sm + c.tB[P_Y], st);   // same lane owns st[k]
             for (int k = w.lane; k < nDU; k += WAVE) Phi[pk(nZ - 1, k)] += st[k];
         }
         w.sync();
+        prof_[5] += (double)(clock64_() - tic5_);
+    }
+
+    MPCQP_HD static long long clock64_() {
+#if defined(MPCQP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        return clock64();
+#else
+        return 0;
+#endif
     }
 
     // ---- in-place Cholesky of packed Phi (row-major lower), one row per lane, nZ <= 64 --------
     // pivot guard: a non-positive pivot (float64 breakdown of the normal equations) freezes that
     // coordinate for this Newton step instead of poisoning the factor with NaN.
     MPCQP_HD void cholesky() {
+        MPCQP_TIC();
         const int n = d.nZ;
         const int i = w.lane;
+        const int rowi = pk(i < n ? i : 0, 0);
         MPCQP_NOUNROLL
         for (int k = 0; k < n; ++k) {
-            double v = 0.0;
+            double v0 = 0.0, v1 = 0.0;
             if (i >= k && i < n) {
-                v = Phi[pk(i, k)];
-                const double* Li = Phi + pk(i, 0);
+                const double* Li = Phi + rowi;
                 const double* Lk = Phi + pk(k, 0);
-                MPCQP_UNROLL4
-                for (int j = 0; j < k; ++j) v -= Li[j] * Lk[j];
+                v0 = Li[k];
+                int j = 0;
+                _Pragma("unroll 4")
+                for (; j + 1 < k; j += 2) { v0 -= Li[j] * Lk[j]; v1 -= Li[j + 1] * Lk[j + 1]; }
+                if (j < k) v0 -= Li[j] * Lk[j];
             }
+            const double v = v0 + v1;
             const double piv = w.bcast(v, k);
             const double ref = fabs(Phi[pk(k, k)]);
-            w.sync();     // everyone has read its column-k inputs (incl. the old diagonal)
             const bool bad = !(piv > 1e-14 * ref);
-            const double dd = bad ? 1e32 : sqrt(piv);
-            const double id = 1.0 / dd;
-            if (i == k) { Phi[pk(k, k)] = dd; invd[k] = id; }
-            else if (i > k && i < n) Phi[pk(i, k)] = bad ? 0.0 : v * id;
+            const double id = bad ? 1e-32 : rsqrt_(piv);     // 1/sqrt(pivot)
+            w.sync();     // everyone has read its column-k inputs (incl. the old diagonal)
+            if (i == k) { Phi[pk(k, k)] = bad ? 1e32 : piv * id; invd[k] = id; myinvd = id; }
+            else if (i > k && i < n) Phi[rowi + k] = bad ? 0.0 : v * id;
             w.sync();
         }
+        MPCQP_TOC(6);
+    }
+
+    MPCQP_HD static double rsqrt_(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        double r = __builtin_amdgcn_rsq(x);
+        // two Newton steps: r <- r (1.5 - 0.5 x r^2)
+        r = r * fma(-0.5 * x * r, r, 1.5);
+        r = r * fma(-0.5 * x * r, r, 1.5);
+        return r;
+#else
+        return 1.0 / sqrt(x);
+#endif
     }
 
     // ---- dz <- Phi^{-1} gt  (factor in Phi/invd) -----------------------------------------------
     MPCQP_HD void solve_into_dz() {
+        MPCQP_TIC();
         const int n = d.nZ;
         const int i = w.lane;
+        const int ii = i < n ? i : 0;
+        const int rowi = pk(ii, 0);
         double r = (i < n) ? gt[i] : 0.0;
+        // L y = r, column sweep.  The factor entries a lane needs do not depend on the running
+        // solution, so they are fetched CH columns ahead of the dependent chain (which is then
+        // v_mul -> v_readlane -> v_fma per column, no LDS round trip).
+        constexpr int CH = 4;
+        double lc[CH], ln[CH];
+        MPCQP_UNROLL
+        for (int u = 0; u < CH; ++u) lc[u] = (u < ii) ? Phi[rowi + u] : 0.0;
         MPCQP_NOUNROLL
-        for (int k = 0; k < n; ++k) {                 // L y = r, column sweep
-            const double yk = w.bcast((i == k) ? r * invd[k] : 0.0, k);
-            if (i == k) r = yk;
-            else if (i > k && i < n) r -= Phi[pk(i, k)] * yk;
+        for (int k0 = 0; k0 < n; k0 += CH) {
+            MPCQP_UNROLL
+            for (int u = 0; u < CH; ++u) { const int k = k0 + CH + u; ln[u] = (k < ii) ? Phi[rowi + k] : 0.0; }
+            MPCQP_UNROLL
+            for (int u = 0; u < CH; ++u) {
+                const int k = k0 + u;
+                if (k < n) {
+                    const double yk = w.bcast(r * myinvd, k);
+                    r = (i == k) ? yk : r - lc[u] * yk;      // lc = 0 for lanes i <= k or i >= n
+                }
+            }
+            MPCQP_UNROLL
+            for (int u = 0; u < CH; ++u) lc[u] = ln[u];
         }
+        // L' x = y, row sweep (lane i < k needs L[k][i]: row k, contiguous)
+        MPCQP_UNROLL
+        for (int u = 0; u < CH; ++u) { const int k = n - 1 - u; lc[u] = (k >= 0 && k > i) ? Phi[pk(k, 0) + i] : 0.0; }
         MPCQP_NOUNROLL
-        for (int k = n - 1; k >= 0; --k) {            // L' x = y, row sweep
-            const double xk = w.bcast((i == k) ? r * invd[k] : 0.0, k);
-            if (i == k) r = xk;
-            else if (i < k) r -= Phi[pk(k, i)] * xk;
+        for (int k0 = n - 1; k0 >= 0; k0 -= CH) {
+            MPCQP_UNROLL
+            for (int u = 0; u < CH; ++u) { const int k = k0 - CH - u; ln[u] = (k >= 0 && k > i) ? Phi[pk(k, 0) + i] : 0.0; }
+            MPCQP_UNROLL
+            for (int u = 0; u < CH; ++u) {
+                const int k = k0 - u;
+                if (k >= 0) {
+                    const double xk = w.bcast(r * myinvd, k);
+                    r = (i == k) ? xk : r - lc[u] * xk;      // lc = 0 for lanes i >= k
+                }
+            }
+            MPCQP_UNROLL
+            for (int u = 0; u < CH; ++u) lc[u] = ln[u];
         }
         if (i < n) dz[i] = r;
         w.sync();
+        MPCQP_TOC(7);
     }
 
     // ---- rp, mu ; then rd = H̃ z + q + G' lam with H̃ freshly staged in Phi ---------------------
@@ -984,6 +1101,7 @@ struct Step {
         mu = w.sum(musum) / mact;
         rpn = w.maxv(rpmax);
         apply_Gt([&](Row& r) { return r.lam; });
+        MPCQP_TIC();
         load_H();
         double mx = 0.0, sc = 0.0;
         for (int k = w.lane; k < n; k += WAVE) {
@@ -998,22 +1116,23 @@ struct Step {
         rdn = w.maxv(mx);
         nd_ = 1.0 + w.maxv(sc);
         w.sync();
+        MPCQP_TOC(2);
     }
 
     // Row part of one Newton step of the dual-regularised system (D~ = D w, w = 1/(1+δD)):
     //   dl = -w rc/s + D~ (rp + G dz),   ds = -(rc + s dl)/lam
     MPCQP_HD void row_step(const Row& r, double rc, double& ds, double& dl) const {
-        const double D = r.lam / r.s, ww = 1.0 / (1.0 + delta * D);
-        dl = -ww * rc / r.s + D * ww * (r.rp + r.gd);
-        ds = -(rc + r.s * dl) / r.lam;
+        const double is = rcp(r.s), D = r.lam * is, ww = rcp(1.0 + delta * D);
+        dl = ww * (D * (r.rp + r.gd) - rc * is);
+        ds = -(rc + r.s * dl) * rcp(r.lam);
     }
 
     // (H + G'D~G) dz = -rd + G'(w rc/s - D~ rp); then gd = G dz.  rc(Row&) given by functor.
     template <class Fn>
     MPCQP_HD void newton(Fn rc) {
         apply_Gt([&](Row& r) {
-            const double D = r.lam / r.s, ww = 1.0 / (1.0 + delta * D);
-            return ww * rc(r) / r.s - D * ww * r.rp;
+            const double is = rcp(r.s), ww = rcp(1.0 + delta * r.lam * is);
+            return ww * is * (rc(r) - r.lam * r.rp);
         });
         for (int k = w.lane; k < d.nZ; k += WAVE) gt[k] -= rd[k];
         w.sync();
@@ -1052,7 +1171,7 @@ struct Step {
         double mu, rpn, rdn, ndd;
         // ---- starting point: affine step from (z, s=1, lam=1), then push into the interior ----
         residuals(mu, rpn, rdn, ndd);
-        add_GtDG([&](Row& r) { return r.lam / r.s; });
+        add_GtDG([&](Row& r) { return r.lam * rcp(r.s); });
         cholesky();
         newton([&](Row& r) { return r.s * r.lam; });
         for_rows([&](int, int, Row& r) {
@@ -1074,8 +1193,8 @@ struct Step {
                 break;
             }
             add_GtDG([&](Row& r) {
-                const double D = r.lam / r.s;
-                return D / (1.0 + delta * D);
+                const double D = r.lam * rcp(r.s);
+                return D * rcp(1.0 + delta * D);
             });
             cholesky();
             // predictor: rc = s lam
@@ -1085,8 +1204,8 @@ struct Step {
                 if (!fin(r)) return;
                 double ds, dl;
                 row_step(r, r.s * r.lam, ds, dl);
-                if (ds < 0.0) amin = fmin(amin, -r.s / ds);
-                if (dl < 0.0) amin = fmin(amin, -r.lam / dl);
+                if (ds < 0.0) amin = fmin(amin, -r.s * rcp(ds));
+                if (dl < 0.0) amin = fmin(amin, -r.lam * rcp(dl));
                 r.pp = ds * dl;
             });
             const double aaff = w.minv(amin);
@@ -1108,8 +1227,8 @@ struct Step {
                 if (!fin(r)) return;
                 double ds, dl;
                 row_step(r, r.s * r.lam + r.pp - smu, ds, dl);
-                if (ds < 0.0) amin = fmin(amin, -r.s / ds);
-                if (dl < 0.0) amin = fmin(amin, -r.lam / dl);
+                if (ds < 0.0) amin = fmin(amin, -r.s * rcp(ds));
+                if (dl < 0.0) amin = fmin(amin, -r.lam * rcp(dl));
             });
             const double alpha = fmin(1.0, 0.99 * w.minv(amin));
             for_rows([&](int, int, Row& r) {
@@ -1146,7 +1265,13 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
         for (int r = w.lane; r < d.nY; r += WAVE) io.F_keep[(size_t)b * d.nY + r] = st.F[r];
     }
     int iters = 0;
+    const long long t_run0 = Step<W, DM>::clock64_();
     const int status = st.run(io, iters);
+    if (io.prof) {
+        st.prof_[15] = (double)(Step<W, DM>::clock64_() - t_run0);
+        if (w.lane == 0)
+            for (int i = 0; i < 16; ++i) io.prof[(size_t)b * 16 + i] = st.prof_[i];
+    }
     // outputs: Z̃, u0 = Z̃[1:nu] + lastu0 (getinput!), Ŷ0 = Ẽ Z̃ + F (predict!)
     for (int k = w.lane; k < d.nZ; k += WAVE) io.Z[(size_t)b * d.nZ + k] = st.z[k];
     for (int k = w.lane; k < d.nu; k += WAVE)

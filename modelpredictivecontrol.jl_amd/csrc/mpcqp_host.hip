@@ -44,7 +44,7 @@ struct mpcqp_handle_s {
     DBuf bnd[16];
     // staging for the host-pointer step
     DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
-    DBuf keep_q, keep_F;
+    DBuf keep_q, keep_F, prof;
 };
 
 static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
@@ -362,6 +362,13 @@ int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
         io.q_keep = (double*)h->keep_q.p;
         io.F_keep = (double*)h->keep_F.p;
     }
+#ifdef MPCQP_PROFILE
+    {
+        int rc = dev_alloc(h, h->prof, (size_t)d.B * 16 * sizeof(double));
+        if (rc) return rc;
+        io.prof = (double*)h->prof.p;
+    }
+#endif
     HIPCHK(hipEventRecord(h->ev_s0, st));
     HIPCHK(launch_step(d, h->m, io, st));
     HIPCHK(hipEventRecord(h->ev_s1, st));
@@ -467,6 +474,10 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
         case MPCQP_GET_FVEC:
             if (!h->keep_F.p) return MPCQP_ERR_ORDER;
             HIPCHK(hipMemcpy(out, h->keep_F.p, B * d.nY * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        case 99:     /* per-phase cycle counters of profiling builds: (16,B) */
+            if (!h->prof.p) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->prof.p, B * 16 * sizeof(double), hipMemcpyDeviceToHost));
             return MPCQP_OK;
         default:
             return MPCQP_ERR_ARG;

@@ -11,30 +11,45 @@
 
 namespace mpcqp {
 
+// Wave-level primitives without LDS traffic: reductions run on DPP lane permutes inside each
+// 16-lane row and v_readlane across the four rows; broadcasts of a wave-uniform lane are two
+// v_readlane.  (ds_bpermute-based __shfl costs an LDS round trip per step, and this kernel's
+// critical path is a chain of ~120 broadcasts + ~12 reductions per IPM iteration.)
 struct DevWave {
     int lane;
     __device__ __forceinline__ void sync() { __syncthreads(); }
-    __device__ __forceinline__ double sum(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
+
+    template <int CTRL>
+    static __device__ __forceinline__ double dpp(double v) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
     }
-    __device__ __forceinline__ double minv(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-        return v;
+    static __device__ __forceinline__ double lane_value(double v, int src) {   // src wave-uniform
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
     }
-    __device__ __forceinline__ double maxv(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-        return v;
+    template <class Op>
+    static __device__ __forceinline__ double reduce(double v, Op op) {
+        v = op(v, dpp<0xB1>(v));     // quad_perm [1,0,3,2]
+        v = op(v, dpp<0x4E>(v));     // quad_perm [2,3,0,1]
+        v = op(v, dpp<0x141>(v));    // row_half_mirror
+        v = op(v, dpp<0x140>(v));    // row_mirror: every lane holds its 16-lane row's value
+        const double a = lane_value(v, 0), b = lane_value(v, 16);
+        const double c = lane_value(v, 32), d = lane_value(v, 48);
+        return op(op(a, b), op(c, d));
     }
+    __device__ __forceinline__ double sum(double v) { return reduce(v, [](double x, double y) { return x + y; }); }
+    __device__ __forceinline__ double minv(double v) { return reduce(v, [](double x, double y) { return fmin(x, y); }); }
+    __device__ __forceinline__ double maxv(double v) { return reduce(v, [](double x, double y) { return fmax(x, y); }); }
     __device__ __forceinline__ int isum(int v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         return v;
     }
-    __device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
+    __device__ __forceinline__ double bcast(double v, int src) { return lane_value(v, src); }
 };
 
 extern __shared__ __attribute__((aligned(16))) double mpcqp_smem[];

@@ -90,6 +90,7 @@ struct StepIO {
     double *Z, *u0, *Yhat0;
     int32_t *status, *iters;
     double *q_keep, *F_keep;   // optional (MPCQP_FLAG_KEEP_QP)
+    double *prof;              // optional [B][16] per-phase cycle counts (-DMPCQP_PROFILE builds only)
 };
 
 MPCQP_HD inline int pk(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
