@@ -59,7 +59,7 @@ struct StaticDims {
     static constexpr bool is_static = true;
     static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS, nd = 0;
     static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP, nD = 0;
-    static constexpr int npk = nZ * (nZ + 1) / 2;
+    static constexpr int npk = 2 * ((nZ + 1) / 2) * ((nZ + 2) / 2);     // pk_size(nZ)
     // LDS stride of one Σ_m block: padded so the MFMA operand reads of E'DE (64 lanes = 4 block
     // columns x NY*NU entries) fall in distinct bank groups (see DESIGN.md "LDS layout")
     static constexpr int sp = (NY * NU) % 16 == 0 ? NY * NU + 8 : NY * NU;
@@ -321,7 +321,7 @@ struct Qp {
                 const double* dt = dd + t * ny;
                 for (int a = 0; a < ny; ++a) acc += S1[a * nu] * dt[a] * S2[a * nu];
             }
-            P[idx] += scale * acc;
+            P[pk(i, ip)] += scale * acc;
         }
         return false;
     }
@@ -496,7 +496,7 @@ MPCQP_HD void hessian_body(W& w, const DM& d, const Model& m, int b, double* sm)
         if (cc == c2)
             for (int t = qp.jl(j); t < d.Hp; ++t) acc += L[t * nu + cc];
         if (i == ip) acc += m.Ndiag[(size_t)b * d.nDU + i];     // 2 N
-        P[idx] += 2.0 * acc;
+        P[pk(i, ip)] += 2.0 * acc;
     }
     if (d.neps && w.lane == 0) P[pk(d.nZ - 1, d.nZ - 1)] = 2.0 * m.Cwt[b];    // Ñ = blkdiag(N, C)
     w.sync();
@@ -946,7 +946,7 @@ struct Step {
                 Qp<W, DM>::unpack_idx(idx, i, ip);
                 double acc = 0.0;
                 for (int r = 0; r < d.nxh; ++r) acc += qp.Xat(r, i) * tX[r] * qp.Xat(r, ip);
-                Phi[idx] += acc;
+                Phi[pk(i, ip)] += acc;
             }
         }
         w.sync();
@@ -998,6 +998,7 @@ struct Step {
         const int n = d.nZ;
         const int i = w.lane;
         const int rowi = pk(i < n ? i : 0, 0);
+        const double dia = (i < n) ? Phi[rowi + i] : 1.0;
         MPCQP_NOUNROLL
         for (int k = 0; k < n; ++k) {
             double v0 = 0.0, v1 = 0.0;
@@ -1012,10 +1013,9 @@ struct Step {
             }
             const double v = v0 + v1;
             const double piv = w.bcast(v, k);
-            const double ref = fabs(Phi[pk(k, k)]);
+            const double ref = fabs(w.bcast(dia, k));        // original diagonal entry of row k
             const bool bad = !(piv > 1e-14 * ref);
             const double id = bad ? 1e-32 : rsqrt_(piv);     // 1/sqrt(pivot)
-            w.sync();     // everyone has read its column-k inputs (incl. the old diagonal)
             if (i == k) { Phi[pk(k, k)] = bad ? 1e32 : piv * id; invd[k] = id; myinvd = id; }
             else if (i > k && i < n) Phi[rowi + k] = bad ? 0.0 : v * id;
             w.sync();

@@ -132,7 +132,7 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     d.Hp = in->Hp; d.Hc = in->Hc; d.neps = in->neps;
     d.nZ = nZ; d.nDU = in->nu * in->Hc; d.nU = in->nu * in->Hp; d.nY = in->ny * in->Hp;
     d.nD = in->nd * in->Hp;
-    d.npk = nZ * (nZ + 1) / 2;
+    d.npk = pk_size(nZ);
     d.flags = in->flags;
     d.max_iter = in->max_iter > 0 ? in->max_iter : 60;
     d.gap_tol = in->gap_tol > 0 ? in->gap_tol : 1e-12;

@@ -17,7 +17,14 @@ namespace mpcqp {
 // critical path is a chain of ~120 broadcasts + ~12 reductions per IPM iteration.)
 struct DevWave {
     int lane;
-    __device__ __forceinline__ void sync() { __syncthreads(); }
+    // One wavefront per workgroup: LDS operations of a wave execute in issue order, so ordering
+    // LDS traffic between lanes needs no s_barrier and no s_waitcnt -- only a fence the compiler
+    // may not move memory operations across.
+    __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     template <int CTRL>
     static __device__ __forceinline__ double dpp(double v) {

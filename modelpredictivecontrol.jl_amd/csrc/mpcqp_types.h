@@ -45,7 +45,7 @@ constexpr double BIG = 1e300;     // |h| >= BIG  <=>  row absent (bound was +-In
 struct Dims {
     int B, nxh, nu, ny, nd, Hp, Hc, neps;
     int nZ, nDU, nU, nY, nD;
-    int npk;                 // nZ*(nZ+1)/2  (packed lower triangle)
+    int npk;                 // pk_size(nZ): packed lower triangle, rows padded to even length
     uint32_t gmask;          // bit g set <=> row group g may hold finite rows (handle level)
     int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
     int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh
@@ -93,6 +93,11 @@ struct StepIO {
     double *prof;              // optional [B][16] per-phase cycle counts (-DMPCQP_PROFILE builds only)
 };
 
-MPCQP_HD inline int pk(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
+// Packed lower triangle, row-major, every row padded to an even length so that it starts on a
+// 16-byte boundary: the compiler fuses neighbouring LDS loads into ds_read_b128 / ds_read2_b64,
+// and a 16-byte DS access off its natural alignment is replayed at ~64 cycles per wave
+// instruction (cdna_hip_programming.md, Guideline 17).  Rows 2q and 2q+1 both occupy 2(q+1).
+MPCQP_HD inline int pk(int i, int j) { return 2 * ((i + 1) / 2) * ((i + 2) / 2) + j; }   // i >= j
+MPCQP_HD inline int pk_size(int n) { return 2 * ((n + 1) / 2) * ((n + 2) / 2); }
 
 }  // namespace mpcqp
