@@ -142,11 +142,20 @@ def main():
     if rank == 0:
         total = B * world * args.steps
         value = total / elapsed
-        rows_u = (np.isfinite(cfg.umin) + np.isfinite(cfg.umax)) * hd.nU
-        rows_y = (np.isfinite(cfg.ymin) + np.isfinite(cfg.ymax)) * hd.nY
+        # row counts of the reference's A Z̃ <= b (i_b rule); the kernel merges the U rows of a
+        # move-blocking interval, the flop model keeps the reference's count
+        rows_u = (int(np.isfinite(cfg.umin)) + int(np.isfinite(cfg.umax))) * hd.nU
+        rows_y = (int(np.isfinite(cfg.ymin)) + int(np.isfinite(cfg.ymax))) * hd.nY
         flops, w_grad, w_iter = algorithmic_flops(cfg, mean_it, rows_u, rows_y)
         kms = float(np.mean(kern_ms))
         achieved = flops * B / (kms * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_k_step.json")))
+            if tr["config"] == args.config and tr["batch"] == B:
+                traffic = tr["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "QP solves/sec (moveinput!)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -160,7 +169,7 @@ def main():
                        "sharding": "contiguous index ranges, no collective on the data path"},
             "roofline": {"bound": "mfma", "kernel": "k_step", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel_ms": kms, "flops_per_solve": flops,
                          "hbm_algorithmic_GBps": algorithmic_bytes(cfg) * B / (kms * 1e-3) / 1e9,
                          "note": "FP64 vector/matrix peak (no f64 entry in the MFMA table: "
@@ -189,13 +198,16 @@ def cpu_baseline(cfg, args):
     rate = probe / (time.perf_counter() - t0)
     n = int(min(args.batch, max(probe, rate * args.cpu_seconds)))
     n = max(256, (n // 256) * 256)
+    reps = max(1, int(round(rate * args.cpu_seconds / n)))        # ~cpu_seconds of CPU work in all
     bt = synth.make_batch(cfg, n, seed=args.seed)
     rb = cport.from_synth(cfg, bt)
     t0 = time.perf_counter()
-    _, _, st, it = rb.step(bt["xhat0"], bt["lastu0"], bt["ry"])
+    for _ in range(reps):
+        _, _, st, it = rb.step(bt["xhat0"], bt["lastu0"], bt["ry"])
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
-            "sample": f"first {n} instances of the same workload, cold start, {dt:.1f} s, "
+    return {"value": n * reps / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
+            "sample": f"first {n} instances of the same workload x {reps} cold-start passes, "
+                      f"{dt:.1f} s, dense per-controller C restatement (oracle/linmpc_ref.c), "
                       f"mean {float(it.mean()):.1f} IPM iterations, all optimal: {bool((st == 0).all())}"}
 
 
