@@ -38,8 +38,7 @@ def algorithmic_flops(cfg, mean_iters, rows_u, rows_y):
     w_grad = 2 * p * (nxh + cfg.nu) + 2 * p * n
     w_iter = ((p * n * n if rows_y else 0) + n * n + n ** 3 / 3.0 + 4 * n * n
               + 8 * (rows_y * n + rows_u * 1))
-    # +1: the starting-point step costs one more factorisation/solve
-    return w_grad + (mean_iters + 1.0) * w_iter, w_grad, w_iter
+    return w_grad + mean_iters * w_iter, w_grad, w_iter
 
 
 def algorithmic_bytes(cfg):
@@ -173,7 +172,7 @@ def main():
                          "kernel_ms": kms, "flops_per_solve": flops,
                          "hbm_algorithmic_GBps": algorithmic_bytes(cfg) * B / (kms * 1e-3) / 1e9,
                          "note": "FP64 vector/matrix peak (no f64 entry in the MFMA table: "
-                                 "half the 157.3 TF FP32 rate); flops = W_grad + (I+1) W_iter, "
+                                 "half the 157.3 TF FP32 rate); flops = W_grad + I W_iter, "
                                  "SURVEY 8(d) structure-exploiting count"},
         }
         if world == 1 and not args.no_cpu_baseline:

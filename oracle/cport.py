@@ -52,7 +52,7 @@ class RefBatch:
                                          *[_p(a) for a in self._keep])
 
     def step(self, xhat0, lastu0, ry, Z=None, cold=True, nthreads=0, gap_tol=1e-12, res_tol=1e-9,
-             delta=1e-12, max_iter=60):
+             delta=1e-12, max_iter=100):
         B = self.B
         x, lu, r = (np.ascontiguousarray(a, dtype=np.float64) for a in (xhat0, lastu0, ry))
         Z = np.zeros((B, self.nZ)) if Z is None else Z
