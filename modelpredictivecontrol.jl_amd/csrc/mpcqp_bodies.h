@@ -186,39 +186,53 @@ struct Qp {
         const int ny = d.ny, nu = d.nu;
         for (int r = w.lane; r < d.nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
-            // block columns j with jl(j) <= t; default blocking: j = 0..min(t, Hc-1)
-            int jn = d.Hc;
-            if (d.default_nb) jn = t + 1 < d.Hc ? t + 1 : d.Hc;
             double acc0 = 0.0, acc1 = 0.0;
-            MPCQP_UNROLL4
-            for (int j = 0; j < jn; ++j) {
-                if (!d.default_nb && jl(j) > t) break;
-                const double* Sb = S + (t - jl(j)) * sp + a * nu;
-                const double* vj = v + j * nu;
-                int cc = 0;
-                for (; cc + 1 < nu; cc += 2) { acc0 += Sb[cc] * vj[cc]; acc1 += Sb[cc + 1] * vj[cc + 1]; }
-                if (cc < nu) acc0 += Sb[cc] * vj[cc];
+            if (d.default_nb) {
+                // wave-uniform trip count: block columns j > t read block 0 and are masked out
+                const double* Sa = S + a * nu;
+                MPCQP_UNROLL4
+                for (int j = 0; j < d.Hc; ++j) {
+                    const bool ok = j <= t;
+                    const double* Sb = Sa + (ok ? t - j : 0) * sp;
+                    const double* vj = v + j * nu;
+                    double p0 = 0.0, p1 = 0.0;
+                    int cc = 0;
+                    for (; cc + 1 < nu; cc += 2) { p0 += Sb[cc] * vj[cc]; p1 += Sb[cc + 1] * vj[cc + 1]; }
+                    if (cc < nu) p0 += Sb[cc] * vj[cc];
+                    acc0 += ok ? p0 : 0.0;
+                    acc1 += ok ? p1 : 0.0;
+                }
+            } else {
+                for (int j = 0; j < d.Hc && jl(j) <= t; ++j) {
+                    const double* Sb = S + (t - jl(j)) * sp + a * nu;
+                    const double* vj = v + j * nu;
+                    for (int cc = 0; cc < nu; ++cc) acc0 += Sb[cc] * vj[cc];
+                }
             }
             out[r] = acc0 + acc1;
         }
     }
 
     // out[k] += scale * sum_r E[r,k] wv[r]   (k < nDU).  The t loop is wave-uniform (lanes of
-    // later block columns just start contributing later), so wv[t,a] is a broadcast LDS read.
+    // later block columns just start contributing later), so wv[t,a] is a broadcast LDS read and
+    // there is no divergent branch in the loop.
     MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0) {
         const int ny = d.ny, nu = d.nu;
         for (int k = w.lane; k < d.nDU; k += WAVE) {
             const int j = k / nu, cc = k - j * nu, t0 = jl(j);
-            const double* Sk = S + cc - t0 * sp;
+            const double* Sk = S + cc;
             double acc0 = 0.0, acc1 = 0.0;
             MPCQP_UNROLL4
             for (int t = 0; t < d.Hp; ++t) {
-                if (t < t0) continue;
-                const double* Sb = Sk + t * sp;
+                const bool ok = t >= t0;
+                const double* Sb = Sk + (ok ? t - t0 : 0) * sp;
                 const double* wt = wv + t * ny;
+                double p0 = 0.0, p1 = 0.0;
                 int a = 0;
-                for (; a + 1 < ny; a += 2) { acc0 += Sb[a * nu] * wt[a]; acc1 += Sb[(a + 1) * nu] * wt[a + 1]; }
-                if (a < ny) acc0 += Sb[a * nu] * wt[a];
+                for (; a + 1 < ny; a += 2) { p0 += Sb[a * nu] * wt[a]; p1 += Sb[(a + 1) * nu] * wt[a + 1]; }
+                if (a < ny) p0 += Sb[a * nu] * wt[a];
+                acc0 += ok ? p0 : 0.0;
+                acc1 += ok ? p1 : 0.0;
             }
             out[k] += scale * (acc0 + acc1);
         }
@@ -803,6 +817,7 @@ struct Step {
     // ---- primitives of G v: ucum (held cumulative sum), tY = E v, tX = ex̂ v ------------------
     MPCQP_HD void primitives(const double* v) {
         const int nu = d.nu;
+        const long long tic11_ = clock64_();
         if (qp.pair_on(P_U)) {
             double* ucum = sm + c.ucum;
             for (int k = w.lane; k < d.nDU; k += WAVE) {
@@ -813,7 +828,10 @@ struct Step {
                 ucum[k] = acc;
             }
         }
+        prof_[11] += (double)(clock64_() - tic11_);
+        const long long tic12_ = clock64_();
         if (qp.pair_on(P_Y)) qp.E_apply(v, sm + c.tA[P_Y]);
+        prof_[12] += (double)(clock64_() - tic12_);
         if (qp.pair_on(P_X)) {
             double* tX = sm + c.tA[P_X];
             for (int i = w.lane; i < d.nxh; i += WAVE) {
@@ -854,6 +872,7 @@ struct Step {
     template <class Fn>
     MPCQP_HD void apply_Gt(Fn wv) {
         MPCQP_TIC();
+        const long long tic_gt_ = clock64_();
         const int nu = d.nu;
         // per pair: tA[k] = w_max - w_min ; eps accumulates -(c_min w_min + c_max w_max)
         double eacc = 0.0;
@@ -865,6 +884,8 @@ struct Step {
         });
         eacc = w.sum(eacc);
         w.sync();
+        prof_[8] += (double)(clock64_() - tic_gt_);
+        const long long tic9_ = clock64_();
         for (int k = w.lane; k < d.nZ; k += WAVE) {
             double acc = 0.0;
             if (qp.pair_on(P_BOX)) acc += sm[c.tA[P_BOX] + k];
@@ -884,12 +905,15 @@ struct Step {
             }
             gt[k] = acc;
         }
+        prof_[9] += (double)(clock64_() - tic9_);
+        const long long tic10_ = clock64_();
         if (qp.pair_on(P_Y)) qp.Et_apply_add(sm + c.tA[P_Y], gt);   // same lane owns gt[k]
         w.sync();
+        prof_[10] += (double)(clock64_() - tic10_);
         MPCQP_TOC(1);
     }
 
-    // ---- Phi <- H̃ (global -> LDS), hz = H̃ z per lane ----------------------------------------
+    // ---- Phi <- H̃ (global -> LDS) ------------------------------------------------------------
     MPCQP_HD void load_H() {
         const double* H = m.Hpk + (size_t)b * d.npk;
         for (int i = w.lane; i < d.npk; i += WAVE) Phi[i] = H[i];
@@ -997,27 +1021,54 @@ struct Step {
         MPCQP_TIC();
         const int n = d.nZ;
         const int i = w.lane;
-        const int rowi = pk(i < n ? i : 0, 0);
-        const double dia = (i < n) ? Phi[rowi + i] : 1.0;
+        const bool act = i < n;
+        const int rowi = pk(act ? i : 0, 0);
+        const double dia = act ? Phi[rowi + i] : 1.0;
+        // Left-looking, one row per lane, CB columns at a time: the part of the CB dot products
+        // that only needs finished columns (j < k0) is accumulated in one sweep over the lane's
+        // own row (CB independent FMA chains, own-row entry loaded once for CB columns); the
+        // CB x CB triangle inside the block is then finished from registers with v_readlane
+        // broadcasts -- no LDS round trip on the column-to-column dependency.
+        constexpr int CB = 4;
         MPCQP_NOUNROLL
-        for (int k = 0; k < n; ++k) {
-            double v0 = 0.0, v1 = 0.0;
-            if (i >= k && i < n) {
+        for (int k0 = 0; k0 < n; k0 += CB) {
+            double v[CB];
+            const bool mine = act && i >= k0;
+            MPCQP_UNROLL
+            for (int cc = 0; cc < CB; ++cc) v[cc] = (mine && k0 + cc <= i) ? Phi[rowi + k0 + cc] : 0.0;
+            if (mine && k0 > 0) {
                 const double* Li = Phi + rowi;
-                const double* Lk = Phi + pk(k, 0);
-                v0 = Li[k];
-                int j = 0;
-                _Pragma("unroll 4")
-                for (; j + 1 < k; j += 2) { v0 -= Li[j] * Lk[j]; v1 -= Li[j + 1] * Lk[j + 1]; }
-                if (j < k) v0 -= Li[j] * Lk[j];
+                const double* Lk[CB];
+                MPCQP_UNROLL
+                for (int cc = 0; cc < CB; ++cc) Lk[cc] = Phi + pk(k0 + cc < n ? k0 + cc : n - 1, 0);
+                _Pragma("unroll 2")
+                for (int j = 0; j < k0; j += 2) {        // k0 is a multiple of CB: pairs are aligned
+                    const double a0 = Li[j], a1 = Li[j + 1];
+                    MPCQP_UNROLL
+                    for (int cc = 0; cc < CB; ++cc) {
+                        v[cc] -= a0 * Lk[cc][j];
+                        v[cc] -= a1 * Lk[cc][j + 1];
+                    }
+                }
             }
-            const double v = v0 + v1;
-            const double piv = w.bcast(v, k);
-            const double ref = fabs(w.bcast(dia, k));        // original diagonal entry of row k
-            const bool bad = !(piv > 1e-14 * ref);
-            const double id = bad ? 1e-32 : rsqrt_(piv);     // 1/sqrt(pivot)
-            if (i == k) { Phi[pk(k, k)] = bad ? 1e32 : piv * id; invd[k] = id; myinvd = id; }
-            else if (i > k && i < n) Phi[rowi + k] = bad ? 0.0 : v * id;
+            MPCQP_UNROLL
+            for (int cc = 0; cc < CB; ++cc) {
+                const int k = k0 + cc;
+                if (k < n) {
+                    const double piv = w.bcast(v[cc], k);
+                    const double ref = fabs(w.bcast(dia, k));        // original diagonal entry of row k
+                    const bool bad = !(piv > 1e-14 * ref);
+                    const double id = bad ? 1e-32 : rsqrt_(piv);     // 1/sqrt(pivot)
+                    double lk = 0.0;
+                    if (i == k) { Phi[rowi + k] = bad ? 1e32 : piv * id; invd[k] = id; myinvd = id; }
+                    else if (act && i > k) { lk = bad ? 0.0 : v[cc] * id; Phi[rowi + k] = lk; }
+                    MPCQP_UNROLL
+                    for (int c2 = cc + 1; c2 < CB; ++c2) {
+                        const int k2 = k0 + c2;
+                        if (k2 < n) v[c2] -= lk * w.bcast(lk, k2);   // L[i][k] L[k2][k]
+                    }
+                }
+            }
             w.sync();
         }
         MPCQP_TOC(6);
@@ -1105,9 +1156,17 @@ struct Step {
         load_H();
         double mx = 0.0, sc = 0.0;
         for (int k = w.lane; k < n; k += WAVE) {
-            double hz = 0.0;
+            // H̃ z with the packed lower triangle: row k up to the diagonal is contiguous,
+            // the rest of the (symmetric) row comes from column k of the rows below
+            double h0 = 0.0, h1 = 0.0;
+            const double* Hk = Phi + pk(k, 0);
+            int j = 0;
             MPCQP_UNROLL4
-            for (int j = 0; j < n; ++j) hz += Phi[k >= j ? pk(k, j) : pk(j, k)] * z[j];
+            for (; j + 1 <= k; j += 2) { h0 += Hk[j] * z[j]; h1 += Hk[j + 1] * z[j + 1]; }
+            if (j <= k) h0 += Hk[j] * z[j];
+            MPCQP_UNROLL4
+            for (int jj = k + 1; jj < n; ++jj) h1 += Phi[pk(jj, k)] * z[jj];
+            const double hz = h0 + h1;
             const double r = hz + q[k] + gt[k];
             rd[k] = r;
             mx = fmax(mx, fabs(r));

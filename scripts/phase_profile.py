@@ -16,6 +16,7 @@ out = np.empty((B, 16));
 import ctypes as C
 mpcqp.api._chk(lib, lib.mpcqp_get(mpc.hd.h, 99, out.ctypes.data_as(C.c_void_p)))
 names = ["apply_G", "apply_Gt", "loadH+Hz", "GtDG rows", "EtDE(mfma)", "GtDG struct", "cholesky", "solve", "", "", "", "", "", "", "", "run total"]
+sub = {8: "  Gt: rows+reduce", 9: "  Gt: box/U/eps part", 10: "  Gt: Et_apply", 11: "  G: ucum", 12: "  G: E_apply"}
 it = mpc.iters.mean() + 1
 tot = out[:, 15].mean()
 print(f"{name} B={B} kernel {mpc.hd.last_step_ms():.2f} ms, mean iters {mpc.iters.mean():.2f}; mean cycles per wave: {tot:.0f} ({tot/it:.0f} per iteration)")
@@ -24,4 +25,6 @@ for i, n in enumerate(names):
     if n and i < 15:
         v = out[:, i].mean(); acc += v
         print(f"  {n:12s} {v:12.0f} cyc  {100*v/tot:5.1f}%   per-iter {v/it:9.0f}")
+for i, n in sub.items():
+    v = out[:, i].mean(); print(f"  {n:22s} {v:12.0f} cyc  {100*v/tot:5.1f}%   per-iter {v/it:9.0f}")
 print(f"  {'other(rows,..)':12s} {tot-acc:12.0f} cyc  {100*(tot-acc)/tot:5.1f}%   per-iter {(tot-acc)/it:9.0f}")
