@@ -1244,13 +1244,39 @@ struct Step {
         // a restart for those costs more in kernel tail than the average gains.)
         int status = ST_ITERATION_LIMIT;
         int it = 0;
-        for (it = 0; it < d.max_iter; ++it) {
-            residuals(mu, rpn, rdn, ndd);
+        // Residuals are evaluated exactly (G z, G'lam, H̃ z) at the first iterate and whenever the
+        // recursively updated ones claim convergence; in between they follow the Newton identities
+        //   r_p <- r_p + alpha (G dz + ds)   (exact),      r_d <- (1 - alpha) r_d
+        // (first block row of the Newton system is H dz + G'dlam = -r_d), which saves one G z, one
+        // G'lam and one H̃ z per iteration.  A verification that fails simply continues from the
+        // exact values.
+        bool exact = true, verified = false;
+        while (it < d.max_iter) {
+            if (exact) {
+                residuals(mu, rpn, rdn, ndd);      // also stages H̃ in Phi
+                exact = false;
+                verified = true;
+            } else {
+                double musum = 0.0, rpmax = 0.0;
+                for_rows([&](int, int, Row& r) {
+                    if (!fin(r)) return;
+                    rpmax = fmax(rpmax, fabs(r.rp));
+                    musum += r.s * r.lam;
+                });
+                mu = w.sum(musum) / mact;
+                rpn = w.maxv(rpmax);
+                double mx = 0.0;
+                for (int k = w.lane; k < n; k += WAVE) mx = fmax(mx, fabs(rd[k]));
+                rdn = w.maxv(mx);
+                verified = false;
+            }
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
             if (mu <= d.gap_tol && rdn <= d.res_tol * ndd && rpn <= d.res_tol * nh) {
-                status = ST_OPTIMAL;
-                break;
+                if (verified) { status = ST_OPTIMAL; break; }
+                exact = true;                      // re-evaluate exactly at the same iterate
+                continue;
             }
+            if (!verified) load_H();
             add_GtDG([&](Row& r) {
                 const double D = r.lam * rcp(r.s);
                 return D * rcp(1.0 + delta * D);
@@ -1296,9 +1322,11 @@ struct Step {
                 row_step(r, r.s * r.lam + r.pp - smu, ds, dl);
                 r.s += alpha * ds;
                 r.lam += alpha * dl;
+                r.rp += alpha * (r.gd + ds);
             });
-            for (int k = w.lane; k < n; k += WAVE) z[k] += alpha * dz[k];
+            for (int k = w.lane; k < n; k += WAVE) { z[k] += alpha * dz[k]; rd[k] *= (1.0 - alpha); }
             w.sync();
+            ++it;
         }
         // never primal-feasible (or NaN) => the reference's error branch (execute.jl:484-489)
         if (status == ST_ITERATION_LIMIT && !(rpn <= 1e-6 * nh)) status = ST_ERROR;
