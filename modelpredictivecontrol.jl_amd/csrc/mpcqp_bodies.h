@@ -184,32 +184,41 @@ struct Qp {
     // out[r] = sum_k E[r,k] v[k]   (r < nY; v has >= nDU entries)
     MPCQP_HD void E_apply(const double* v, double* out) {
         const int ny = d.ny, nu = d.nu;
+        if constexpr (DM::is_static) {
+            if constexpr (DM::nu == 4 && DM::nY <= 2 * WAVE) {
+                // every lane owns rows r0 = lane and r1 = lane + 64: the (wave-uniform) v[j,:]
+                // loads are shared by both rows; block columns j > t are masked, not branched on
+                const int r0 = w.lane, r1 = w.lane + WAVE;
+                const bool ok0 = r0 < DM::nY, ok1 = r1 < DM::nY;
+                const int t0 = (ok0 ? r0 : 0) / DM::ny, a0 = (ok0 ? r0 : 0) % DM::ny;
+                const int t1 = (ok1 ? r1 : 0) / DM::ny, a1 = (ok1 ? r1 : 0) % DM::ny;
+                double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
+                MPCQP_UNROLL4
+                for (int j = 0; j < DM::Hc; ++j) {
+                    const double* vj = v + j * 4;
+                    const double v0 = vj[0], v1 = vj[1], v2 = vj[2], v3 = vj[3];
+                    const bool m0 = ok0 && j <= t0, m1 = ok1 && j <= t1;
+                    const double* Sa = S + (m0 ? t0 - j : 0) * sp + a0 * 4;
+                    const double* Sb = S + (m1 ? t1 - j : 0) * sp + a1 * 4;
+                    const double q0 = Sa[0] * v0 + Sa[2] * v2, q1 = Sa[1] * v1 + Sa[3] * v3;
+                    const double u0 = Sb[0] * v0 + Sb[2] * v2, u1 = Sb[1] * v1 + Sb[3] * v3;
+                    x0 += m0 ? q0 : 0.0; x1 += m0 ? q1 : 0.0;
+                    y0 += m1 ? u0 : 0.0; y1 += m1 ? u1 : 0.0;
+                }
+                if (ok0) out[r0] = x0 + x1;
+                if (ok1) out[r1] = y0 + y1;
+                return;
+            }
+        }
         for (int r = w.lane; r < d.nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
-            double acc0 = 0.0, acc1 = 0.0;
-            if (d.default_nb) {
-                // wave-uniform trip count: block columns j > t read block 0 and are masked out
-                const double* Sa = S + a * nu;
-                MPCQP_UNROLL4
-                for (int j = 0; j < d.Hc; ++j) {
-                    const bool ok = j <= t;
-                    const double* Sb = Sa + (ok ? t - j : 0) * sp;
-                    const double* vj = v + j * nu;
-                    double p0 = 0.0, p1 = 0.0;
-                    int cc = 0;
-                    for (; cc + 1 < nu; cc += 2) { p0 += Sb[cc] * vj[cc]; p1 += Sb[cc + 1] * vj[cc + 1]; }
-                    if (cc < nu) p0 += Sb[cc] * vj[cc];
-                    acc0 += ok ? p0 : 0.0;
-                    acc1 += ok ? p1 : 0.0;
-                }
-            } else {
-                for (int j = 0; j < d.Hc && jl(j) <= t; ++j) {
-                    const double* Sb = S + (t - jl(j)) * sp + a * nu;
-                    const double* vj = v + j * nu;
-                    for (int cc = 0; cc < nu; ++cc) acc0 += Sb[cc] * vj[cc];
-                }
+            double acc0 = 0.0;
+            for (int j = 0; j < d.Hc && jl(j) <= t; ++j) {
+                const double* Sb = S + (t - jl(j)) * sp + a * nu;
+                const double* vj = v + j * nu;
+                for (int cc = 0; cc < nu; ++cc) acc0 += Sb[cc] * vj[cc];
             }
-            out[r] = acc0 + acc1;
+            out[r] = acc0;
         }
     }
 
@@ -218,6 +227,28 @@ struct Qp {
     // there is no divergent branch in the loop.
     MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0) {
         const int ny = d.ny, nu = d.nu;
+        if constexpr (DM::is_static) {
+            if constexpr (DM::ny == 4 && DM::nu == 4 && DM::nDU <= WAVE) {
+                // lane (j, a) reads whole rows S_{t-j}[a][0..3] (two 16-byte loads instead of four
+                // strided 8-byte ones) and keeps one partial sum per channel c; the four a-lanes
+                // of a block column are then added with two quad permutes and lane a keeps c = a.
+                const int k = w.lane < DM::nDU ? w.lane : 0;
+                const int j = k >> 2, a = k & 3;
+                const double* Sk = S + a * 4;
+                double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                MPCQP_UNROLL4
+                for (int t = 0; t < DM::Hp; ++t) {
+                    const bool ok = t >= j && w.lane < DM::nDU;
+                    const double* Sb = Sk + (ok ? t - j : 0) * sp;
+                    const double wt = ok ? wv[t * 4 + a] : 0.0;
+                    p0 += Sb[0] * wt; p1 += Sb[1] * wt; p2 += Sb[2] * wt; p3 += Sb[3] * wt;
+                }
+                p0 = w.quad_sum(p0); p1 = w.quad_sum(p1); p2 = w.quad_sum(p2); p3 = w.quad_sum(p3);
+                const double mine = a == 0 ? p0 : a == 1 ? p1 : a == 2 ? p2 : p3;
+                if (w.lane < DM::nDU) out[k] += scale * mine;
+                return;
+            }
+        }
         for (int k = w.lane; k < d.nDU; k += WAVE) {
             const int j = k / nu, cc = k - j * nu, t0 = jl(j);
             const double* Sk = S + cc;

@@ -48,6 +48,12 @@ struct DevWave {
         const double c = lane_value(v, 32), d = lane_value(v, 48);
         return op(op(a, b), op(c, d));
     }
+    // sum over each aligned group of four lanes (result in all four)
+    __device__ __forceinline__ double quad_sum(double v) {
+        v += dpp<0xB1>(v);
+        v += dpp<0x4E>(v);
+        return v;
+    }
     __device__ __forceinline__ double sum(double v) { return reduce(v, [](double x, double y) { return x + y; }); }
     __device__ __forceinline__ double minv(double v) { return reduce(v, [](double x, double y) { return fmin(x, y); }); }
     __device__ __forceinline__ double maxv(double v) { return reduce(v, [](double x, double y) { return fmax(x, y); }); }

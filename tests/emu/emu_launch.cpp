@@ -29,6 +29,13 @@ struct EmuWave {
         sync();
         return s;
     }
+    double quad_sum(double v) {
+        sh->xd[lane] = v; sync();
+        const int q = lane & ~3;
+        double s = sh->xd[q] + sh->xd[q + 1] + sh->xd[q + 2] + sh->xd[q + 3];
+        sync();
+        return s;
+    }
     double minv(double v) {
         sh->xd[lane] = v; sync();
         double s = sh->xd[0];
