@@ -296,18 +296,25 @@ struct Qp {
             jI[I] = i < NDU ? j : (1 << 20);           // padding columns never become valid
             offI[I] = -j * SP + cc;
         }
-        // one pass per tile row I (accumulators of row I only: keeps the register budget at
-        // two waves per SIMD); the K loop starts at the first step that reaches block column 16 I / NU
+        // Tile rows are processed in passes whose accumulators fit the register budget of two
+        // waves per SIMD: rows {0,1} together (3 tiles, 3 independent MFMA chains per K step),
+        // then every further row on its own.  A pass starts at the first K step that reaches its
+        // first block column (E is block lower triangular).
+        constexpr int IE = NDU / 16, LE = NDU % 16;     // tile row / lane column of the ϵ row
         MPCQP_UNROLL
-        for (int I = 0; I < NT; ++I) {
-            v4d acc[NT];
+        for (int I0 = 0; I0 < NT; I0 += (I0 == 0 ? 2 : 1)) {
+            constexpr int MAXT = NT + 1;
+            const int I1 = (I0 == 0 && NT > 1) ? 1 : I0;              // last tile row of the pass
+            v4d acc[2][MAXT];
             MPCQP_UNROLL
-            for (int J = 0; J <= I; ++J) acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
+            for (int x = 0; x < 2; ++x) {
+                MPCQP_UNROLL
+                for (int J = 0; J < MAXT; ++J) acc[x][J] = v4d{0.0, 0.0, 0.0, 0.0};
+            }
             // ϵ row (index NDU, when present): row NDU of Phi is sum_r tb[r] E[r,:], i.e. the same
             // contraction with A operand tb instead of E*dd -- rides in its tile row for free
-            constexpr int IE = NDU / 16, LE = NDU % 16;
-            const bool erow = DM::neps && tb != nullptr && I == IE;
-            const int kk0 = erow ? 0 : (((16 * I) / NU) * NY) / 4;    // first K step with t >= jmin(I)
+            const bool erow = DM::neps && tb != nullptr && IE >= I0 && IE <= I1;
+            const int kk0 = erow ? 0 : (((16 * I0) / NU) * NY) / 4;   // first K step with t >= jmin(I0)
             _Pragma("unroll 2")
             for (int kk = kk0; kk < NK; ++kk) {
                 const int r = 4 * kk + lk;
@@ -318,24 +325,35 @@ struct Qp {
                 const int base = t * SP + a * NU;
                 double e[NT];
                 MPCQP_UNROLL
-                for (int J = 0; J <= I; ++J) {
+                for (int J = 0; J <= I1; ++J) {
                     const bool ok = rok && t >= jI[J];
                     const double sv = S[ok ? base + offI[J] : 0];
                     e[J] = ok ? sv : 0.0;
                 }
-                double ad = e[I] * dv;
-                if (erow && li == LE) ad = rok ? tb[rr] : 0.0;
+                const int tmax = (4 * kk + 3) / NY;                    // wave-uniform
                 MPCQP_UNROLL
-                for (int J = 0; J <= I; ++J)
-                    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[J], 0, 0, 0);
+                for (int I = I0; I <= I1; ++I) {
+                    const bool eI = erow && I == IE;
+                    if (eI || tmax >= (16 * I) / NU) {
+                        double ad = e[I] * dv;
+                        if (eI && li == LE) ad = rok ? tb[rr] : 0.0;
+                        MPCQP_UNROLL
+                        for (int J = 0; J <= I; ++J)
+                            acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[I - I0][J], 0, 0, 0);
+                    }
+                }
             }
             MPCQP_UNROLL
-            for (int J = 0; J <= I; ++J) {
+            for (int I = I0; I <= I1; ++I) {
+                const bool eI = erow && I == IE;
                 MPCQP_UNROLL
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int i = 16 * I + lk + 4 * reg, ip = 16 * J + li;
-                    if (ip < NDU && ((i < NDU && ip <= i) || (erow && i == NDU)))
-                        P[pk(i, ip)] += scale * acc[J][reg];
+                for (int J = 0; J <= I; ++J) {
+                    MPCQP_UNROLL
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = 16 * I + lk + 4 * reg, ip = 16 * J + li;
+                        if (ip < NDU && ((i < NDU && ip <= i) || (eI && i == NDU)))
+                            P[pk(i, ip)] += scale * acc[I - I0][J][reg];
+                    }
                 }
             }
         }
@@ -1139,14 +1157,12 @@ struct Step {
             MPCQP_UNROLL
             for (int u = 0; u < CH; ++u) {
                 const int k = k0 + u;
-                if (k < n) {
-                    const double yk = w.bcast(r * myinvd, k);
-                    r = (i == k) ? yk : r - lc[u] * yk;      // lc = 0 for lanes i <= k or i >= n
-                }
+                if (k < n) r -= lc[u] * w.bcast(r * myinvd, k);     // lc = 0 for lanes i <= k or i >= n
             }
             MPCQP_UNROLL
             for (int u = 0; u < CH; ++u) lc[u] = ln[u];
         }
+        r *= myinvd;      // y_i = (r_i - sum_{k<i} L[i][k] y_k) / L[i][i]; lanes >= n hold 0
         // L' x = y, row sweep (lane i < k needs L[k][i]: row k, contiguous)
         MPCQP_UNROLL
         for (int u = 0; u < CH; ++u) { const int k = n - 1 - u; lc[u] = (k >= 0 && k > i) ? Phi[pk(k, 0) + i] : 0.0; }
@@ -1157,15 +1173,12 @@ struct Step {
             MPCQP_UNROLL
             for (int u = 0; u < CH; ++u) {
                 const int k = k0 - u;
-                if (k >= 0) {
-                    const double xk = w.bcast(r * myinvd, k);
-                    r = (i == k) ? xk : r - lc[u] * xk;      // lc = 0 for lanes i >= k
-                }
+                if (k >= 0) r -= lc[u] * w.bcast(r * myinvd, k);    // lc = 0 for lanes i >= k
             }
             MPCQP_UNROLL
             for (int u = 0; u < CH; ++u) lc[u] = ln[u];
         }
-        if (i < n) dz[i] = r;
+        if (i < n) dz[i] = r * myinvd;
         w.sync();
         MPCQP_TOC(7);
     }
