@@ -138,6 +138,11 @@ def main():
         dist.all_reduce(agg)
         n_opt, mean_it = int(agg[0].item()), float(agg[1].item()) / (B * world)
 
+    # setmodel! path (K1 + K2 re-condensation of all models), reported next to the step time
+    hd.recondense_device(stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    recond_ms = hd.last_condense_ms()
+
     if rank == 0:
         total = B * world * args.steps
         value = total / elapsed
@@ -165,6 +170,7 @@ def main():
                        "nx": cfg.nx, "nxhat": nxh, "nu": nu, "ny": ny, "Hp": Hp, "Hc": Hc,
                        "nZ": hd.nZ, "rows": int(rows_u + rows_y + neps), "cold_start": True,
                        "ipm_mean_iters": mean_it, "optimal_fraction": n_opt / (B * world),
+                       "recondense_ms": recond_ms,
                        "sharding": "contiguous index ranges, no collective on the data path"},
             "roofline": {"bound": "mfma", "kernel": "k_step", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -114,10 +114,11 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
     c.S = take(d.Hp * stride_S(d));
     c.Phi = take(d.npk);
-    c.invd = take(d.nZ);
+    c.invd = 0;                                   // (1/L[k][k] lives in a register of lane k)
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
-    c.zlo = take(d.nZ); c.zhi = take(d.nZ); c.gt = take(d.nZ); c.rd = take(d.nZ);
-    c.F = take(d.nY);
+    c.gt = take(d.nZ); c.rd = take(d.nZ);
+    c.zlo = c.dz; c.zhi = c.gt;                   // only live while the rows are being set up
+    c.F = -1;                                     // placed below (aliases the Ŷ-row scratch when it exists)
     MPCQP_UNROLL
     for (int p = 0; p < NPAIR; ++p) {
         const bool on = (d.gmask >> (2 * p)) & 3u;
@@ -125,6 +126,9 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
         c.tA[p] = take((on || p == P_Y) ? d.cnt(p) : 0);
         c.tB[p] = take((on && p != P_BOX) ? d.cnt(p) : 0);
     }
+    // F is consumed by the end of Step::build (it goes into the right-hand sides; the optional Ŷ
+    // output parks it in the caller's Yhat0 buffer), so it shares the tB scratch of the Ŷ rows
+    c.F = (((d.gmask >> (2 * P_Y)) & 3u) && c.tB[P_Y] >= 0) ? c.tB[P_Y] : take(d.nY);
     c.ucum = take(d.nDU);
     c.exT = take(((d.gmask >> (2 * P_X)) & 3u) ? d.Hc * d.nxh * d.nu : 0);
     const int M = DM::is_static ? 0 : d.nrows();
@@ -1109,7 +1113,7 @@ struct Step {
                     const bool bad = !(piv > 1e-14 * ref);
                     const double id = bad ? 1e-32 : rsqrt_(piv);     // 1/sqrt(pivot)
                     double lk = 0.0;
-                    if (i == k) { Phi[rowi + k] = bad ? 1e32 : piv * id; invd[k] = id; myinvd = id; }
+                    if (i == k) { Phi[rowi + k] = bad ? 1e32 : piv * id; myinvd = id; }
                     else if (act && i > k) { lk = bad ? 0.0 : v[cc] * id; Phi[rowi + k] = lk; }
                     MPCQP_UNROLL
                     for (int c2 = cc + 1; c2 < CB; ++c2) {
@@ -1147,34 +1151,39 @@ struct Step {
         // solution, so they are fetched CH columns ahead of the dependent chain (which is then
         // v_mul -> v_readlane -> v_fma per column, no LDS round trip).
         constexpr int CH = 4;
+        const int nc = (n + CH - 1) / CH * CH;      // padded step count: lanes >= n hold r = 0, invd = 0
         double lc[CH], ln[CH];
+        // unconditional loads at a clamped index + a select: no exec-mask juggling per load
+        auto Lcol = [&](int k) {                     // L[i][k] for i > k, else 0
+            const double x = Phi[rowi + (k < ii ? k : 0)];
+            return (k < ii && i < n) ? x : 0.0;
+        };
+        auto Lrow = [&](int k) {                     // L[k][i] for k > i (k < n), else 0
+            const bool ok = k > i && k < n;
+            const double x = Phi[ok ? pk(k, 0) + i : 0];
+            return ok ? x : 0.0;
+        };
         MPCQP_UNROLL
-        for (int u = 0; u < CH; ++u) lc[u] = (u < ii) ? Phi[rowi + u] : 0.0;
+        for (int u = 0; u < CH; ++u) lc[u] = Lcol(u);
         MPCQP_NOUNROLL
-        for (int k0 = 0; k0 < n; k0 += CH) {
+        for (int k0 = 0; k0 < nc; k0 += CH) {
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) { const int k = k0 + CH + u; ln[u] = (k < ii) ? Phi[rowi + k] : 0.0; }
+            for (int u = 0; u < CH; ++u) ln[u] = Lcol(k0 + CH + u);
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) {
-                const int k = k0 + u;
-                if (k < n) r -= lc[u] * w.bcast(r * myinvd, k);     // lc = 0 for lanes i <= k or i >= n
-            }
+            for (int u = 0; u < CH; ++u) r -= lc[u] * w.bcast(r * myinvd, k0 + u);
             MPCQP_UNROLL
             for (int u = 0; u < CH; ++u) lc[u] = ln[u];
         }
         r *= myinvd;      // y_i = (r_i - sum_{k<i} L[i][k] y_k) / L[i][i]; lanes >= n hold 0
         // L' x = y, row sweep (lane i < k needs L[k][i]: row k, contiguous)
         MPCQP_UNROLL
-        for (int u = 0; u < CH; ++u) { const int k = n - 1 - u; lc[u] = (k >= 0 && k > i) ? Phi[pk(k, 0) + i] : 0.0; }
+        for (int u = 0; u < CH; ++u) lc[u] = Lrow(nc - 1 - u);
         MPCQP_NOUNROLL
-        for (int k0 = n - 1; k0 >= 0; k0 -= CH) {
+        for (int k0 = nc - 1; k0 >= 0; k0 -= CH) {
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) { const int k = k0 - CH - u; ln[u] = (k >= 0 && k > i) ? Phi[pk(k, 0) + i] : 0.0; }
+            for (int u = 0; u < CH; ++u) ln[u] = Lrow(k0 - CH - u);
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) {
-                const int k = k0 - u;
-                if (k >= 0) r -= lc[u] * w.bcast(r * myinvd, k);    // lc = 0 for lanes i >= k
-            }
+            for (int u = 0; u < CH; ++u) r -= lc[u] * w.bcast(r * myinvd, k0 - u);
             MPCQP_UNROLL
             for (int u = 0; u < CH; ++u) lc[u] = ln[u];
         }
@@ -1395,6 +1404,8 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
         for (int k = w.lane; k < d.nZ; k += WAVE) io.q_keep[(size_t)b * d.nZ + k] = st.q[k];
         for (int r = w.lane; r < d.nY; r += WAVE) io.F_keep[(size_t)b * d.nY + r] = st.F[r];
     }
+    if (io.Yhat0)      // park F in the output buffer: its LDS copy is scratch from here on
+        for (int r = w.lane; r < d.nY; r += WAVE) io.Yhat0[(size_t)b * d.nY + r] = st.F[r];
     int iters = 0;
     const long long t_run0 = Step<W, DM>::clock64_();
     const int status = st.run(io, iters);
@@ -1410,7 +1421,7 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
     if (io.Yhat0) {
         double* tY = sm + st.c.tA[P_Y];
         qp.E_apply(st.z, tY);
-        for (int r = w.lane; r < d.nY; r += WAVE) io.Yhat0[(size_t)b * d.nY + r] = tY[r] + st.F[r];
+        for (int r = w.lane; r < d.nY; r += WAVE) io.Yhat0[(size_t)b * d.nY + r] += tY[r];      // same lane parked F[r]
     }
     if (w.lane == 0) {
         io.status[b] = status;

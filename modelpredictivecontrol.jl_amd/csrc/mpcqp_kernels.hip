@@ -9,6 +9,10 @@
 #include "mpcqp_dispatch.h"
 #include "mpcqp_launch.h"
 
+#ifndef MPCQP_STEP_WAVES
+#define MPCQP_STEP_WAVES 2      // register budget of the specialised step kernel, in waves per SIMD
+#endif
+
 namespace mpcqp {
 
 // Wave-level primitives without LDS traffic: reductions run on DPP lane permutes inside each
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(64) void k_hessian_s(Dims d, Model m) {
 
 // specialised on compile-time dimensions (mpcqp_dispatch.h)
 template <class SD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_step_s(Dims d, Model m, StepIO io) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_STEP_WAVES, 8))) void k_step_s(Dims d, Model m, StepIO io) {
     DevWave w{(int)threadIdx.x};
     const SD sd(d);
     step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem);
