@@ -170,6 +170,23 @@ int mpcqp_recondense_device(mpcqp_handle h, void* stream);
 #define MPCQP_GET_FVEC      6
 int mpcqp_get(mpcqp_handle h, int which, double* out);
 
+/* ---- next row: the SteadyKalmanFilter steps on both sides of moveinput! --------
+ * `preparestate!` -> correct_estimate_obsv! (src/estimator/kalman.jl:284-295):
+ *       x̂0 += K̂ (y0m - Ĉm x̂0 - D̂dm d0)
+ * `updatestate!`  -> predict_estimate_obsv! (src/estimator/kalman.jl:298-309):
+ *       x̂0 <- Â x̂0 + B̂u u0 + B̂d d0 + (f̂op - x̂op)
+ * on the model given to mpcqp_set_model, so that a closed loop keeps x̂0 resident on the GPU.
+ * Khat (nx̂,nym,B) is the steady-state gain (the reference gets it from
+ * ControlSystemsBase.kalman at construction, kalman.jl:204-236: host-side, once);
+ * i_ym [nym] are the 0-based indices of the measured outputs.  nx̂ <= 64.                     */
+int mpcqp_kf_set(mpcqp_handle h, const double* Khat, const int32_t* i_ym, int32_t nym);
+/* xhat0 (nx̂,B) in/out, y0m (nym,B), d0 (nd,B) or NULL, u0 (nu,B): host pointers, synchronous */
+int mpcqp_kf_correct(mpcqp_handle h, double* xhat0, const double* y0m, const double* d0);
+int mpcqp_kf_predict(mpcqp_handle h, double* xhat0, const double* u0, const double* d0);
+/* device pointers, asynchronous on `stream` */
+int mpcqp_kf_correct_device(mpcqp_handle h, double* xhat0, const double* y0m, const double* d0, void* stream);
+int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, const double* d0, void* stream);
+
 /* Device time of the kernels of the last step / recondense on this handle, measured with HIP
  * events on the stream they ran on (milliseconds; < 0 if not available).                     */
 double mpcqp_last_step_ms(mpcqp_handle h);

@@ -32,7 +32,8 @@ GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC = 1, 2, 3, 4
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
            "mpcqp_destroy", "mpcqp_get_sizes", "mpcqp_set_model", "mpcqp_set_weights",
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_recondense_device",
-           "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms")
+           "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_kf_set",
+           "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -95,6 +96,11 @@ def load_library(path: str | None = None):
     lib.mpcqp_last_step_ms.argtypes = [C.c_void_p]
     lib.mpcqp_last_condense_ms.restype = C.c_double
     lib.mpcqp_last_condense_ms.argtypes = [C.c_void_p]
+    lib.mpcqp_kf_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.mpcqp_kf_correct.argtypes = [C.c_void_p] * 4
+    lib.mpcqp_kf_predict.argtypes = [C.c_void_p] * 4
+    lib.mpcqp_kf_correct_device.argtypes = [C.c_void_p] * 5
+    lib.mpcqp_kf_predict_device.argtypes = [C.c_void_p] * 5
     _lib = lib
     return lib
 
@@ -213,8 +219,53 @@ class Handle:
     def last_step_ms(self):
         return self.lib.mpcqp_last_step_ms(self.h)
 
+    # -- SteadyKalmanFilter steps -----------------------------------------------
+    def kf_set(self, Khat, i_ym):
+        K = _f64(Khat)
+        iy = np.ascontiguousarray(i_ym, dtype=np.int32)
+        self.nym = int(iy.size)
+        _chk(self.lib, self.lib.mpcqp_kf_set(self.h, _ptr(K), _ptr(iy), self.nym))
+
+    def kf_correct(self, xhat0, y0m, d0=None):
+        """x̂0 += K̂ (y0m - Ĉm x̂0 - D̂dm d0), in place on the (B,nx̂) host array."""
+        assert xhat0.dtype == np.float64 and xhat0.flags.c_contiguous
+        y, dd = _f64(y0m), (None if d0 is None else _f64(d0))
+        _chk(self.lib, self.lib.mpcqp_kf_correct(self.h, _ptr(xhat0), _ptr(y), _ptr(dd)))
+
+    def kf_predict(self, xhat0, u0, d0=None):
+        """x̂0 <- Â x̂0 + B̂u u0 + B̂d d0 + (f̂op - x̂op), in place on the (B,nx̂) host array."""
+        assert xhat0.dtype == np.float64 and xhat0.flags.c_contiguous
+        u, dd = _f64(u0), (None if d0 is None else _f64(d0))
+        _chk(self.lib, self.lib.mpcqp_kf_predict(self.h, _ptr(xhat0), _ptr(u), _ptr(dd)))
+
+    def kf_correct_device(self, xhat0, y0m, d0=0, stream=0):
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _chk(self.lib, self.lib.mpcqp_kf_correct_device(self.h, v(xhat0), v(y0m), v(d0), v(stream)))
+
+    def kf_predict_device(self, xhat0, u0, d0=0, stream=0):
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _chk(self.lib, self.lib.mpcqp_kf_predict_device(self.h, v(xhat0), v(u0), v(d0), v(stream)))
+
     def last_condense_ms(self):
         return self.lib.mpcqp_last_condense_ms(self.h)
+
+
+def steady_kalman_gain(Ahat, Chat, Qhat, Rhat, i_ym=None):
+    """K̂ of `SteadyKalmanFilter` for a batch: filter-form gain P Ĉm'(Ĉm P Ĉm' + R̂)^-1 with P the
+    predictor DARE solution (`init_skf`, src/estimator/kalman.jl:204-236; construction-time,
+    host-side like the reference, which calls ControlSystemsBase.kalman)."""
+    from scipy.linalg import solve_discrete_are
+    Ahat, Chat = np.asarray(Ahat, float), np.asarray(Chat, float)
+    B, ny, nxh = Chat.shape
+    i_ym = np.arange(ny) if i_ym is None else np.asarray(i_ym, int)
+    Q = np.broadcast_to(np.asarray(Qhat, float), (B, nxh, nxh))
+    R = np.broadcast_to(np.asarray(Rhat, float), (B, len(i_ym), len(i_ym)))
+    K = np.empty((B, nxh, len(i_ym)))
+    for b in range(B):
+        Cm = Chat[b][i_ym]
+        P = solve_discrete_are(Ahat[b].T, Cm.T, Q[b], R[b])
+        K[b] = P @ Cm.T @ np.linalg.inv(Cm @ P @ Cm.T + R[b])
+    return K
 
 
 def move_blocking(Hp, Hc):
@@ -405,6 +456,35 @@ class BatchLinMPC:
         self.hd.set_bounds(**{k: v for k, v in new.items() if v is not None})
         return self
 
+    # -- estimator steps on both sides of moveinput! (SteadyKalmanFilter) ---------------------
+    def setestimator(self, Khat, i_ym=None, xhat0=None):
+        """Attach a SteadyKalmanFilter: Khat (B,nx̂,nym) steady-state gain (see
+        `steady_kalman_gain`), i_ym measured-output indices (default all).  The estimate x̂0
+        (deviation, (B,nx̂)) is then carried by this object like `mpc.estim.x̂0`."""
+        self.i_ym = np.arange(self.ny) if i_ym is None else np.asarray(i_ym, int)
+        Khat = np.asarray(Khat, float)
+        if Khat.shape != (self.B, self.nxh, len(self.i_ym)):
+            raise ValueError("Khat size must be (B, nx̂, nym)")
+        self.hd.kf_set(colmajor(Khat), self.i_ym)
+        self.xhat0 = np.zeros((self.B, self.nxh)) if xhat0 is None else _f64(np.broadcast_to(xhat0, (self.B, self.nxh))).copy()
+        return self
+
+    def preparestate(self, ym, d=None):
+        """`preparestate!` (src/estimator/execute.jl:334-345 -> correct_estimate_obsv!,
+        kalman.jl:284-295): x̂0 += K̂ (y0m - Ĉm x̂0 - D̂dm d0).  Returns x̂ = x̂0 + x̂op."""
+        y0m = self._bc(ym, len(self.i_ym), "ym") - self.yop[:, self.i_ym]
+        d0 = None if self.nd == 0 else self._bc(d, self.nd, "d") - self.dop
+        self.hd.kf_correct(self.xhat0, y0m, d0)
+        return self.xhat0 + self.xhop
+
+    def updatestate(self, u, ym=None, d=None):
+        """`updatestate!` (src/estimator/execute.jl:374-386 -> predict_estimate_obsv!,
+        kalman.jl:298-309): x̂0 <- Â x̂0 + B̂u u0 + B̂d d0 + f̂op - x̂op."""
+        u0 = self._bc(u, self.nu, "u") - self.uop
+        d0 = None if self.nd == 0 else self._bc(d, self.nd, "d") - self.dop
+        self.hd.kf_predict(self.xhat0, u0, d0)
+        return self.xhat0 + self.xhop
+
     # -- per-step ---------------------------------------------------------------------------
     def initstate(self, u):
         """controller part of `initstate!` (src/controller/execute.jl:9-13)."""
@@ -419,6 +499,8 @@ class BatchLinMPC:
         (B,ny*Hp), `Rhatu` (B,nu*Hp), `Dhat` (B,nd*Hp) are engineering values like the reference.
         Returns u (B,nu)."""
         B, Hp = self.B, self.Hp
+        if xhat0 is None:
+            xhat0 = self.xhat0                      # the attached estimator's state (setestimator)
         xhat0 = np.asarray(xhat0, float)
         if xhat0.shape != (B, self.nxh):
             raise ValueError(f"xhat0 size must be ({B},{self.nxh})")

@@ -1429,4 +1429,43 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// SteadyKalmanFilter steps.  One lane per state of one problem; a problem's nx̂
+// lanes sit in one wavefront, so "all lanes read, then all lanes write" needs no barrier on the
+// GPU (xin == xhat0 there; the CPU emulator passes a copy as xin).
+// `slot` = problem handled by this lane, `i` = state index (inactive when i >= nxh).
+// ------------------------------------------------------------------------------------------
+MPCQP_HD inline void kf_correct_lane(const Dims& d, const Model& m, const KfParams& kf, int slot, int i,
+                                     const double* xin, double* xhat0, const double* y0m, const double* d0) {
+    if (slot >= d.B || i >= d.nxh) return;
+    const int nx = d.nxh, ny = d.ny, nd = d.nd;
+    const double* x = xin + (size_t)slot * nx;
+    const double* Cm = m.C + (size_t)slot * ny * nx;            // (ny,nx̂) col-major
+    const double* K = kf.Khat + (size_t)slot * kf.nym * nx;     // (nx̂,nym) col-major
+    double acc = x[i];
+    for (int mm = 0; mm < kf.nym; ++mm) {
+        const int a = kf.i_ym[mm];
+        double v = y0m[(size_t)slot * kf.nym + mm];             // innovation y0m - Ĉm x̂0 - D̂dm d0
+        for (int k = 0; k < nx; ++k) v -= Cm[a + ny * k] * x[k];
+        for (int e = 0; e < nd; ++e) v -= m.Dd[(size_t)slot * ny * nd + a + ny * e] * d0[(size_t)slot * nd + e];
+        acc += K[i + nx * mm] * v;
+    }
+    // (all loads of the wave above precede this store in program order)
+    xhat0[(size_t)slot * nx + i] = acc;
+}
+
+MPCQP_HD inline void kf_predict_lane(const Dims& d, const Model& m, int slot, int i, const double* xin,
+                                     double* xhat0, const double* u0, const double* d0) {
+    if (slot >= d.B || i >= d.nxh) return;
+    const int nx = d.nxh, nu = d.nu, nd = d.nd;
+    const double* x = xin + (size_t)slot * nx;
+    const double* A = m.Ahat + (size_t)slot * nx * nx;
+    double acc = m.dop ? m.dop[(size_t)slot * nx + i] : 0.0;
+    for (int k = 0; k < nx; ++k) acc += A[i + nx * k] * x[k];
+    for (int c = 0; c < nu; ++c) acc += m.Bu[(size_t)slot * nx * nu + i + nx * c] * u0[(size_t)slot * nu + c];
+    for (int e = 0; e < nd; ++e) acc += m.Bd[(size_t)slot * nx * nd + i + nx * e] * d0[(size_t)slot * nd + e];
+    xhat0[(size_t)slot * nx + i] = acc;
+}
+
 }  // namespace mpcqp

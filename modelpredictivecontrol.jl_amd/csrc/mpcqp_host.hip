@@ -45,6 +45,10 @@ struct mpcqp_handle_s {
     // staging for the host-pointer step
     DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
     DBuf keep_q, keep_F, prof;
+    // SteadyKalmanFilter
+    DBuf kf_K, kf_iym, kf_x, kf_y, kf_u, kf_d;
+    KfParams kf{};
+    bool have_kf = false;
 };
 
 static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
@@ -482,6 +486,75 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
         default:
             return MPCQP_ERR_ARG;
     }
+}
+
+int mpcqp_kf_set(mpcqp_handle h, const double* Khat, const int32_t* i_ym, int32_t nym) {
+    if (!h || !Khat || !i_ym) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    if (nym < 1 || nym > d.ny) return MPCQP_ERR_DIMS;
+    if (d.nxh > 64) return MPCQP_ERR_UNSUPPORTED;
+    for (int i = 0; i < nym; ++i) {
+        if (i_ym[i] < 0 || i_ym[i] >= d.ny) return MPCQP_ERR_ARG;     // validate_ym, construct.jl:190-196
+        for (int j = 0; j < i; ++j)
+            if (i_ym[j] == i_ym[i]) return MPCQP_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = upload(h, h->kf_K, Khat, (size_t)d.B * d.nxh * nym * sizeof(double));
+    if (!rc) rc = upload(h, h->kf_iym, i_ym, (size_t)nym * sizeof(int32_t));
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->kf.Khat = (const double*)h->kf_K.p;
+    h->kf.i_ym = (const int*)h->kf_iym.p;
+    h->kf.nym = nym;
+    h->have_kf = true;
+    return MPCQP_OK;
+}
+
+int mpcqp_kf_correct_device(mpcqp_handle h, double* xhat0, const double* y0m, const double* d0, void* stream) {
+    if (!h || !xhat0 || !y0m) return MPCQP_ERR_NULL;
+    if (h->d.nd > 0 && !d0) return MPCQP_ERR_NULL;
+    if (!h->have_model || !h->have_kf) return MPCQP_ERR_ORDER;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(launch_kf_correct(h->d, h->m, h->kf, xhat0, y0m, d0, (hipStream_t)stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, const double* d0, void* stream) {
+    if (!h || !xhat0 || !u0) return MPCQP_ERR_NULL;
+    if (h->d.nd > 0 && !d0) return MPCQP_ERR_NULL;
+    if (!h->have_model) return MPCQP_ERR_ORDER;
+    if (h->d.nxh > 64) return MPCQP_ERR_UNSUPPORTED;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(launch_kf_predict(h->d, h->m, xhat0, u0, d0, (hipStream_t)stream));
+    return MPCQP_OK;
+}
+
+static int kf_host(mpcqp_handle h, double* xhat0, const double* a, size_t na, const double* d0, bool correct) {
+    if (!h || !xhat0 || !a) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    if (d.nd > 0 && !d0) return MPCQP_ERR_NULL;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = d.B, sz = sizeof(double);
+    int rc = upload(h, h->kf_x, xhat0, B * d.nxh * sz);
+    if (!rc) rc = upload(h, correct ? h->kf_y : h->kf_u, a, B * na * sz);
+    if (!rc && d.nd > 0) rc = upload(h, h->kf_d, d0, B * d.nd * sz);
+    if (rc) return rc;
+    const double* dd = d.nd > 0 ? (const double*)h->kf_d.p : nullptr;
+    rc = correct ? mpcqp_kf_correct_device(h, (double*)h->kf_x.p, (const double*)h->kf_y.p, dd, h->stream)
+                 : mpcqp_kf_predict_device(h, (double*)h->kf_x.p, (const double*)h->kf_u.p, dd, h->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(xhat0, h->kf_x.p, B * d.nxh * sz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_kf_correct(mpcqp_handle h, double* xhat0, const double* y0m, const double* d0) {
+    if (h && !h->have_kf) return MPCQP_ERR_ORDER;
+    return kf_host(h, xhat0, y0m, h ? (size_t)h->kf.nym : 0, d0, true);
+}
+
+int mpcqp_kf_predict(mpcqp_handle h, double* xhat0, const double* u0, const double* d0) {
+    return kf_host(h, xhat0, u0, h ? (size_t)h->d.nu : 0, d0, false);
 }
 
 static double elapsed(hipEvent_t a, hipEvent_t b, bool timed) {

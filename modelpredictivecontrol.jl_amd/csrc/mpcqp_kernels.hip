@@ -101,6 +101,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_STEP_W
     step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem);
 }
 
+// SteadyKalmanFilter steps: npad = next power of two >= nx̂ lanes per problem, 256-thread blocks
+__global__ __launch_bounds__(256) void k_kf_correct(Dims d, Model m, KfParams kf, double* xhat0,
+                                                    const double* y0m, const double* d0, int npad) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    kf_correct_lane(d, m, kf, g / npad, g % npad, xhat0, xhat0, y0m, d0);
+}
+
+__global__ __launch_bounds__(256) void k_kf_predict(Dims d, Model m, double* xhat0, const double* u0,
+                                                    const double* d0, int npad) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    kf_predict_lane(d, m, g / npad, g % npad, xhat0, xhat0, u0, d0);
+}
+
 // ---- launchers (host) ------------------------------------------------------------------------
 static hipError_t ensure_lds(const void* fn, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
@@ -165,6 +178,30 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
     hipError_t e = ensure_lds((const void*)k_step, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_step, dim3(d.B), dim3(WAVE), lds, st, d, m, io);
+    return hipGetLastError();
+}
+
+static int kf_npad(const Dims& d) {
+    int n = 1;
+    while (n < d.nxh) n <<= 1;
+    return n;
+}
+
+hipError_t launch_kf_correct(const Dims& d, const Model& m, const KfParams& kf, double* xhat0,
+                             const double* y0m, const double* d0, hipStream_t st) {
+    const int npad = kf_npad(d);
+    const long long total = (long long)d.B * npad;
+    hipLaunchKernelGGL(k_kf_correct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, m, kf,
+                       xhat0, y0m, d0, npad);
+    return hipGetLastError();
+}
+
+hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const double* u0,
+                             const double* d0, hipStream_t st) {
+    const int npad = kf_npad(d);
+    const long long total = (long long)d.B * npad;
+    hipLaunchKernelGGL(k_kf_predict, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, m,
+                       xhat0, u0, d0, npad);
     return hipGetLastError();
 }
 

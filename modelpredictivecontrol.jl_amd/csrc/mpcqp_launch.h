@@ -9,4 +9,8 @@ hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStrea
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st);
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
 size_t step_lds_bytes(const Dims& d);
+hipError_t launch_kf_correct(const Dims& d, const Model& m, const KfParams& kf, double* xhat0,
+                             const double* y0m, const double* d0, hipStream_t st);
+hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const double* u0,
+                             const double* d0, hipStream_t st);
 }  // namespace mpcqp

@@ -85,6 +85,13 @@ struct Model {
     const int* blk;  // [Hp]   index of the block that holds step t
 };
 
+// steady-state Kalman filter of the batch (estimator/kalman.jl:284-309)
+struct KfParams {
+    const double* Khat;   // [B][nym][nxh]  (ABI (nx̂,nym,B): nx̂ fastest)
+    const int* i_ym;      // [nym]
+    int nym;
+};
+
 struct StepIO {
     const double *xhat0, *lastu0, *Ry, *Ru, *d0, *Dhat0;
     double *Z, *u0, *Yhat0;

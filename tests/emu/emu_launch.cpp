@@ -123,6 +123,20 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
     run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { step_body(w, d, m, io, b, sm); });
     return hipSuccess;
 }
+hipError_t launch_kf_correct(const Dims& d, const Model& m, const KfParams& kf, double* xhat0,
+                             const double* y0m, const double* d0, hipStream_t) {
+    std::vector<double> xin(xhat0, xhat0 + (size_t)d.B * d.nxh);     // lanes are not in lockstep here
+    for (int b = 0; b < d.B; ++b)
+        for (int i = 0; i < d.nxh; ++i) kf_correct_lane(d, m, kf, b, i, xin.data(), xhat0, y0m, d0);
+    return hipSuccess;
+}
+hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const double* u0,
+                             const double* d0, hipStream_t) {
+    std::vector<double> xin(xhat0, xhat0 + (size_t)d.B * d.nxh);
+    for (int b = 0; b < d.B; ++b)
+        for (int i = 0; i < d.nxh; ++i) kf_predict_lane(d, m, b, i, xin.data(), xhat0, u0, d0);
+    return hipSuccess;
+}
 size_t step_lds_bytes(const Dims& d) { return (size_t)make_carve(d).total * sizeof(double); }
 
 }  // namespace mpcqp

@@ -124,3 +124,38 @@ def test_host_argument_validation(emulib):
         mpc.setconstraint(c_umax=[0.1])                  # construct.jl:443
     with pytest.raises(RuntimeError, match="Inf"):
         mpc.setconstraint(umax=[np.inf])                 # construct.jl:549-551
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("nd", [0, 1])
+def test_kalman_steps_on_cpu_emulator(nd, emulib):
+    """preparestate!/updatestate! of the SteadyKalmanFilter around moveinput!, closed
+    loop of 6 periods, against the oracle's estimator + controller."""
+    kf, orc, kw, model = _small_case(nd)
+    B = 2
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd) if nd else None,
+                            rep(kf.Dhd) if nd else None, uop=model.uop, yop=model.yop, dop=model.dop,
+                            xhop=kf.xhop, fhop=kf.fhop, lib=emulib, **kw)
+    K = mpcqp.steady_kalman_gain(rep(kf.Ah), rep(kf.Ch), np.diag([0.25, 0.25, 1.0]), np.eye(1))
+    assert np.abs(K[0] - kf.Khat).max() < 1e-12           # product-side gain == oracle's
+    gpu.setestimator(K)
+    for o in (orc, gpu):
+        o.setconstraint(umin=[0.0], umax=[1.2], ymax=[2.6])
+    gpu.initstate([0.5]); orc.lastu0 = np.zeros(1)
+    plant = es.LinModelOracle(model.A, model.Bu, model.C, model.Bd, model.Dd).setop(
+        uop=model.uop, yop=model.yop, dop=model.dop)
+    d = [0.45] if nd else None
+    dd = d if nd else ()
+    for k in range(6):
+        y = plant.evaloutput(dd) + 0.01 * k
+        xg = gpu.preparestate(y, d)
+        xo = kf.preparestate(y, dd)
+        assert np.abs(xg[1] - xo).max() < 1e-10
+        ug = gpu.moveinput(None, [2.5], d)
+        uo = orc.moveinput(kf.x0, [2.5], d)
+        assert np.abs(ug[0] - uo).max() < 1e-6
+        gpu.updatestate(ug, y, d)
+        kf.updatestate(uo, y, dd)
+        plant.updatestate(uo, dd)
+        assert np.abs(gpu.xhat0[0] - kf.x0).max() < 1e-6

@@ -258,3 +258,45 @@ def test_abi_error_codes(hiplib):
     h = H(4, 3, 1, 1, 0, Hp=5, Hc=2)
     with pytest.raises(mpcqp.MpcqpError, match="must be set before"):
         h.step(np.zeros((4, 3)), np.zeros((4, 1)), np.zeros((4, 5)), np.zeros((4, 3)))
+
+
+def test_kalman_closed_loop_on_gpu(hiplib):
+    """SteadyKalmanFilter preparestate!/updatestate! on the GPU around moveinput!.
+    (a) the doctest golden u = 17.577311 with the correction step done on the device;
+    (b) a 15-period closed loop of a C2 batch with per-instance Kalman gains and measurement
+        noise, against the oracle estimator + controller."""
+    kf, orc, gpu = _pair({"model": _tf(2.0, 10.0, 1.0), "skf": dict(sigmaQ=[1], sigmaR=[1], sigmaQint_ym=[1])},
+                         dict(Hp=10, Hc=2))
+    K = mpcqp.steady_kalman_gain(np.tile(kf.Ah, (3, 1, 1)), np.tile(kf.Ch, (3, 1, 1)), np.eye(2), np.eye(1))
+    gpu.setestimator(K)
+    gpu.preparestate([1.0])
+    u = gpu.moveinput(None, [10.0])
+    assert [round(float(v), 6) for v in u[:, 0]] == [17.577311] * 3
+    # (b)
+    cfg = synth.C2
+    B = 6
+    bt = synth.make_batch(cfg, B, seed=21)
+    gpu = make_controller(cfg, bt)
+    nxh = cfg.nxh
+    Q = np.diag(np.r_[np.full(cfg.nx, 1.0 / cfg.nx), np.ones(cfg.ny)] ** 2)
+    K = mpcqp.steady_kalman_gain(bt["Ahat"], bt["Chat"], Q, np.eye(cfg.ny))
+    gpu.setestimator(K, xhat0=bt["xhat0"])
+    gpu.lastu0 = bt["lastu0"].copy()
+    orcs = [make_oracle(cfg, bt, i) for i in range(B)]
+    xo = bt["xhat0"].copy()
+    xp = bt["xhat0"].copy()                       # "plant" = the augmented model itself
+    rng = np.random.default_rng(0)
+    for i in range(B):
+        orcs[i].lastu0 = bt["lastu0"][i].copy()
+    for k in range(15):
+        y = np.einsum("bij,bj->bi", bt["Chat"], xp) + 0.02 * rng.standard_normal((B, cfg.ny))
+        gpu.preparestate(y)
+        ug = gpu.moveinput(None, bt["ry"])
+        for i in range(B):
+            xo[i] = xo[i] + K[i] @ (y[i] - bt["Chat"][i] @ xo[i])
+            uo = orcs[i].moveinput(xo[i], bt["ry"][i])
+            assert np.abs(ug[i] - uo).max() <= TOL
+            xo[i] = bt["Ahat"][i] @ xo[i] + bt["Bhu"][i] @ uo
+        gpu.updatestate(ug, y)
+        assert np.abs(gpu.xhat0 - xo).max() <= 1e-5 * max(1.0, np.abs(xo).max())
+        xp = np.einsum("bij,bj->bi", bt["Ahat"], xp) + np.einsum("bij,bj->bi", bt["Bhu"], ug)
