@@ -1,0 +1,108 @@
+// mpcqp_devwave.h -- the gfx950 implementation of the wave interface the kernel bodies are
+// written against (lane id, wave fence, wave reductions, broadcasts).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mpcqp_types.h"
+
+#ifndef MPCQP_STEP_WAVES
+#define MPCQP_STEP_WAVES 2      // register budget of the specialised step kernel, in waves per SIMD
+#endif
+
+namespace mpcqp {
+
+// Wave-level primitives without LDS traffic: reductions run on DPP lane permutes inside each
+// 16-lane row and v_readlane across the four rows; broadcasts of a wave-uniform lane are two
+// v_readlane.  (ds_bpermute-based __shfl costs an LDS round trip per step, and this kernel's
+// critical path is a chain of ~120 broadcasts + ~12 reductions per IPM iteration.)
+struct DevWave {
+    int lane;
+    // One wavefront per workgroup: LDS operations of a wave execute in issue order, so ordering
+    // LDS traffic between lanes needs no s_barrier and no s_waitcnt -- only a fence the compiler
+    // may not move memory operations across.
+    __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    template <int CTRL>
+    static __device__ __forceinline__ double dpp(double v) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ double lane_value(double v, int src) {   // src wave-uniform
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    }
+    template <class Op>
+    static __device__ __forceinline__ double reduce(double v, Op op) {
+        v = op(v, dpp<0xB1>(v));     // quad_perm [1,0,3,2]
+        v = op(v, dpp<0x4E>(v));     // quad_perm [2,3,0,1]
+        v = op(v, dpp<0x141>(v));    // row_half_mirror
+        v = op(v, dpp<0x140>(v));    // row_mirror: every lane holds its 16-lane row's value
+        const double a = lane_value(v, 0), b = lane_value(v, 16);
+        const double c = lane_value(v, 32), d = lane_value(v, 48);
+        return op(op(a, b), op(c, d));
+    }
+    // sum over each aligned group of four lanes (result in all four)
+    __device__ __forceinline__ double quad_sum(double v) {
+        v += dpp<0xB1>(v);
+        v += dpp<0x4E>(v);
+        return v;
+    }
+    __device__ __forceinline__ double sum(double v) { return reduce(v, [](double x, double y) { return x + y; }); }
+    __device__ __forceinline__ double minv(double v) { return reduce(v, [](double x, double y) { return fmin(x, y); }); }
+    __device__ __forceinline__ double maxv(double v) { return reduce(v, [](double x, double y) { return fmax(x, y); }); }
+    __device__ __forceinline__ int isum(int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+    __device__ __forceinline__ double bcast(double v, int src) { return lane_value(v, src); }
+};
+
+extern __shared__ __attribute__((aligned(16))) double mpcqp_smem[];
+
+// specialised on compile-time dimensions
+template <class SD>
+__global__ __launch_bounds__(64) void k_hessian_s(Dims d, Model m) {
+    DevWave w{(int)threadIdx.x};
+    const SD sd(d);
+    hessian_body(w, sd, m, (int)blockIdx.x, mpcqp_smem);
+}
+
+template <class SD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_STEP_WAVES, 8))) void k_step_s(Dims d, Model m, StepIO io) {
+    DevWave w{(int)threadIdx.x};
+    const SD sd(d);
+    step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem);
+}
+
+inline hipError_t ensure_lds(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <class SD>
+inline hipError_t launch_step_static(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
+    const size_t lds = (size_t)make_carve(SD(d)).total * sizeof(double);
+    hipError_t e = ensure_lds((const void*)k_step_s<SD>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_step_s<SD>, dim3(d.B), dim3(WAVE), lds, st, d, m, io);
+    return hipGetLastError();
+}
+
+template <class SD>
+inline hipError_t launch_hessian_static(const Dims& d, const Model& m, hipStream_t st) {
+    const size_t lds = (size_t)make_carve(SD(d)).total * sizeof(double);
+    hipError_t e = ensure_lds((const void*)k_hessian_s<SD>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_hessian_s<SD>, dim3(d.B), dim3(WAVE), lds, st, d, m);
+    return hipGetLastError();
+}
+
+}  // namespace mpcqp

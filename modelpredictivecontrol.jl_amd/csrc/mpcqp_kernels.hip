@@ -5,71 +5,21 @@
 
 #include <cstdlib>
 
+#include <dlfcn.h>
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+
 #include "mpcqp_bodies.h"
+#include "mpcqp_devwave.h"
 #include "mpcqp_dispatch.h"
 #include "mpcqp_launch.h"
 
-#ifndef MPCQP_STEP_WAVES
-#define MPCQP_STEP_WAVES 2      // register budget of the specialised step kernel, in waves per SIMD
-#endif
-
 namespace mpcqp {
-
-// Wave-level primitives without LDS traffic: reductions run on DPP lane permutes inside each
-// 16-lane row and v_readlane across the four rows; broadcasts of a wave-uniform lane are two
-// v_readlane.  (ds_bpermute-based __shfl costs an LDS round trip per step, and this kernel's
-// critical path is a chain of ~120 broadcasts + ~12 reductions per IPM iteration.)
-struct DevWave {
-    int lane;
-    // One wavefront per workgroup: LDS operations of a wave execute in issue order, so ordering
-    // LDS traffic between lanes needs no s_barrier and no s_waitcnt -- only a fence the compiler
-    // may not move memory operations across.
-    __device__ __forceinline__ void sync() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    template <int CTRL>
-    static __device__ __forceinline__ double dpp(double v) {
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-        return __hiloint2double(hi, lo);
-    }
-    static __device__ __forceinline__ double lane_value(double v, int src) {   // src wave-uniform
-        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-        return __hiloint2double(hi, lo);
-    }
-    template <class Op>
-    static __device__ __forceinline__ double reduce(double v, Op op) {
-        v = op(v, dpp<0xB1>(v));     // quad_perm [1,0,3,2]
-        v = op(v, dpp<0x4E>(v));     // quad_perm [2,3,0,1]
-        v = op(v, dpp<0x141>(v));    // row_half_mirror
-        v = op(v, dpp<0x140>(v));    // row_mirror: every lane holds its 16-lane row's value
-        const double a = lane_value(v, 0), b = lane_value(v, 16);
-        const double c = lane_value(v, 32), d = lane_value(v, 48);
-        return op(op(a, b), op(c, d));
-    }
-    // sum over each aligned group of four lanes (result in all four)
-    __device__ __forceinline__ double quad_sum(double v) {
-        v += dpp<0xB1>(v);
-        v += dpp<0x4E>(v);
-        return v;
-    }
-    __device__ __forceinline__ double sum(double v) { return reduce(v, [](double x, double y) { return x + y; }); }
-    __device__ __forceinline__ double minv(double v) { return reduce(v, [](double x, double y) { return fmin(x, y); }); }
-    __device__ __forceinline__ double maxv(double v) { return reduce(v, [](double x, double y) { return fmax(x, y); }); }
-    __device__ __forceinline__ int isum(int v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
-    }
-    __device__ __forceinline__ double bcast(double v, int src) { return lane_value(v, src); }
-};
-
-extern __shared__ __attribute__((aligned(16))) double mpcqp_smem[];
 
 __global__ __launch_bounds__(64) void k_predmat(Dims d, Model m, int terminal) {
     DevWave w{(int)threadIdx.x};
@@ -86,21 +36,6 @@ __global__ __launch_bounds__(64) void k_step(Dims d, Model m, StepIO io) {
     step_body(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
 }
 
-template <class SD>
-__global__ __launch_bounds__(64) void k_hessian_s(Dims d, Model m) {
-    DevWave w{(int)threadIdx.x};
-    const SD sd(d);
-    hessian_body(w, sd, m, (int)blockIdx.x, mpcqp_smem);
-}
-
-// specialised on compile-time dimensions (mpcqp_dispatch.h)
-template <class SD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_STEP_WAVES, 8))) void k_step_s(Dims d, Model m, StepIO io) {
-    DevWave w{(int)threadIdx.x};
-    const SD sd(d);
-    step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem);
-}
-
 // SteadyKalmanFilter steps: npad = next power of two >= nx̂ lanes per problem, 256-thread blocks
 __global__ __launch_bounds__(256) void k_kf_correct(Dims d, Model m, KfParams kf, double* xhat0,
                                                     const double* y0m, const double* d0, int npad) {
@@ -115,11 +50,6 @@ __global__ __launch_bounds__(256) void k_kf_predict(Dims d, Model m, double* xha
 }
 
 // ---- launchers (host) ------------------------------------------------------------------------
-static hipError_t ensure_lds(const void* fn, size_t bytes) {
-    if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStream_t st) {
     size_t lds = (size_t)predmat_lds_doubles(d) * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_predmat, lds);
@@ -128,24 +58,98 @@ hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStrea
     return hipGetLastError();
 }
 
-static bool force_generic();
+static bool env_flag(const char* name, bool dflt) {
+    const char* e = getenv(name);
+    return e ? e[0] == '1' : dflt;
+}
+static bool force_generic() { static const bool f = env_flag("MPCQP_FORCE_GENERIC", false); return f; }
+
+// ---- on-demand specialisation ----------------------------------------------------------------
+// Dimensions outside the ahead-of-time list get their own compile-time-dims kernel the first
+// time they are used: csrc/mpcqp_spec.hip is compiled with the installation's hipcc (the same
+// compiler as the ahead-of-time build), cached as lib/spec_cache/spec_<dims>.so and dlopen'ed.
+// MPCQP_JIT=0 disables it (generic runtime-dims kernel then); any failure falls back to the
+// generic kernel with one message on stderr.  Restrictions of a specialisation: nd = 0, default
+// move blocking.
+struct SpecLib {
+    int (*matches)(const Dims*) = nullptr;
+    int (*matches_dims)(const Dims*) = nullptr;
+    int (*step)(const Dims*, const Model*, const StepIO*, void*) = nullptr;
+    int (*hessian)(const Dims*, const Model*, void*) = nullptr;
+};
+using SpecKey = std::tuple<int, int, int, int, int, int, unsigned>;
+static std::mutex g_spec_mu;
+static std::map<SpecKey, SpecLib> g_spec;        // failed builds are cached as empty entries
+
+static std::string lib_dir() {
+    Dl_info info;
+    if (!dladdr((const void*)&lib_dir, &info) || !info.dli_fname) return ".";
+    std::string p(info.dli_fname);
+    size_t s = p.rfind('/');
+    return s == std::string::npos ? "." : p.substr(0, s);
+}
+
+static const SpecLib* jit_specialise(const Dims& d) {
+    static const bool enabled = env_flag("MPCQP_JIT", true);
+    if (!enabled || d.nd != 0 || !d.default_nb) return nullptr;
+    const SpecKey key{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask};
+    std::lock_guard<std::mutex> lock(g_spec_mu);
+    auto it = g_spec.find(key);
+    if (it != g_spec.end()) return it->second.step ? &it->second : nullptr;
+    SpecLib sl;
+    const std::string dir = lib_dir(), cache = dir + "/spec_cache", src = dir + "/../csrc";
+    char name[160];
+    snprintf(name, sizeof name, "spec_%d_%d_%d_%d_%d_%d_%x.so", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask);
+    const std::string so = cache + "/" + name;
+    struct stat sb;
+    if (stat(so.c_str(), &sb) != 0) {
+        mkdir(cache.c_str(), 0755);
+        const char* hipcc = getenv("HIPCC") ? getenv("HIPCC") : "/opt/rocm/bin/hipcc";
+        char cmd[2048];
+        snprintf(cmd, sizeof cmd,
+                 "%s --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -w -I%s "
+                 "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu %s/mpcqp_spec.hip -o %s.tmp 2>&1 && mv %s.tmp %s",
+                 hipcc, src.c_str(), d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, src.c_str(),
+                 so.c_str(), so.c_str(), so.c_str());
+        fprintf(stderr, "[mpcqp] specialising the step kernel for nu=%d ny=%d nxhat=%d Hp=%d Hc=%d "
+                        "neps=%d rows=0x%x (one-time, cached in %s)\n",
+                d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, cache.c_str());
+        FILE* p = popen(cmd, "r");
+        std::string out;
+        if (p) {
+            char buf[512];
+            while (fgets(buf, sizeof buf, p)) out += buf;
+            const int rc = pclose(p);
+            if (rc != 0) fprintf(stderr, "[mpcqp] specialisation failed (rc=%d), using the generic kernel:\n%s\n", rc, out.c_str());
+        }
+    }
+    if (stat(so.c_str(), &sb) == 0) {
+        void* hdl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (hdl) {
+            sl.matches = (int (*)(const Dims*))dlsym(hdl, "mpcqp_spec_matches");
+            sl.matches_dims = (int (*)(const Dims*))dlsym(hdl, "mpcqp_spec_matches_dims");
+            sl.step = (int (*)(const Dims*, const Model*, const StepIO*, void*))dlsym(hdl, "mpcqp_spec_launch_step");
+            sl.hessian = (int (*)(const Dims*, const Model*, void*))dlsym(hdl, "mpcqp_spec_launch_hessian");
+            if (!sl.matches || !sl.step || !sl.hessian || !sl.matches(&d)) sl = SpecLib{};
+        } else {
+            fprintf(stderr, "[mpcqp] dlopen(%s) failed: %s\n", so.c_str(), dlerror());
+        }
+    }
+    auto res = g_spec.emplace(key, sl);
+    return res.first->second.step ? &res.first->second : nullptr;
+}
 
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
     if (!force_generic()) {
-#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                        \
-        {                                                                                       \
-            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                               \
-            if (SD::matches_dims(d)) {                                                          \
-                const size_t lds_s = (size_t)make_carve(SD(d)).total * sizeof(double);          \
-                hipError_t e = ensure_lds((const void*)k_hessian_s<SD>, lds_s);                 \
-                if (e != hipSuccess) return e;                                                  \
-                hipLaunchKernelGGL(k_hessian_s<SD>, dim3(d.B), dim3(WAVE), lds_s, st, d, m);    \
-                return hipGetLastError();                                                       \
-            }                                                                                   \
+#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
+        {                                                                           \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                   \
+            if (SD::matches_dims(d)) return launch_hessian_static<SD>(d, m, st);    \
         }
         MPCQP_SPECIALIZATIONS(X)
 #undef X
     }
+    // (the Hessian of other dimensions stays on the generic kernel: it runs once per set_model)
     size_t lds = (size_t)make_carve(d).total * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_hessian, lds);
     if (e != hipSuccess) return e;
@@ -153,26 +157,16 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
     return hipGetLastError();
 }
 
-static bool force_generic() {
-    static const bool f = [] { const char* e = getenv("MPCQP_FORCE_GENERIC"); return e && e[0] == '1'; }();
-    return f;
-}
-
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
     if (!force_generic()) {
-#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                        \
-        {                                                                                       \
-            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                               \
-            if (SD::matches(d)) {                                                               \
-                const size_t lds_s = (size_t)make_carve(SD(d)).total * sizeof(double);          \
-                hipError_t e = ensure_lds((const void*)k_step_s<SD>, lds_s);                    \
-                if (e != hipSuccess) return e;                                                  \
-                hipLaunchKernelGGL(k_step_s<SD>, dim3(d.B), dim3(WAVE), lds_s, st, d, m, io);   \
-                return hipGetLastError();                                                       \
-            }                                                                                   \
+#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
+        {                                                                           \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                   \
+            if (SD::matches(d)) return launch_step_static<SD>(d, m, io, st);        \
         }
         MPCQP_SPECIALIZATIONS(X)
 #undef X
+        if (const SpecLib* sl = jit_specialise(d)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
     }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_step, lds);

@@ -300,3 +300,26 @@ def test_kalman_closed_loop_on_gpu(hiplib):
         gpu.updatestate(ug, y)
         assert np.abs(gpu.xhat0 - xo).max() <= 1e-5 * max(1.0, np.abs(xo).max())
         xp = np.einsum("bij,bj->bi", bt["Ahat"], xp) + np.einsum("bij,bj->bi", bt["Bhu"], ug)
+
+
+def test_on_demand_specialisation(hiplib):
+    """Dimensions outside the ahead-of-time list get a compile-time-dims kernel built at first use
+    (csrc/mpcqp_spec.hip through the installation's hipcc, cached under lib/spec_cache): odd sizes
+    (nu=3, ny=2, nx̂=7, Hp=12, Hc=4), every row group that can be specialised."""
+    import glob
+    import os
+    cfg = synth.Config("odd", nx=5, nu=3, ny=2, Hp=12, Hc=4, umin=-0.8, umax=0.9, dumin=-0.5,
+                       dumax=0.4, ymin=-1.5, ymax=1.2)
+    B = 40
+    bt = synth.make_batch(cfg, B, seed=9)
+    got = run_batch(cfg, bt)
+    ref = oracle_batch(cfg, bt)
+    assert np.all(got["status"] == 0)
+    err = rel_err(got["Z"], ref["Z"], cfg.nu * cfg.Hc)
+    assert err[ref["certified"]].max() <= TOL
+    cache = os.path.join(os.path.dirname(mpcqp.DEFAULT_LIB), "spec_cache")
+    if os.environ.get("MPCQP_JIT", "1") != "0" and os.environ.get("MPCQP_FORCE_GENERIC", "0") != "1":
+        assert glob.glob(os.path.join(cache, "spec_3_2_7_12_4_1_*.so")), "specialisation was not built"
+    # second handle of the same dimensions: served from the in-process / on-disk cache
+    got2 = run_batch(cfg, bt)
+    assert np.array_equal(got2["Z"], got["Z"])
