@@ -177,9 +177,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
     const int B = r->B, nxh = r->nxh, nu = r->nu, ny = r->ny, Hp = r->Hp, Hc = r->Hc;
     const int nZ = r->nZ, nDU = r->nDU, nU = r->nU, nY = r->nY, neps = r->neps, mmax = r->m;
     int nbad = 0;
-    /* experiment knobs (defaults = the shipped algorithm) */
-    const double lam0 = getenv("MPC_LAM0") ? atof(getenv("MPC_LAM0")) : 10.0;
-    const double frac2 = getenv("MPC_FRAC2") ? atof(getenv("MPC_FRAC2")) : 0.99;
+    const double lam0 = 10.0;      /* starting point: s = max(h - G z, 1), lam = lam0 / s */
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -285,7 +283,6 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                 chol_solve(Phi, z, nZ);
                 st = 0;
             }
-            double fr2 = frac2;
             for (int pass = 0; m > 0 && pass < max_iter; ++pass) {
                 /* residuals */
                 double mu = 0, rdn = 0, ndd = 0;
@@ -308,23 +305,10 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                     if (sc > ndd) ndd = sc;
                 }
                 ndd += 1.0;
-                if (pass >= 0) {
+                {
                     it = pass;
                     if (!(mu == mu)) { st = 2; break; }
                     if (mu <= gap_tol && rdn <= res_tol * ndd && rpn <= res_tol * nh) { st = 0; break; }
-                }
-                if (pass == 30 && fr2 != 0.99) {      /* one restart with the safe step fraction */
-                    fr2 = 0.99;
-                    memcpy(z, zs, nZ * sizeof(double));
-                    for (int i = 0; i < m; ++i) {
-                        double a = 0;
-                        for (int k = 0; k < nZ; ++k) a += G[(size_t)i * nZ + k] * z[k];
-                        s[i] = fmax(h[i] - a, 1.0);
-                        lam[i] = lam0 / s[i];
-                    }
-                    --pass;     /* redo the residuals from the restarted point */
-                    fr2 = 0.99;
-                    continue;
                 }
                 /* Phi = H + G' D~ G */
                 for (int i = 0; i < m; ++i) {
@@ -361,17 +345,6 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                         for (int k = 0; k < nZ; ++k) a += g[k] * dz[k];
                         gd[i] = a;
                     }
-                    if (pass < 0) {       /* starting point */
-                        for (int i = 0; i < m; ++i) {
-                            double rc = s[i] * lam[i];
-                            double dl = -wv[i] * rc / s[i] + Dt[i] * (rp[i] + gd[i]);
-                            double ds = -(rc + s[i] * dl) / lam[i];
-                            s[i] = fmax(fabs(s[i] + ds), 1.0);
-                            lam[i] = fmax(fabs(lam[i] + dl), 1.0);
-                        }
-                        for (int k = 0; k < nZ; ++k) z[k] += dz[k];
-                        break;
-                    }
                     for (int i = 0; i < m; ++i) {
                         double rc = s[i] * lam[i] + (phase ? pp[i] - smu : 0.0);
                         double dl = -wv[i] * rc / s[i] + Dt[i] * (rp[i] + gd[i]);
@@ -390,7 +363,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                         double sig = (mas / m) / mu;
                         smu = sig * sig * sig * mu;
                     } else {
-                        double alpha = fmin(1.0, (mu < 1e-2 ? fr2 : 0.99) * amin);
+                        double alpha = fmin(1.0, 0.99 * amin);
                         for (int i = 0; i < m; ++i) { s[i] += alpha * dsv[i]; lam[i] += alpha * dlv[i]; }
                         for (int k = 0; k < nZ; ++k) z[k] += alpha * dz[k];
                     }
