@@ -52,20 +52,20 @@ MPCQP_HD inline double rcp(double x) {
 // Compile-time dimensions: same member names as the runtime `Dims`, so the bodies below are
 // written once against a dims policy DM.  Specialised kernels (mpcqp_dispatch.h) give the
 // compiler constant trip counts everywhere and let the per-row IPM state live in registers.
-// Restrictions of a specialisation: nd = 0, default move blocking nb = [1,..,1,Hp-Hc+1].
+// The number of measured disturbances nd and the move-blocking table stay run-time data.
 // ------------------------------------------------------------------------------------------
-template <int NU, int NY, int NXH, int HP, int HC, int NEPS, unsigned GMASK>
+template <int NU, int NY, int NXH, int HP, int HC, int NEPS, unsigned GMASK, int DNB = 1>
 struct StaticDims {
     static constexpr bool is_static = true;
-    static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS, nd = 0;
-    static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP, nD = 0;
+    static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS;
+    static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP;
     static constexpr int npk = 2 * ((nZ + 1) / 2) * ((nZ + 2) / 2);     // pk_size(nZ)
     // LDS stride of one Σ_m block: padded so the MFMA operand reads of E'DE (64 lanes = 4 block
     // columns x NY*NU entries) fall in distinct bank groups (see DESIGN.md "LDS layout")
     static constexpr int sp = (NY * NU) % 16 == 0 ? NY * NU + 8 : NY * NU;
     static constexpr uint32_t gmask = GMASK;
-    static constexpr int default_nb = 1;
-    int B, max_iter;
+    static constexpr int default_nb = DNB;          // 1: nb = [1,..,1,Hp-Hc+1]; 0: table in LDS
+    int B, nd, nD, max_iter;
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
     MPCQP_HD static constexpr int cnt(int p) {
@@ -79,11 +79,11 @@ struct StaticDims {
     }
     MPCQP_HD static constexpr int nrows() { return rowoff(NGROUP); }
     MPCQP_HD explicit StaticDims(const Dims& d)
-        : B(d.B), max_iter(d.max_iter), gap_tol(d.gap_tol), res_tol(d.res_tol),
+        : B(d.B), nd(d.nd), nD(d.nD), max_iter(d.max_iter), gap_tol(d.gap_tol), res_tol(d.res_tol),
           dual_reg(d.dual_reg), flags(d.flags) {}
     static bool matches_dims(const Dims& d) {
         return d.nu == NU && d.ny == NY && d.nxh == NXH && d.Hp == HP && d.Hc == HC &&
-               d.neps == NEPS && d.nd == 0 && d.default_nb == 1;
+               d.neps == NEPS && d.default_nb == DNB;
     }
     static bool matches(const Dims& d) { return matches_dims(d) && d.gmask == GMASK; }
 };
@@ -134,8 +134,8 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     const int M = DM::is_static ? 0 : d.nrows();
     MPCQP_UNROLL
     for (int a = 0; a < NROWARR; ++a) c.rows[a] = take(M);
-    c.jl = take(DM::is_static ? 0 : (d.Hc + 2) / 2 + 1);
-    c.blk = take(DM::is_static ? 0 : (d.Hp + 1) / 2 + 1);
+    c.jl = take(d.default_nb ? 0 : (d.Hc + 2) / 2 + 1);      // tables only for move-blocking vectors
+    c.blk = take(d.default_nb ? 0 : (d.Hp + 1) / 2 + 1);
     c.total = o;
     return c;
 }
@@ -173,7 +173,7 @@ struct Qp {
         const int nb_ = d.ny * d.nu, ns = d.Hp * nb_;
         const double* g = m.Stab + (size_t)b * ns;
         for (int i = w.lane; i < ns; i += WAVE) S[(i / nb_) * sp + (i % nb_)] = g[i];
-        if (!DM::is_static) {
+        if (!d.default_nb) {
             for (int i = w.lane; i <= d.Hc; i += WAVE) jlt[i] = m.jl[i];
             for (int i = w.lane; i < d.Hp; i += WAVE) blkt[i] = m.blk[i];
         }
@@ -189,7 +189,7 @@ struct Qp {
     MPCQP_HD void E_apply(const double* v, double* out) {
         const int ny = d.ny, nu = d.nu;
         if constexpr (DM::is_static) {
-            if constexpr (DM::nu == 4 && DM::nY <= 2 * WAVE) {
+            if (DM::nu == 4 && DM::nY <= 2 * WAVE && d.default_nb) {
                 // every lane owns rows r0 = lane and r1 = lane + 64: the (wave-uniform) v[j,:]
                 // loads are shared by both rows; block columns j > t are masked, not branched on
                 const int r0 = w.lane, r1 = w.lane + WAVE;
@@ -232,7 +232,7 @@ struct Qp {
     MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0) {
         const int ny = d.ny, nu = d.nu;
         if constexpr (DM::is_static) {
-            if constexpr (DM::ny == 4 && DM::nu == 4 && DM::nDU <= WAVE) {
+            if (DM::ny == 4 && DM::nu == 4 && DM::nDU <= WAVE && d.default_nb) {
                 // lane (j, a) reads whole rows S_{t-j}[a][0..3] (two 16-byte loads instead of four
                 // strided 8-byte ones) and keeps one partial sum per channel c; the four a-lanes
                 // of a block column are then added with two quad permutes and lane a keeps c = a.
@@ -297,8 +297,9 @@ struct Qp {
         for (int I = 0; I < NT; ++I) {
             const int i = 16 * I + li;
             const int j = i / NU, cc = i - j * NU;
-            jI[I] = i < NDU ? j : (1 << 20);           // padding columns never become valid
-            offI[I] = -j * SP + cc;
+            const int tj = jl(i < NDU ? j : 0);        // first step of block column j
+            jI[I] = i < NDU ? tj : (1 << 20);          // padding columns never become valid
+            offI[I] = -tj * SP + cc;
         }
         // Tile rows are processed in passes whose accumulators fit the register budget of two
         // waves per SIMD: rows {0,1} together (3 tiles, 3 independent MFMA chains per K step),
@@ -318,7 +319,7 @@ struct Qp {
             // ϵ row (index NDU, when present): row NDU of Phi is sum_r tb[r] E[r,:], i.e. the same
             // contraction with A operand tb instead of E*dd -- rides in its tile row for free
             const bool erow = DM::neps && tb != nullptr && IE >= I0 && IE <= I1;
-            const int kk0 = erow ? 0 : (((16 * I0) / NU) * NY) / 4;   // first K step with t >= jmin(I0)
+            const int kk0 = erow ? 0 : (jl((16 * I0) / NU) * NY) / 4; // first K step with t >= jmin(I0)
             _Pragma("unroll 2")
             for (int kk = kk0; kk < NK; ++kk) {
                 const int r = 4 * kk + lk;
@@ -338,7 +339,7 @@ struct Qp {
                 MPCQP_UNROLL
                 for (int I = I0; I <= I1; ++I) {
                     const bool eI = erow && I == IE;
-                    if (eI || tmax >= (16 * I) / NU) {
+                    if (eI || tmax >= jl((16 * I) / NU)) {
                         double ad = e[I] * dv;
                         if (eI && li == LE) ad = rok ? tb[rr] : 0.0;
                         MPCQP_UNROLL

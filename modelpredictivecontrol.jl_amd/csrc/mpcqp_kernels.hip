@@ -69,15 +69,14 @@ static bool force_generic() { static const bool f = env_flag("MPCQP_FORCE_GENERI
 // time they are used: csrc/mpcqp_spec.hip is compiled with the installation's hipcc (the same
 // compiler as the ahead-of-time build), cached as lib/spec_cache/spec_<dims>.so and dlopen'ed.
 // MPCQP_JIT=0 disables it (generic runtime-dims kernel then); any failure falls back to the
-// generic kernel with one message on stderr.  Restrictions of a specialisation: nd = 0, default
-// move blocking.
+// generic kernel with one message on stderr.
 struct SpecLib {
     int (*matches)(const Dims*) = nullptr;
     int (*matches_dims)(const Dims*) = nullptr;
     int (*step)(const Dims*, const Model*, const StepIO*, void*) = nullptr;
     int (*hessian)(const Dims*, const Model*, void*) = nullptr;
 };
-using SpecKey = std::tuple<int, int, int, int, int, int, unsigned>;
+using SpecKey = std::tuple<int, int, int, int, int, int, unsigned, int>;
 static std::mutex g_spec_mu;
 static std::map<SpecKey, SpecLib> g_spec;        // failed builds are cached as empty entries
 
@@ -91,15 +90,15 @@ static std::string lib_dir() {
 
 static const SpecLib* jit_specialise(const Dims& d) {
     static const bool enabled = env_flag("MPCQP_JIT", true);
-    if (!enabled || d.nd != 0 || !d.default_nb) return nullptr;
-    const SpecKey key{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask};
+    if (!enabled) return nullptr;
+    const SpecKey key{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb};
     std::lock_guard<std::mutex> lock(g_spec_mu);
     auto it = g_spec.find(key);
     if (it != g_spec.end()) return it->second.step ? &it->second : nullptr;
     SpecLib sl;
     const std::string dir = lib_dir(), cache = dir + "/spec_cache", src = dir + "/../csrc";
     char name[160];
-    snprintf(name, sizeof name, "spec_%d_%d_%d_%d_%d_%d_%x.so", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask);
+    snprintf(name, sizeof name, "spec_%d_%d_%d_%d_%d_%d_%x_%d.so", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
     const std::string so = cache + "/" + name;
     struct stat sb;
     if (stat(so.c_str(), &sb) != 0) {
@@ -108,8 +107,8 @@ static const SpecLib* jit_specialise(const Dims& d) {
         char cmd[2048];
         snprintf(cmd, sizeof cmd,
                  "%s --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -w -I%s "
-                 "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu %s/mpcqp_spec.hip -o %s.tmp 2>&1 && mv %s.tmp %s",
-                 hipcc, src.c_str(), d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, src.c_str(),
+                 "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu,%d %s/mpcqp_spec.hip -o %s.tmp 2>&1 && mv %s.tmp %s",
+                 hipcc, src.c_str(), d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb, src.c_str(),
                  so.c_str(), so.c_str(), so.c_str());
         fprintf(stderr, "[mpcqp] specialising the step kernel for nu=%d ny=%d nxhat=%d Hp=%d Hc=%d "
                         "neps=%d rows=0x%x (one-time, cached in %s)\n",

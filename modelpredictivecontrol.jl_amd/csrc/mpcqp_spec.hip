@@ -1,6 +1,6 @@
 // mpcqp_spec.hip -- ONE specialisation of the step / Hessian kernels, compiled on demand by
 // libmpcqp.so for dimensions that are not in its ahead-of-time list (mpcqp_dispatch.h):
-//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -DMPCQP_SPEC_DIMS=NU,NY,NXH,HP,HC,NEPS,GMASK ...
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -DMPCQP_SPEC_DIMS=NU,NY,NXH,HP,HC,NEPS,GMASK,DEFAULT_NB ...
 // The resulting object is dlopen'ed and cached next to the library (see jit_specialise()).
 #include <hip/hip_runtime.h>
 
@@ -8,7 +8,7 @@
 #include "mpcqp_devwave.h"
 
 #ifndef MPCQP_SPEC_DIMS
-#error "define MPCQP_SPEC_DIMS=NU,NY,NXH,HP,HC,NEPS,GMASK"
+#error "define MPCQP_SPEC_DIMS=NU,NY,NXH,HP,HC,NEPS,GMASK,DEFAULT_NB"
 #endif
 
 using SpecDims = mpcqp::StaticDims<MPCQP_SPEC_DIMS>;

@@ -10,6 +10,14 @@
 #include "mpcqp_dispatch.h"
 #include "mpcqp_launch.h"
 
+// specialisations of the small test problems of tests/test_abi_and_host.py, so that the
+// compile-time-dims code path (incl. move-blocking vectors and nd > 0) is exercised on the CPU too
+#define MPCQP_EMU_SPECIALIZATIONS(X) \
+    MPCQP_SPECIALIZATIONS(X)         \
+    XNB(1, 1, 3, 6, 3, 1, 0x09Fu)    \
+    XNB(1, 1, 3, 6, 3, 1, 0x39Fu)    \
+    XNB(1, 1, 3, 6, 3, 1, 0x08Du)
+
 namespace mpcqp {
 
 struct EmuShared {
@@ -88,9 +96,11 @@ hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStrea
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
     const char* fg = getenv("MPCQP_FORCE_GENERIC");
     if (!(fg && fg[0] == '1')) {
-#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                       \
+#define XNB(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 0)
+#define X(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 1)
+#define XX(NU, NY, NXH, HP, HC, NEPS, GM, NB)                                                  \
         {                                                                                      \
-            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                              \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM, NB>;                          \
             if (SD::matches_dims(d)) {                                                         \
                 const SD sd(d);                                                                \
                 run_waves(d.B, make_carve(sd).total, [&](EmuWave& w, int b, double* sm) {      \
@@ -98,8 +108,10 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
                 return hipSuccess;                                                             \
             }                                                                                  \
         }
-        MPCQP_SPECIALIZATIONS(X)
+        MPCQP_EMU_SPECIALIZATIONS(X)
 #undef X
+#undef XX
+#undef XNB
     }
     run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { hessian_body(w, d, m, b, sm); });
     return hipSuccess;
@@ -107,9 +119,11 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
     const char* fg = getenv("MPCQP_FORCE_GENERIC");
     if (!(fg && fg[0] == '1')) {
-#define X(NU, NY, NXH, HP, HC, NEPS, GM)                                                       \
+#define XNB(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 0)
+#define X(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 1)
+#define XX(NU, NY, NXH, HP, HC, NEPS, GM, NB)                                                  \
         {                                                                                      \
-            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                              \
+            using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM, NB>;                          \
             if (SD::matches(d)) {                                                              \
                 const SD sd(d);                                                                \
                 run_waves(d.B, make_carve(sd).total, [&](EmuWave& w, int b, double* sm) {      \
@@ -117,8 +131,10 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
                 return hipSuccess;                                                             \
             }                                                                                  \
         }
-        MPCQP_SPECIALIZATIONS(X)
+        MPCQP_EMU_SPECIALIZATIONS(X)
 #undef X
+#undef XX
+#undef XNB
     }
     run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { step_body(w, d, m, io, b, sm); });
     return hipSuccess;
