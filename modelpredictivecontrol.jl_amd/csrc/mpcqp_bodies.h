@@ -59,7 +59,7 @@ struct StaticDims {
     static constexpr bool is_static = true;
     static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS;
     static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP;
-    static constexpr int npk = 2 * ((nZ + 1) / 2) * ((nZ + 2) / 2);     // pk_size(nZ)
+    static constexpr int npk = pk_size(nZ);
     // LDS stride of one Σ_m block: padded so the MFMA operand reads of E'DE (64 lanes = 4 block
     // columns x NY*NU entries) fall in distinct bank groups (see DESIGN.md "LDS layout")
     static constexpr int sp = (NY * NU) % 16 == 0 ? NY * NU + 8 : NY * NU;
@@ -95,7 +95,7 @@ struct StaticDims {
 constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs (cs only stored with runtime dims)
 
 struct Carve {
-    int S, Phi, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT;
+    int S, Phi, zero, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT;
     int rows[NROWARR];
     int jl, blk;               // int tables (offset in doubles, storage as int)
     int total;                 // doubles
@@ -114,6 +114,7 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
     c.S = take(d.Hp * stride_S(d));
     c.Phi = take(d.npk);
+    c.zero = take(4);                             // four zeros: where masked lanes of a chunk read point
     c.invd = 0;                                   // (1/L[k][k] lives in a register of lane k)
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
     c.gt = take(d.nZ); c.rd = take(d.nZ);
@@ -182,6 +183,7 @@ struct Qp {
             const double* e = m.exT + (size_t)b * ne;
             for (int i = w.lane; i < ne; i += WAVE) sm[c.exT + i] = e[i];
         }
+        if (w.lane < 4) sm[c.zero + w.lane] = 0.0;
         w.sync();
     }
 
@@ -319,9 +321,17 @@ struct Qp {
             // ϵ row (index NDU, when present): row NDU of Phi is sum_r tb[r] E[r,:], i.e. the same
             // contraction with A operand tb instead of E*dd -- rides in its tile row for free
             const bool erow = DM::neps && tb != nullptr && IE >= I0 && IE <= I1;
-            const int kk0 = erow ? 0 : (jl((16 * I0) / NU) * NY) / 4; // first K step with t >= jmin(I0)
-            _Pragma("unroll 2")
-            for (int kk = kk0; kk < NK; ++kk) {
+            // First K step at which tile row I sees a block column that has started (t >= j_l of
+            // its first column); the ϵ row needs every step.  The K loop is split at these points
+            // so that its bodies are branch-free (accumulators stay in place across iterations).
+            auto kfirst = [&](int I) {
+                if (erow && I == IE) return 0;
+                const int v = (jl((16 * I) / NU) * NY) / 4;           // first kk with (4kk+3)/NY >= j_l
+                return v < NK ? v : NK;
+            };
+            const int kB = (I1 > I0) ? kfirst(I1) : NK;               // second row of the pass joins here
+            const int kA = kfirst(I0) < kB ? kfirst(I0) : kB;          // (an earlier start only adds zeros)
+            auto kstep = [&](int kk, bool row0, bool row1) {
                 const int r = 4 * kk + lk;
                 const bool rok = r < NYR;
                 const int rr = rok ? r : 0;
@@ -335,18 +345,22 @@ struct Qp {
                     const double sv = S[ok ? base + offI[J] : 0];
                     e[J] = ok ? sv : 0.0;
                 }
-                const int tmax = (4 * kk + 3) / NY;                    // wave-uniform
                 MPCQP_UNROLL
                 for (int I = I0; I <= I1; ++I) {
+                    if (I == I0 ? !row0 : !row1) continue;
                     const bool eI = erow && I == IE;
-                    if (eI || tmax >= jl((16 * I) / NU)) {
-                        double ad = e[I] * dv;
-                        if (eI && li == LE) ad = rok ? tb[rr] : 0.0;
-                        MPCQP_UNROLL
-                        for (int J = 0; J <= I; ++J)
-                            acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[I - I0][J], 0, 0, 0);
-                    }
+                    double ad = e[I] * dv;
+                    if (eI && li == LE) ad = rok ? tb[rr] : 0.0;
+                    MPCQP_UNROLL
+                    for (int J = 0; J <= I; ++J)
+                        acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[I - I0][J], 0, 0, 0);
                 }
+            };
+            _Pragma("unroll 2")
+            for (int kk = kA; kk < kB; ++kk) kstep(kk, true, false);
+            if (I1 > I0) {
+                _Pragma("unroll 2")
+                for (int kk = kB; kk < NK; ++kk) kstep(kk, true, true);
             }
             MPCQP_UNROLL
             for (int I = I0; I <= I1; ++I) {
@@ -1068,9 +1082,37 @@ struct Step {
 #endif
     }
 
-    // ---- in-place Cholesky of packed Phi (row-major lower), one row per lane, nZ <= 64 --------
-    // pivot guard: a non-positive pivot (float64 breakdown of the normal equations) freezes that
-    // coordinate for this Newton step instead of poisoning the factor with NaN.
+    // four consecutive doubles from a 32-byte aligned LDS address (two ds_read_b128 / ds_write_b128)
+    MPCQP_HD static void load4(const double* p, double* x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef double v2d_ __attribute__((ext_vector_type(2)));
+        const v2d_ a = reinterpret_cast<const v2d_*>(p)[0], b2 = reinterpret_cast<const v2d_*>(p)[1];
+        x[0] = a.x; x[1] = a.y; x[2] = b2.x; x[3] = b2.y;
+#else
+        x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; x[3] = p[3];
+#endif
+    }
+    MPCQP_HD static void store4(double* p, const double* x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef double v2d_ __attribute__((ext_vector_type(2)));
+        reinterpret_cast<v2d_*>(p)[0] = v2d_{x[0], x[1]};
+        reinterpret_cast<v2d_*>(p)[1] = v2d_{x[2], x[3]};
+#else
+        p[0] = x[0]; p[1] = x[1]; p[2] = x[2]; p[3] = x[3];
+#endif
+    }
+
+    // ---- in-place Cholesky of packed Phi (row-major lower, see pk()), one row per lane, nZ <= 64
+    // Left-looking, four columns at a time.  The part of the four dot products that only needs
+    // finished columns (j < k0) is accumulated in one sweep over the lane's own row (four
+    // independent FMA chains, own-row entries loaded once for four columns); the 4 x 4 triangle
+    // inside the block is then finished from registers with v_readlane broadcasts -- straight-line
+    // code, no LDS round trip and no branch on the column-to-column dependency: every lane takes
+    // the reciprocal square root of its own entry and lane k's is broadcast.
+    // The factor is stored strictly below the diagonal; the diagonal slot and the pad entries of
+    // a row are (re)written as zeros and 1/L[k][k] stays in a register of lane k (myinvd).
+    // Pivot guard: a non-positive pivot (float64 breakdown of the normal equations) freezes that
+    // coordinate for this Newton step (zero column, 1/L = 1e-32) instead of poisoning the factor.
     MPCQP_HD void cholesky() {
         MPCQP_TIC();
         const int n = d.nZ;
@@ -1078,23 +1120,21 @@ struct Step {
         const bool act = i < n;
         const int rowi = pk(act ? i : 0, 0);
         const double dia = act ? Phi[rowi + i] : 1.0;
-        // Left-looking, one row per lane, CB columns at a time: the part of the CB dot products
-        // that only needs finished columns (j < k0) is accumulated in one sweep over the lane's
-        // own row (CB independent FMA chains, own-row entry loaded once for CB columns); the
-        // CB x CB triangle inside the block is then finished from registers with v_readlane
-        // broadcasts -- no LDS round trip on the column-to-column dependency.
+        const double thr = 1e-14 * fabs(dia);        // lanes >= n: entries 0, never above thr
+        const double* zero4 = sm + c.zero;
+        myinvd = 0.0;
         constexpr int CB = 4;
         MPCQP_NOUNROLL
         for (int k0 = 0; k0 < n; k0 += CB) {
-            double v[CB];
             const bool mine = act && i >= k0;
-            MPCQP_UNROLL
-            for (int cc = 0; cc < CB; ++cc) v[cc] = (mine && k0 + cc <= i) ? Phi[rowi + k0 + cc] : 0.0;
+            double v[CB];
+            load4(mine ? Phi + rowi + k0 : zero4, v);     // entries right of the diagonal are pads = 0
             if (mine && k0 > 0) {
                 const double* Li = Phi + rowi;
+                const int rb = pk(k0, 0), rs = k0 + CB;   // rows k0..k0+3 share the stride k0+4
                 const double* Lk[CB];
                 MPCQP_UNROLL
-                for (int cc = 0; cc < CB; ++cc) Lk[cc] = Phi + pk(k0 + cc < n ? k0 + cc : n - 1, 0);
+                for (int cc = 0; cc < CB; ++cc) Lk[cc] = Phi + rb + (k0 + cc < n ? cc : n - 1 - k0) * rs;
                 _Pragma("unroll 2")
                 for (int j = 0; j < k0; j += 2) {        // k0 is a multiple of CB: pairs are aligned
                     const double a0 = Li[j], a1 = Li[j + 1];
@@ -1105,23 +1145,21 @@ struct Step {
                     }
                 }
             }
+            double lk[CB];
             MPCQP_UNROLL
             for (int cc = 0; cc < CB; ++cc) {
-                const int k = k0 + cc;
-                if (k < n) {
-                    const double piv = w.bcast(v[cc], k);
-                    const double ref = fabs(w.bcast(dia, k));        // original diagonal entry of row k
-                    const bool bad = !(piv > 1e-14 * ref);
-                    const double id = bad ? 1e-32 : rsqrt_(piv);     // 1/sqrt(pivot)
-                    double lk = 0.0;
-                    if (i == k) { Phi[rowi + k] = bad ? 1e32 : piv * id; myinvd = id; }
-                    else if (act && i > k) { lk = bad ? 0.0 : v[cc] * id; Phi[rowi + k] = lk; }
-                    MPCQP_UNROLL
-                    for (int c2 = cc + 1; c2 < CB; ++c2) {
-                        const int k2 = k0 + c2;
-                        if (k2 < n) v[c2] -= lk * w.bcast(lk, k2);   // L[i][k] L[k2][k]
-                    }
-                }
+                const int k = k0 + cc;                   // k <= 63; a column k >= n only sees zeros
+                const double idl = (v[cc] > thr) ? rsqrt_(v[cc]) : 0.0;   // lane k: 1/sqrt(pivot), 0 if bad
+                const double idb = w.bcast(idl, k);
+                lk[cc] = v[cc] * idb;                    // lane i > k: L[i][k]
+                if (i == k) myinvd = fmax(idl, 1e-32);
+                MPCQP_UNROLL
+                for (int c2 = cc + 1; c2 < CB; ++c2) v[c2] -= lk[cc] * w.bcast(lk[cc], k0 + c2);   // L[i][k] L[k2][k]
+            }
+            if (mine) {
+                MPCQP_UNROLL
+                for (int cc = 0; cc < CB; ++cc) lk[cc] = (i > k0 + cc) ? lk[cc] : 0.0;
+                store4(Phi + rowi + k0, lk);
             }
             w.sync();
         }
@@ -1140,55 +1178,63 @@ struct Step {
 #endif
     }
 
-    // ---- dz <- Phi^{-1} gt  (factor in Phi/invd) -----------------------------------------------
+    // ---- dz <- Phi^{-1} gt  (factor in Phi / myinvd) --------------------------------------------
+    // Column sweeps in chunks of four, all lanes in lock step, no exec masking: a lane whose row is
+    // already finished reads the four-zero slot instead of the factor, and inside the diagonal
+    // block the zero diagonal slot / pad entries do the masking.  The chunk of the next group is fetched ahead of the dependent chain, which is then
+    // v_mul -> v_readlane -> v_fma per column.
     MPCQP_HD void solve_into_dz() {
         MPCQP_TIC();
         const int n = d.nZ;
         const int i = w.lane;
-        const int ii = i < n ? i : 0;
-        const int rowi = pk(ii, 0);
-        double r = (i < n) ? gt[i] : 0.0;
-        // L y = r, column sweep.  The factor entries a lane needs do not depend on the running
-        // solution, so they are fetched CH columns ahead of the dependent chain (which is then
-        // v_mul -> v_readlane -> v_fma per column, no LDS round trip).
-        constexpr int CH = 4;
-        const int nc = (n + CH - 1) / CH * CH;      // padded step count: lanes >= n hold r = 0, invd = 0
-        double lc[CH], ln[CH];
-        // unconditional loads at a clamped index + a select: no exec-mask juggling per load
-        auto Lcol = [&](int k) {                     // L[i][k] for i > k, else 0
-            const double x = Phi[rowi + (k < ii ? k : 0)];
-            return (k < ii && i < n) ? x : 0.0;
-        };
-        auto Lrow = [&](int k) {                     // L[k][i] for k > i (k < n), else 0
-            const bool ok = k > i && k < n;
-            const double x = Phi[ok ? pk(k, 0) + i : 0];
-            return ok ? x : 0.0;
-        };
-        MPCQP_UNROLL
-        for (int u = 0; u < CH; ++u) lc[u] = Lcol(u);
-        MPCQP_NOUNROLL
-        for (int k0 = 0; k0 < nc; k0 += CH) {
+        const bool act = i < n;
+        const int rowi = pk(act ? i : 0, 0);
+        const int nfull = n >> 2, rem = n & 3;
+        const double* zero4 = sm + c.zero;
+        double r = act ? gt[i] : 0.0;
+        double c0[4], c1[4];
+        // L y = r: x[u] = L[i][k0+u] (0 on/right of the diagonal; finished rows i < k0 read zeros)
+        auto ldf = [&](int k0, double* x) { load4((act && i >= k0) ? Phi + rowi + k0 : zero4, x); };
+        ldf(0, c0);
+        _Pragma("unroll 2")
+        for (int g = 0; g < nfull; ++g) {
+            const int k0 = 4 * g;
+            if (k0 + 4 < n) ldf(k0 + 4, c1);
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) ln[u] = Lcol(k0 + CH + u);
+            for (int u = 0; u < 4; ++u) r -= c0[u] * w.bcast(r * myinvd, k0 + u);
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) r -= lc[u] * w.bcast(r * myinvd, k0 + u);
-            MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) lc[u] = ln[u];
+            for (int u = 0; u < 4; ++u) c0[u] = c1[u];
         }
+        MPCQP_UNROLL
+        for (int u = 0; u < 3; ++u)
+            if (u < rem) r -= c0[u] * w.bcast(r * myinvd, 4 * nfull + u);
         r *= myinvd;      // y_i = (r_i - sum_{k<i} L[i][k] y_k) / L[i][i]; lanes >= n hold 0
-        // L' x = y, row sweep (lane i < k needs L[k][i]: row k, contiguous)
-        MPCQP_UNROLL
-        for (int u = 0; u < CH; ++u) lc[u] = Lrow(nc - 1 - u);
-        MPCQP_NOUNROLL
-        for (int k0 = nc - 1; k0 >= 0; k0 -= CH) {
+        // L' x = y: x[u] = L[k0+u][i] (0 for the rows k0+u <= i of the group; finished lanes
+        // i >= k0+4 read zeros); the rows of a group are k0+4 apart
+        auto ldb = [&](int k0, int cnt, double* x) {
+            const bool on = act && i < k0 + 4;
+            const double* p = on ? Phi + pk(k0, 0) + i : zero4;
+            const int rs = on ? k0 + 4 : 0;
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) ln[u] = Lrow(k0 - CH - u);
+            for (int u = 0; u < 4; ++u) x[u] = (u < cnt) ? p[u * rs] : 0.0;
+        };
+        if (rem) {
+            ldb(4 * nfull, rem, c0);
             MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) r -= lc[u] * w.bcast(r * myinvd, k0 - u);
-            MPCQP_UNROLL
-            for (int u = 0; u < CH; ++u) lc[u] = ln[u];
+            for (int u = 2; u >= 0; --u)
+                if (u < rem) r -= c0[u] * w.bcast(r * myinvd, 4 * nfull + u);
         }
-        if (i < n) dz[i] = r * myinvd;
+        if (nfull > 0) ldb(4 * (nfull - 1), 4, c0);
+        _Pragma("unroll 2")
+        for (int g = nfull - 1; g >= 0; --g) {
+            const int k0 = 4 * g;
+            if (g > 0) ldb(k0 - 4, 4, c1);
+            MPCQP_UNROLL
+            for (int u = 3; u >= 0; --u) r -= c0[u] * w.bcast(r * myinvd, k0 + u);
+            MPCQP_UNROLL
+            for (int u = 0; u < 4; ++u) c0[u] = c1[u];
+        }
+        if (act) dz[i] = r * myinvd;
         w.sync();
         MPCQP_TOC(7);
     }

@@ -69,7 +69,10 @@ extern __shared__ __attribute__((aligned(16))) double mpcqp_smem[];
 
 // specialised on compile-time dimensions
 template <class SD>
-__global__ __launch_bounds__(64) void k_hessian_s(Dims d, Model m) {
+// (waves_per_eu >= 2 caps the kernel at 256 registers, which makes the compiler select the VGPR
+// form of v_mfma: accumulators stay in place across the K loop instead of being shuttled
+// between AGPRs and VGPRs every iteration)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_hessian_s(Dims d, Model m) {
     DevWave w{(int)threadIdx.x};
     const SD sd(d);
     hessian_body(w, sd, m, (int)blockIdx.x, mpcqp_smem);

@@ -45,7 +45,7 @@ constexpr double BIG = 1e300;     // |h| >= BIG  <=>  row absent (bound was +-In
 struct Dims {
     int B, nxh, nu, ny, nd, Hp, Hc, neps;
     int nZ, nDU, nU, nY, nD;
-    int npk;                 // pk_size(nZ): packed lower triangle, rows padded to even length
+    int npk;                 // pk_size(nZ): packed lower triangle, rows padded in groups of four
     uint32_t gmask;          // bit g set <=> row group g may hold finite rows (handle level)
     int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
     int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh
@@ -100,11 +100,17 @@ struct StepIO {
     double *prof;              // optional [B][16] per-phase cycle counts (-DMPCQP_PROFILE builds only)
 };
 
-// Packed lower triangle, row-major, every row padded to an even length so that it starts on a
-// 16-byte boundary: the compiler fuses neighbouring LDS loads into ds_read_b128 / ds_read2_b64,
-// and a 16-byte DS access off its natural alignment is replayed at ~64 cycles per wave
-// instruction (cdna_hip_programming.md, Guideline 17).  Rows 2q and 2q+1 both occupy 2(q+1).
-MPCQP_HD inline int pk(int i, int j) { return 2 * ((i + 1) / 2) * ((i + 2) / 2) + j; }   // i >= j
-MPCQP_HD inline int pk_size(int n) { return 2 * ((n + 1) / 2) * ((n + 2) / 2); }
+// Packed lower triangle, row-major.  Rows are grouped in fours; every row of group g = i/4 is padded
+// to 4(g+1) entries, so that
+//   * a row starts on a 32-byte boundary and every aligned 4-column chunk of it is two
+//     ds_read_b128 (a 16-byte DS access off its natural alignment is replayed at ~64 cycles per
+//     wave instruction, cdna_hip_programming.md Guideline 17);
+//   * the four rows of a group share one stride, 4(g+1);
+//   * the entries (i, j) with j > i inside the last chunk of row i exist and hold ZERO.  The factor
+//     keeps a zero in the diagonal slot as well (1/L[i][i] lives in a register of lane i), so the
+//     triangular sweeps read whole chunks without masking the diagonal block.
+// Row i starts at 4(g+1)(2g + i%4); n rows take pk(n, 0) doubles.
+MPCQP_HD constexpr int pk(int i, int j) { return 4 * ((i >> 2) + 1) * (2 * (i >> 2) + (i & 3)) + j; }   // i >= j
+MPCQP_HD constexpr int pk_size(int n) { return pk(n, 0); }
 
 }  // namespace mpcqp
