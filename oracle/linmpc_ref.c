@@ -348,7 +348,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                     for (int i = 0; i < m; ++i) {
                         double rc = s[i] * lam[i] + (phase ? pp[i] - smu : 0.0);
                         double dl = -wv[i] * rc / s[i] + Dt[i] * (rp[i] + gd[i]);
-                        double ds = -(rc + s[i] * dl) / lam[i];
+                        double ds = -wv[i] * ((rp[i] + gd[i]) + delta * rc / s[i]);   /* = -(rc + s dl)/lam */
                         if (ds < 0) amin = fmin(amin, -s[i] / ds);
                         if (dl < 0) amin = fmin(amin, -lam[i] / dl);
                         dsv[i] = ds;
@@ -363,7 +363,15 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                         double sig = (mas / m) / mu;
                         smu = sig * sig * sig * mu;
                     } else {
-                        double alpha = fmin(1.0, 0.99 * amin);
+                        /* fraction to the boundary: 0.9999 if the iterate it leads to stays in the
+                           wide neighbourhood min s_i lam_i >= 0.01 mu, else 0.99 */
+                        double alpha = fmin(1.0, 0.9999 * amin), pmin = 1e300, psum = 0;
+                        for (int i = 0; i < m; ++i) {
+                            double p = (s[i] + alpha * dsv[i]) * (lam[i] + alpha * dlv[i]);
+                            psum += p;
+                            if (p < pmin) pmin = p;
+                        }
+                        if (!(pmin * m >= 0.01 * psum)) alpha = fmin(1.0, 0.99 * amin);
                         for (int i = 0; i < m; ++i) { s[i] += alpha * dsv[i]; lam[i] += alpha * dlv[i]; }
                         for (int k = 0; k < nZ; ++k) z[k] += alpha * dz[k];
                     }
