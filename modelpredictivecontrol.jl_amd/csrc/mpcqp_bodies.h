@@ -193,23 +193,23 @@ struct Qp {
         if constexpr (DM::is_static) {
             if (DM::nu == 4 && DM::nY <= 2 * WAVE && d.default_nb) {
                 // every lane owns rows r0 = lane and r1 = lane + 64: the (wave-uniform) v[j,:]
-                // loads are shared by both rows; block columns j > t are masked, not branched on
+                // loads are shared by both rows; a block column j > t reads the zero slot
                 const int r0 = w.lane, r1 = w.lane + WAVE;
                 const bool ok0 = r0 < DM::nY, ok1 = r1 < DM::nY;
                 const int t0 = (ok0 ? r0 : 0) / DM::ny, a0 = (ok0 ? r0 : 0) % DM::ny;
                 const int t1 = (ok1 ? r1 : 0) / DM::ny, a1 = (ok1 ? r1 : 0) % DM::ny;
+                const int zoff = c.zero - c.S;
                 double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
                 MPCQP_UNROLL4
                 for (int j = 0; j < DM::Hc; ++j) {
                     const double* vj = v + j * 4;
                     const double v0 = vj[0], v1 = vj[1], v2 = vj[2], v3 = vj[3];
-                    const bool m0 = ok0 && j <= t0, m1 = ok1 && j <= t1;
-                    const double* Sa = S + (m0 ? t0 - j : 0) * sp + a0 * 4;
-                    const double* Sb = S + (m1 ? t1 - j : 0) * sp + a1 * 4;
-                    const double q0 = Sa[0] * v0 + Sa[2] * v2, q1 = Sa[1] * v1 + Sa[3] * v3;
-                    const double u0 = Sb[0] * v0 + Sb[2] * v2, u1 = Sb[1] * v1 + Sb[3] * v3;
-                    x0 += m0 ? q0 : 0.0; x1 += m0 ? q1 : 0.0;
-                    y0 += m1 ? u0 : 0.0; y1 += m1 ? u1 : 0.0;
+                    const double* Sa = S + ((ok0 && j <= t0) ? (t0 - j) * sp + a0 * 4 : zoff);
+                    const double* Sb = S + ((ok1 && j <= t1) ? (t1 - j) * sp + a1 * 4 : zoff);
+                    x0 = fma(Sa[0], v0, x0); x1 = fma(Sa[1], v1, x1);
+                    y0 = fma(Sb[0], v0, y0); y1 = fma(Sb[1], v1, y1);
+                    x0 = fma(Sa[2], v2, x0); x1 = fma(Sa[3], v3, x1);
+                    y0 = fma(Sb[2], v2, y0); y1 = fma(Sb[3], v3, y1);
                 }
                 if (ok0) out[r0] = x0 + x1;
                 if (ok1) out[r1] = y0 + y1;
@@ -240,14 +240,14 @@ struct Qp {
                 // of a block column are then added with two quad permutes and lane a keeps c = a.
                 const int k = w.lane < DM::nDU ? w.lane : 0;
                 const int j = k >> 2, a = k & 3;
-                const double* Sk = S + a * 4;
+                const int zoff = c.zero - c.S;
                 double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
                 MPCQP_UNROLL4
                 for (int t = 0; t < DM::Hp; ++t) {
                     const bool ok = t >= j && w.lane < DM::nDU;
-                    const double* Sb = Sk + (ok ? t - j : 0) * sp;
-                    const double wt = ok ? wv[t * 4 + a] : 0.0;
-                    p0 += Sb[0] * wt; p1 += Sb[1] * wt; p2 += Sb[2] * wt; p3 += Sb[3] * wt;
+                    const double* Sb = S + (ok ? (t - j) * sp + a * 4 : zoff);     // zero slot before the block column starts
+                    const double wt = wv[t * 4 + a];
+                    p0 = fma(Sb[0], wt, p0); p1 = fma(Sb[1], wt, p1); p2 = fma(Sb[2], wt, p2); p3 = fma(Sb[3], wt, p3);
                 }
                 p0 = w.quad_sum(p0); p1 = w.quad_sum(p1); p2 = w.quad_sum(p2); p3 = w.quad_sum(p3);
                 const double mine = a == 0 ? p0 : a == 1 ? p1 : a == 2 ? p2 : p3;
@@ -294,7 +294,7 @@ struct Qp {
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp;
         constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
         const int li = w.lane & 15, lk = w.lane >> 4;
-        int offI[NT], jI[NT];
+        int offI[NT], offL[NT], jI[NT];
         MPCQP_UNROLL
         for (int I = 0; I < NT; ++I) {
             const int i = 16 * I + li;
@@ -302,6 +302,7 @@ struct Qp {
             const int tj = jl(i < NDU ? j : 0);        // first step of block column j
             jI[I] = i < NDU ? tj : (1 << 20);          // padding columns never become valid
             offI[I] = -tj * SP + cc;
+            offL[I] = offI[I] + lk * NU;               // + the lane's row inside an aligned K step
         }
         // Tile rows are processed in passes whose accumulators fit the register budget of two
         // waves per SIMD: rows {0,1} together (3 tiles, 3 independent MFMA chains per K step),
@@ -331,26 +332,36 @@ struct Qp {
             };
             const int kB = (I1 > I0) ? kfirst(I1) : NK;               // second row of the pass joins here
             const int kA = kfirst(I0) < kB ? kfirst(I0) : kB;          // (an earlier start only adds zeros)
+            // One K step: operands straight from the Σ table.  A lane whose block column has not
+            // started at step t reads the zero slot (no select on the value).  With ny a multiple
+            // of 4 the step t of the four K rows is wave-uniform and every row exists.
+            const int zoff = c.zero - c.S;
             auto kstep = [&](int kk, bool row0, bool row1) {
-                const int r = 4 * kk + lk;
-                const bool rok = r < NYR;
-                const int rr = rok ? r : 0;
-                const int t = rr / NY, a = rr - t * NY;
-                const double dv = rok ? dd[rr] : 0.0;
-                const int base = t * SP + a * NU;
-                double e[NT];
-                MPCQP_UNROLL
-                for (int J = 0; J <= I1; ++J) {
-                    const bool ok = rok && t >= jI[J];
-                    const double sv = S[ok ? base + offI[J] : 0];
-                    e[J] = ok ? sv : 0.0;
+                double dv, tbv = 0.0, e[NT];
+                if constexpr (NY % 4 == 0) {
+                    const int t = (4 * kk) / NY, a0 = 4 * kk - t * NY;         // uniform
+                    const int base = t * SP + a0 * NU;
+                    dv = dd[4 * kk + lk];
+                    if (erow) tbv = tb[4 * kk + lk];
+                    MPCQP_UNROLL
+                    for (int J = 0; J <= I1; ++J) e[J] = S[t >= jI[J] ? base + offL[J] : zoff];
+                } else {
+                    const int r = 4 * kk + lk;
+                    const bool rok = r < NYR;
+                    const int rr = rok ? r : 0;
+                    const int t = rr / NY, a = rr - t * NY;
+                    dv = rok ? dd[rr] : 0.0;
+                    if (erow) tbv = rok ? tb[rr] : 0.0;
+                    const int base = t * SP + a * NU;
+                    MPCQP_UNROLL
+                    for (int J = 0; J <= I1; ++J) e[J] = S[(rok && t >= jI[J]) ? base + offI[J] : zoff];
                 }
                 MPCQP_UNROLL
                 for (int I = I0; I <= I1; ++I) {
                     if (I == I0 ? !row0 : !row1) continue;
                     const bool eI = erow && I == IE;
                     double ad = e[I] * dv;
-                    if (eI && li == LE) ad = rok ? tb[rr] : 0.0;
+                    if (eI && li == LE) ad = tbv;
                     MPCQP_UNROLL
                     for (int J = 0; J <= I; ++J)
                         acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[I - I0][J], 0, 0, 0);
