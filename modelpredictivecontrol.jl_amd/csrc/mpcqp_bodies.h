@@ -1113,6 +1113,50 @@ struct Step {
 #endif
     }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Blocked (right-looking at 16-column granularity) part of the factorisation on the matrix
+    // cores: before panel P (columns 16P..16P+15) is factored, the contribution of all finished
+    // columns j < 16P to the panel's columns is removed from Phi,
+    //   Phi[i][16P + c] -= sum_{j < 16P} L[i][j] L[16P + c][j]          (rows i >= 16P),
+    // one v_mfma_f64_16x16x4 per (row tile, 4 columns of j).  Operand of row tile T at K step kk is
+    // X_T = L[16T + (lane & 15)][4 kk + (lane >> 4)], used as A for the tile's rows and as B (T = P)
+    // for the panel's columns.  Rows >= nZ are clamped to the last row: they only produce tile
+    // rows / columns that are not written back.
+    template <int P>
+    __device__ __forceinline__ void chol_panel_update() {
+        typedef double v4d_ __attribute__((ext_vector_type(4)));
+        constexpr int n = DM::nZ, NT = (n + 15) / 16;
+        if constexpr (P < NT) {
+            const int li = w.lane & 15, lk = w.lane >> 4;
+            const double* X[NT];
+            v4d_ acc[NT];
+            MPCQP_UNROLL
+            for (int I = P; I < NT; ++I) {
+                const int row = 16 * I + li < n ? 16 * I + li : n - 1;
+                X[I] = Phi + pk(row, 0) + lk;
+                acc[I] = v4d_{0.0, 0.0, 0.0, 0.0};
+            }
+            _Pragma("unroll 2")
+            for (int kk = 0; kk < 4 * P; ++kk) {
+                const double bb = X[P][4 * kk];
+                acc[P] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb, bb, acc[P], 0, 0, 0);
+                MPCQP_UNROLL
+                for (int I = P + 1; I < NT; ++I)
+                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[I][4 * kk], bb, acc[I], 0, 0, 0);
+            }
+            MPCQP_UNROLL
+            for (int I = P; I < NT; ++I) {
+                MPCQP_UNROLL
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * I + lk + 4 * reg, col = 16 * P + li;
+                    if (row < n && col <= row) Phi[pk(row, col)] -= acc[I][reg];
+                }
+            }
+            w.sync();
+        }
+    }
+#endif
+
     // ---- in-place Cholesky of packed Phi (row-major lower, see pk()), one row per lane, nZ <= 64
     // Left-looking, four columns at a time.  The part of the four dot products that only needs
     // finished columns (j < k0) is accumulated in one sweep over the lane's own row (four
@@ -1138,16 +1182,25 @@ struct Step {
         MPCQP_NOUNROLL
         for (int k0 = 0; k0 < n; k0 += CB) {
             const bool mine = act && i >= k0;
+            int j0 = 0;                                  // first column the sweep below has to cover
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (DM::is_static) {
+                if (k0 == 16) chol_panel_update<1>();
+                else if (k0 == 32) chol_panel_update<2>();
+                else if (k0 == 48) chol_panel_update<3>();
+                j0 = k0 & ~15;                           // columns < 16P are already accounted for
+            }
+#endif
             double v[CB];
             load4(mine ? Phi + rowi + k0 : zero4, v);     // entries right of the diagonal are pads = 0
-            if (mine && k0 > 0) {
+            if (mine && k0 > j0) {
                 const double* Li = Phi + rowi;
                 const int rb = pk(k0, 0), rs = k0 + CB;   // rows k0..k0+3 share the stride k0+4
                 const double* Lk[CB];
                 MPCQP_UNROLL
                 for (int cc = 0; cc < CB; ++cc) Lk[cc] = Phi + rb + (k0 + cc < n ? cc : n - 1 - k0) * rs;
                 _Pragma("unroll 2")
-                for (int j = 0; j < k0; j += 2) {        // k0 is a multiple of CB: pairs are aligned
+                for (int j = j0; j < k0; j += 2) {       // j0, k0 multiples of CB: pairs are aligned
                     const double a0 = Li[j], a1 = Li[j + 1];
                     MPCQP_UNROLL
                     for (int cc = 0; cc < CB; ++cc) {
