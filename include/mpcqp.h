@@ -113,9 +113,17 @@ int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const 
 
 /* Diagonal weights: Mdiag (nY,B), Ndiag (nDU,B), Ldiag (nU,B), Cwt (B) (ignored when neps == 0).
  * (`Diagonal(repeat(Mwt,Hp))` etc., src/controller/linmpc.jl:236-238.)  Runs K2 when the model
- * is set.  Dense M_Hp/N_Hc/L_Hp: MPCQP_ERR_UNSUPPORTED path, not in this ABI yet.            */
+ * is set.  Block-diagonal M_Hp: mpcqp_set_output_weight_blocks; dense N_Hc/L_Hp: not in this ABI. */
 int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
                       const double* Ldiag, const double* Cwt);
+
+/* Block-diagonal output weight M_Hp = blkdiag(M_1, ..., M_Hp) with symmetric ny x ny blocks,
+ * Mblk (ny,ny,Hp,B); replaces Mdiag of mpcqp_set_weights (call that first: N, L, C come from it).
+ * This is the `M_Hp=` keyword of LinMPC (src/controller/linmpc.jl:205-214) for the weights the
+ * reference's own tests use: a terminal cost, M_Hp = blkdiag(M, ..., M, P)
+ * (test/3_test_predictive_control.jl:498-527).  NULL returns to the diagonal weight.  A weight that
+ * couples different prediction steps is not supported (MPCQP_ERR_UNSUPPORTED on the host side).  */
+int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk);
 
 /* Bounds (deviation values) and softness (ECR) vectors; shapes (nU,B), (nDU,B), (nY,B), (nx̂,B).
  * Field order follows ControllerConstraint (src/controller/construct.jl:126-199).            */

@@ -33,7 +33,8 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_destroy", "mpcqp_get_sizes", "mpcqp_set_model", "mpcqp_set_weights",
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_recondense_device",
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_kf_set",
-           "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device")
+           "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
+           "mpcqp_set_output_weight_blocks")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -88,6 +89,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_model.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.mpcqp_set_weights.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_set_bounds.argtypes = [C.c_void_p, C.POINTER(Bounds)]
+    lib.mpcqp_set_output_weight_blocks.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpcqp_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
     lib.mpcqp_step_device.argtypes = [C.c_void_p] + [C.c_void_p] * 12
     lib.mpcqp_recondense_device.argtypes = [C.c_void_p, C.c_void_p]
@@ -165,6 +167,11 @@ class Handle:
     def set_weights(self, Mdiag, Ndiag, Ldiag, Cwt=None):
         args = [None if a is None else _f64(a) for a in (Mdiag, Ndiag, Ldiag, Cwt)]
         _chk(self.lib, self.lib.mpcqp_set_weights(self.h, *[_ptr(a) for a in args]))
+
+    def set_output_weight_blocks(self, Mblk):
+        """Mblk (B, Hp, ny, ny), symmetric blocks, or None (back to the diagonal weight)."""
+        a = None if Mblk is None else _f64(np.asarray(Mblk, float).transpose(0, 1, 3, 2))
+        _chk(self.lib, self.lib.mpcqp_set_output_weight_blocks(self.h, _ptr(a)))
 
     def set_bounds(self, **kw):
         b = Bounds()
@@ -298,7 +305,7 @@ class BatchLinMPC:
     """
 
     def __init__(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None, *, Hp, Hc=2, Mwt=None, Nwt=None,
-                 Lwt=None, Cwt=1e5, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
+                 Lwt=None, M_Hp=None, Cwt=1e5, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
                  cold_start=False, keep_qp=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
                  lib=None):
         Ahat, Bhu, Chat = (np.asarray(a, float) for a in (Ahat, Bhu, Chat))
@@ -335,7 +342,7 @@ class BatchLinMPC:
         self.Uop, self.Yop, self.Dop = np.tile(self.uop, Hp), np.tile(self.yop, Hp), np.tile(self.dop, Hp)
         self.Cwt = cw
         self.setmodel(Ahat, Bhu, Chat, Bhd, Dhd)
-        self.setweights(Mwt, Nwt, Lwt)
+        self.setweights(Mwt, Nwt, Lwt, M_Hp=M_Hp)
         # default constraints: none (src/controller/construct.jl:887-913)
         self._b = {k: None for k in BOUND_FIELDS}
         self.Z = np.zeros((B, self.nZ))            # mpc.Z̃ (previous optimum)
@@ -353,9 +360,11 @@ class BatchLinMPC:
                           None if self.nd == 0 else colmajor(Dhd),
                           dopv if np.any(dopv != 0) else None)
 
-    def setweights(self, Mwt=None, Nwt=None, Lwt=None):
-        """Defaults of src/general.jl:3-6 (Mwt=1, Nwt=0.1, Lwt=0)."""
-        B, Hp, Hc = self.B, self.Hp, self.Hc
+    def setweights(self, Mwt=None, Nwt=None, Lwt=None, M_Hp=None):
+        """Defaults of src/general.jl:3-6 (Mwt=1, Nwt=0.1, Lwt=0).  `M_Hp` (nY,nY) or (B,nY,nY) is the
+        reference's `M_Hp=` keyword (src/controller/linmpc.jl:205-214) for block-diagonal weights
+        blkdiag(M_1..M_Hp) with symmetric ny x ny blocks, e.g. a terminal cost; it overrides Mwt."""
+        B, Hp, Hc, ny = self.B, self.Hp, self.Hc, self.ny
         w = lambda v, n, dflt: (np.full((B, n), dflt) if v is None
                                 else np.broadcast_to(np.asarray(v, float), (B, n)).copy())
         M, N, L = w(Mwt, self.ny, 1.0), w(Nwt, self.nu, 0.1), w(Lwt, self.nu, 0.0)
@@ -365,6 +374,27 @@ class BatchLinMPC:
         self.Mwt, self.Nwt, self.Lwt = M, N, L
         self.hd.set_weights(np.tile(M, Hp), np.tile(N, Hc), np.tile(L, Hp),
                             self.Cwt if self.neps else None)
+        self.Mblk = None
+        if M_Hp is not None:
+            Mf = np.asarray(M_Hp, float)
+            if Mf.shape == (self.nY, self.nY):
+                Mf = np.broadcast_to(Mf, (B, self.nY, self.nY))
+            if Mf.shape != (B, self.nY, self.nY):
+                raise ValueError(f"M_Hp size should be ({self.nY}, {self.nY})")
+            if not np.allclose(Mf, Mf.transpose(0, 2, 1), rtol=0, atol=1e-12 * max(1.0, np.abs(Mf).max())):
+                raise ValueError("M_Hp should be Hermitian")
+            blk = np.stack([Mf[:, t * ny:(t + 1) * ny, t * ny:(t + 1) * ny] for t in range(Hp)], axis=1)
+            off = Mf.copy()
+            for t in range(Hp):
+                off[:, t * ny:(t + 1) * ny, t * ny:(t + 1) * ny] = 0.0
+            if np.any(off != 0.0):
+                raise NotImplementedError("M_Hp coupling different prediction steps is not supported "
+                                          "(MPCQP_ERR_UNSUPPORTED): only blkdiag(M_1..M_Hp)")
+            self.Mblk = blk
+            self.hd.set_output_weight_blocks(blk)
+        elif getattr(self, "_had_blocks", False):
+            self.hd.set_output_weight_blocks(None)
+        self._had_blocks = M_Hp is not None
 
     # -- constraints --------------------------------------------------------------------------
     def setconstraint(self, *, umin=None, umax=None, Δumin=None, Δumax=None, ymin=None, ymax=None,

@@ -419,6 +419,31 @@ struct Qp {
         return false;
     }
 
+    // P[pk(i,i')] += scale * sum_t E_t[:,i]' M_t E_t[:,i']  for a block-diagonal weight
+    // M_Hp = blkdiag(M_1..M_Hp), Mb = [Hp][ny][ny] (symmetric blocks).  Set-up path only (K2).
+    MPCQP_HD void EtMblkE_add(const double* Mb, double* P, double scale) {
+        const int ny = d.ny, nu = d.nu, nDU = d.nDU;
+        const int ntri = nDU * (nDU + 1) / 2;
+        for (int idx = w.lane; idx < ntri; idx += WAVE) {
+            int i, ip;
+            unpack_idx(idx, i, ip);
+            const int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
+            const int t0 = jl(j), off2 = jl(j) - jl(j2);
+            double acc = 0.0;
+            for (int t = t0; t < d.Hp; ++t) {
+                const double* S1 = S + (t - t0) * sp + cc;
+                const double* S2 = S + (t - t0 + off2) * sp + c2;
+                const double* Mt = Mb + (size_t)t * ny * ny;
+                for (int a = 0; a < ny; ++a) {
+                    double ms = 0.0;
+                    for (int a2 = 0; a2 < ny; ++a2) ms += Mt[a + ny * a2] * S2[a2 * nu];
+                    acc += S1[a * nu] * ms;
+                }
+            }
+            P[pk(i, ip)] += scale * acc;
+        }
+    }
+
     // ex̂[i,(j,c)]
     MPCQP_HD double Xat(int i, int k) const {
         const int j = k / d.nu, cc = k - j * d.nu;
@@ -572,9 +597,11 @@ MPCQP_HD void hessian_body(W& w, const DM& d, const Model& m, int b, double* sm)
     double* P = qp.Phi;
     double* tY = sm + qp.c.tA[P_Y];
     for (int i = w.lane; i < d.npk; i += WAVE) P[i] = 0.0;
-    for (int i = w.lane; i < d.nY; i += WAVE) tY[i] = m.Mdiag[(size_t)b * d.nY + i];
+    if (!m.Mblk)
+        for (int i = w.lane; i < d.nY; i += WAVE) tY[i] = m.Mdiag[(size_t)b * d.nY + i];
     w.sync();
-    qp.EtDE_add(tY, P, 2.0);                                    // 2 E'ME
+    if (m.Mblk) qp.EtMblkE_add(m.Mblk + (size_t)b * d.Hp * d.ny * d.ny, P, 2.0);
+    else qp.EtDE_add(tY, P, 2.0);                               // 2 E'ME
     w.sync();
     const int nu = d.nu;
     // 2 Pu'L Pu: entry ((j,c),(j',c)) = sum_{t >= j_max(j,j')} L[t,c]   (construct.jl:797-806)
@@ -788,9 +815,19 @@ struct Step {
         double* tY = sm + c.tA[P_Y];
         const double* Md = m.Mdiag + (size_t)b * nY;
         const bool rconst = d.flags & 1u;
-        for (int r = w.lane; r < nY; r += WAVE) {
-            const double ry = rconst ? io.Ry[(size_t)b * ny + (r % ny)] : io.Ry[(size_t)b * nY + r];
-            tY[r] = Md[r] * (F[r] - ry);
+        auto cy = [&](int r) {
+            return F[r] - (rconst ? io.Ry[(size_t)b * ny + (r % ny)] : io.Ry[(size_t)b * nY + r]);
+        };
+        if (m.Mblk) {          // block-diagonal M_Hp: (M Cy)[t,a] = sum_a' M_t[a,a'] Cy[t,a']
+            const double* Mb = m.Mblk + (size_t)b * d.Hp * ny * ny;
+            for (int r = w.lane; r < nY; r += WAVE) {
+                const int t = r / ny, a = r - t * ny;
+                double acc = 0.0;
+                for (int a2 = 0; a2 < ny; ++a2) acc += Mb[((size_t)t * ny + a2) * ny + a] * cy(t * ny + a2);
+                tY[r] = acc;
+            }
+        } else {
+            for (int r = w.lane; r < nY; r += WAVE) tY[r] = Md[r] * cy(r);
         }
         for (int k = w.lane; k < d.nZ; k += WAVE) q[k] = 0.0;
         w.sync();

@@ -40,7 +40,7 @@ struct mpcqp_handle_s {
     std::vector<int> nb, jl, blk;
     std::vector<void*> owned;
     // model / weights / bounds storage
-    DBuf Ahat, Bu, C, Bd, Dd, dop, Mdiag, Ndiag, Ldiag, Cwt;
+    DBuf Ahat, Bu, C, Bd, Dd, dop, Mdiag, Ndiag, Ldiag, Cwt, Mblk;
     DBuf bnd[16];
     // staging for the host-pointer step
     DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
@@ -279,6 +279,25 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
     h->m.Ldiag = (const double*)h->Ldiag.p;
     h->m.Cwt = d.neps ? (const double*)h->Cwt.p : nullptr;
     h->have_weights = true;
+    if (h->have_model) {
+        HIPCHK(launch_hessian(d, h->m, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
+    if (!h) return MPCQP_ERR_NULL;
+    const Dims& d = h->d;
+    if (!h->have_weights) return MPCQP_ERR_ORDER;       // N, L, C come from mpcqp_set_weights
+    HIPCHK(hipSetDevice(h->device));
+    if (Mblk) {
+        int rc = upload(h, h->Mblk, Mblk, (size_t)d.B * d.Hp * d.ny * d.ny * sizeof(double));
+        if (rc) return rc;
+        h->m.Mblk = (const double*)h->Mblk.p;
+    } else {
+        h->m.Mblk = nullptr;
+    }
     if (h->have_model) {
         HIPCHK(launch_hessian(d, h->m, h->stream));
     }

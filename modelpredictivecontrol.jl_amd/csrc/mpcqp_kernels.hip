@@ -98,7 +98,7 @@ static const SpecLib* jit_specialise(const Dims& d) {
     SpecLib sl;
     const std::string dir = lib_dir(), cache = dir + "/spec_cache", src = dir + "/../csrc";
     char name[160];
-    snprintf(name, sizeof name, "spec_%d_%d_%d_%d_%d_%d_%x_%d.so", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
+    snprintf(name, sizeof name, "spec_r%d_%d_%d_%d_%d_%d_%d_%x_%d.so", MPCQP_KERNEL_REV, d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
     const std::string so = cache + "/" + name;
     struct stat sb;
     if (stat(so.c_str(), &sb) != 0) {
@@ -139,7 +139,8 @@ static const SpecLib* jit_specialise(const Dims& d) {
 }
 
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
-    if (!force_generic()) {
+    // (a block-diagonal M_Hp takes the scalar contraction of the runtime-dims kernel: set-up path)
+    if (!force_generic() && !m.Mblk) {
 #define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
         {                                                                           \
             using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                   \

@@ -33,6 +33,10 @@
 #define MPCQP_NOUNROLL
 #endif
 
+// Revision of the kernel sources / device structs: part of the name of cached on-demand
+// specialisations, so that objects built from older sources are never loaded.
+#define MPCQP_KERNEL_REV 2
+
 namespace mpcqp {
 
 enum { P_BOX = 0, P_U = 1, P_DU = 2, P_Y = 3, P_X = 4, NPAIR = 5, NGROUP = 10 };
@@ -77,6 +81,7 @@ struct Model {
     double* Hpk;     // [B][npk]          H̃, packed lower triangle row-major
     // weights
     const double *Mdiag, *Ndiag, *Ldiag, *Cwt;
+    const double* Mblk;   // optional [B][Hp][ny][ny]: block-diagonal M_Hp (symmetric blocks), replaces Mdiag
     // bounds + softness (null = group absent / default softness)
     const double *U0min, *U0max, *DUmin, *DUmax, *Y0min, *Y0max, *x0min, *x0max;
     const double *C_umin, *C_umax, *C_dumin, *C_dumax, *C_ymin, *C_ymax, *c_x0min, *c_x0max;

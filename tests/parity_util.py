@@ -67,3 +67,34 @@ def rel_err(Zg, Zo, nDU):
     """max_b ‖ΔU_gpu − ΔU_oracle‖∞ / max(1, ‖ΔU_oracle‖∞)  (BASELINE.md §4 'Parity')."""
     return np.max(np.abs(Zg[:, :nDU] - Zo[:, :nDU]), axis=1) / np.maximum(
         1.0, np.max(np.abs(Zo[:, :nDU]), axis=1))
+
+
+def lqr_terminal_cost_case():
+    """T6 (test/3_test_predictive_control.jl:498-527): terminal cost = DARE solution => LQR."""
+    from scipy.linalg import solve_discrete_are
+    A = np.array([[0.5, -0.4], [0.6, 0.5]]); Bu = np.eye(2); C = np.eye(2)
+    Q, R = np.eye(2), 0.5 * np.eye(2)
+    P = solve_discrete_are(A, Bu, Q, R)
+    K = np.linalg.solve(R + Bu.T @ P @ Bu, Bu.T @ P @ A)
+    M_Hp = np.block([[np.eye(4), np.zeros((4, 2))], [np.zeros((2, 4)), P]])
+    return A, Bu, C, K, M_Hp
+
+
+def run_lqr_terminal_cost(lib=None, B=3, steps=20):
+    """Closed loop of T6 through the C-ABI (nint_ym = 0: the state is measured); returns the MPC
+    and the LQR state trajectories, (2, steps) each."""
+    A, Bu, C, K, M_Hp = lqr_terminal_cost_case()
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    mpc = mpcqp.BatchLinMPC(rep(A), rep(Bu), rep(C), Hp=3, Hc=3, M_Hp=M_Hp, Nwt=[0, 0], Lwt=[0.5, 0.5], lib=lib)
+    X_mpc, X_lqr = np.zeros((2, steps)), np.zeros((2, steps))
+    x = np.array([1.0, 1.0])
+    for i in range(steps):
+        u = mpc.moveinput(np.tile(x, (B, 1)), [0.0, 0.0])
+        assert np.all(mpc.status == 0) and np.abs(u - u[0]).max() == 0.0
+        X_mpc[:, i] = x
+        x = A @ x + Bu @ u[B - 1]
+    x = np.array([1.0, 1.0])
+    for i in range(steps):
+        X_lqr[:, i] = x
+        x = A @ x + Bu @ (-K @ x)
+    return X_mpc, X_lqr

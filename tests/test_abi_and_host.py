@@ -68,6 +68,19 @@ def _small_case(nd=0, terminal=False, seed=0):
     return kf, orc, kw, model
 
 
+def test_T6_terminal_cost_is_lqr_on_cpu_emulator(emulib):
+    """Block-diagonal M_Hp (mpcqp_set_output_weight_blocks) through K2 + the step body: the
+    reference's tight analytic pin, test/3_test_predictive_control.jl:498-527 (atol 1e-5 there)."""
+    from tests.parity_util import run_lqr_terminal_cost
+    X_mpc, X_lqr = run_lqr_terminal_cost(lib=emulib, B=2)
+    assert np.abs(X_mpc - X_lqr).max() < 1e-10
+    A, Bu, C, K, M_Hp = __import__("tests.parity_util", fromlist=["x"]).lqr_terminal_cost_case()
+    bad = M_Hp.copy(); bad[0, 5] = bad[5, 0] = 0.1            # couples steps 1 and 3
+    rep = lambda a: np.broadcast_to(a, (2,) + a.shape).copy()
+    with pytest.raises(NotImplementedError):
+        mpcqp.BatchLinMPC(rep(A), rep(Bu), rep(C), Hp=3, Hc=3, M_Hp=bad, lib=emulib)
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("nd,terminal", [(0, False), (1, False), (0, True), (1, True)])
 def test_kernel_bodies_on_cpu_emulator(nd, terminal, emulib):

@@ -319,7 +319,16 @@ def test_on_demand_specialisation(hiplib):
     assert err[ref["certified"]].max() <= TOL
     cache = os.path.join(os.path.dirname(mpcqp.DEFAULT_LIB), "spec_cache")
     if os.environ.get("MPCQP_JIT", "1") != "0" and os.environ.get("MPCQP_FORCE_GENERIC", "0") != "1":
-        assert glob.glob(os.path.join(cache, "spec_3_2_7_12_4_1_*.so")), "specialisation was not built"
+        assert glob.glob(os.path.join(cache, "spec_r*_3_2_7_12_4_1_*.so")), "specialisation was not built"
     # second handle of the same dimensions: served from the in-process / on-disk cache
     got2 = run_batch(cfg, bt)
     assert np.array_equal(got2["Z"], got["Z"])
+
+
+def test_T6_terminal_cost_is_lqr_on_gpu(hiplib):
+    """T6, the reference's tight analytic pin of condense + solve (block-diagonal M_Hp with the
+    DARE solution as terminal weight => the MPC law is the LQR), test/3_test_predictive_control.jl:498-527
+    (atol 1e-5 there), through mpcqp_set_output_weight_blocks on the device."""
+    from tests.parity_util import run_lqr_terminal_cost
+    X_mpc, X_lqr = run_lqr_terminal_cost(B=64)
+    assert np.abs(X_mpc - X_lqr).max() < 1e-10
