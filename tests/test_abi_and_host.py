@@ -81,6 +81,20 @@ def test_T6_terminal_cost_is_lqr_on_cpu_emulator(emulib):
         mpcqp.BatchLinMPC(rep(A), rep(Bu), rep(C), Hp=3, Hc=3, M_Hp=bad, lib=emulib)
 
 
+def test_maximum_size_nZ_64_on_cpu_emulator(emulib):
+    """nZ~ = 64: every lane owns a row of the factor (index arithmetic of the packed layout, the
+    chunked sweeps and the row store at their limits)."""
+    from mpcqp import synth
+    from tests.parity_util import oracle_batch, rel_err, run_batch
+    cfg = synth.Config("max", nx=6, nu=7, ny=3, Hp=12, Hc=9, umin=-0.7, umax=0.8, dumin=-0.45,
+                       dumax=0.4, ymin=-1.6, ymax=1.3)
+    bt = synth.make_batch(cfg, 2, seed=5)
+    got = run_batch(cfg, bt, lib=emulib)
+    assert got["Z"].shape[1] == 64 and np.all(got["status"] == 0)
+    ref = oracle_batch(cfg, bt)
+    assert rel_err(got["Z"], ref["Z"], 63).max() <= 1e-5
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("nd,terminal", [(0, False), (1, False), (0, True), (1, True)])
 def test_kernel_bodies_on_cpu_emulator(nd, terminal, emulib):

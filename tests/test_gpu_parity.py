@@ -332,3 +332,20 @@ def test_T6_terminal_cost_is_lqr_on_gpu(hiplib):
     from tests.parity_util import run_lqr_terminal_cost
     X_mpc, X_lqr = run_lqr_terminal_cost(B=64)
     assert np.abs(X_mpc - X_lqr).max() < 1e-10
+
+
+def test_maximum_size_nZ_64_on_gpu(hiplib):
+    """Largest problem one wavefront holds: nZ~ = nu Hc + 1 = 64 (every lane owns a row of the
+    factor, four 16-wide tiles / three panel updates in the Cholesky), hard and soft rows of every
+    kind.  One more variable is rejected (test_abi_errors...)."""
+    cfg = synth.Config("max", nx=6, nu=7, ny=3, Hp=12, Hc=9, umin=-0.7, umax=0.8, dumin=-0.45,
+                       dumax=0.4, ymin=-1.6, ymax=1.3)
+    B = 24
+    bt = synth.make_batch(cfg, B, seed=5)
+    got = run_batch(cfg, bt)
+    assert got["Z"].shape[1] == 64
+    ref = oracle_batch(cfg, bt)
+    assert np.all(got["status"] == 0)
+    err = rel_err(got["Z"], ref["Z"], cfg.nu * cfg.Hc)
+    assert ref["certified"].sum() >= B // 2
+    assert err[ref["certified"]].max() <= TOL
