@@ -34,7 +34,7 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_recondense_device",
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
-           "mpcqp_set_output_weight_blocks")
+           "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -90,6 +90,8 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_weights.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_set_bounds.argtypes = [C.c_void_p, C.POINTER(Bounds)]
     lib.mpcqp_set_output_weight_blocks.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpcqp_set_custom_constraints.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    lib.mpcqp_set_custom_bounds.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
     lib.mpcqp_step_device.argtypes = [C.c_void_p] + [C.c_void_p] * 12
     lib.mpcqp_recondense_device.argtypes = [C.c_void_p, C.c_void_p]
@@ -172,6 +174,14 @@ class Handle:
         """Mblk (B, Hp, ny, ny), symmetric blocks, or None (back to the diagonal weight)."""
         a = None if Mblk is None else _f64(np.asarray(Mblk, float).transpose(0, 1, 3, 2))
         _chk(self.lib, self.lib.mpcqp_set_output_weight_blocks(self.h, _ptr(a)))
+
+    def set_custom_constraints(self, nw, Wy=None, Wu=None, Wd=None, Wr=None, w_op=None):
+        args = [None if a is None else _f64(a) for a in (Wy, Wu, Wd, Wr, w_op)]
+        _chk(self.lib, self.lib.mpcqp_set_custom_constraints(self.h, int(nw), *[_ptr(a) for a in args]))
+
+    def set_custom_bounds(self, Wmin=None, Wmax=None, C_wmin=None, C_wmax=None):
+        args = [None if a is None else _f64(a) for a in (Wmin, Wmax, C_wmin, C_wmax)]
+        _chk(self.lib, self.lib.mpcqp_set_custom_bounds(self.h, *[_ptr(a) for a in args]))
 
     def set_bounds(self, **kw):
         b = Bounds()
@@ -305,7 +315,7 @@ class BatchLinMPC:
     """
 
     def __init__(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None, *, Hp, Hc=2, Mwt=None, Nwt=None,
-                 Lwt=None, M_Hp=None, Cwt=1e5, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
+                 Lwt=None, M_Hp=None, Cwt=1e5, Wy=None, Wu=None, Wd=None, Wr=None, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
                  cold_start=False, keep_qp=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
                  lib=None):
         Ahat, Bhu, Chat = (np.asarray(a, float) for a in (Ahat, Bhu, Chat))
@@ -343,6 +353,35 @@ class BatchLinMPC:
         self.Cwt = cw
         self.setmodel(Ahat, Bhu, Chat, Bhd, Dhd)
         self.setweights(Mwt, Nwt, Lwt, M_Hp=M_Hp)
+        # custom linear constraints (validate_custom_lincon, src/controller/construct.jl:666-694)
+        given = [np.asarray(W, float) for W in (Wy, Wu, Wd, Wr) if W is not None]
+        self.nw = 0
+        if given:
+            first = given[0]
+            self.nw = (first.shape[0] if first.ndim == 2 else first.shape[1]) if first.ndim >= 2 else 1
+        nw = self.nw
+        def wmat(Wm, n, name):
+            if Wm is None:
+                return np.zeros((B, nw, n))
+            a = np.asarray(Wm, float)
+            if a.ndim == 1:
+                a = a.reshape(1, -1)
+            if a.ndim == 2:
+                a = np.broadcast_to(a, (B,) + a.shape)
+            if a.shape[2] != n:
+                raise ValueError(f"{name} must have {n} columns")           # DimensionMismatch, :686-689
+            if a.shape[1] != nw:
+                raise ValueError("Wy, Wu, Wd and Wr must have the same number of rows")
+            return a.copy()
+        self.Wy, self.Wu, self.Wd, self.Wr = wmat(Wy, ny, "Wy"), wmat(Wu, nu, "Wu"), wmat(Wd, nd, "Wd"), wmat(Wr, ny, "Wr")
+        self._wb = dict(Wmin=None, Wmax=None, C_wmin=None, C_wmax=None)
+        if nw > 0:
+            w_op = (np.einsum("bij,bj->bi", self.Wy, self.yop) + np.einsum("bij,bj->bi", self.Wu, self.uop)
+                    + np.einsum("bij,bj->bi", self.Wr, self.yop))
+            if nd > 0:
+                w_op = w_op + np.einsum("bij,bj->bi", self.Wd, self.dop)
+            self.hd.set_custom_constraints(nw, colmajor(self.Wy), colmajor(self.Wu),
+                                           colmajor(self.Wd) if nd > 0 else None, colmajor(self.Wr), w_op)
         # default constraints: none (src/controller/construct.jl:887-913)
         self._b = {k: None for k in BOUND_FIELDS}
         self.Z = np.zeros((B, self.nZ))            # mpc.Z̃ (previous optimum)
@@ -355,6 +394,8 @@ class BatchLinMPC:
     def setmodel(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None):
         """`setmodel!` re-condensation path (src/controller/execute.jl:684-790): K1 (+K2)."""
         dopv = self.fhop - self.xhop
+        self._Chat = np.asarray(Chat, float).copy()
+        self._Dhd = None if self.nd == 0 else np.asarray(Dhd, float).copy()
         self.hd.set_model(colmajor(Ahat), colmajor(Bhu), colmajor(Chat),
                           None if self.nd == 0 else colmajor(Bhd),
                           None if self.nd == 0 else colmajor(Dhd),
@@ -403,8 +444,9 @@ class BatchLinMPC:
                       c_ymin=None, c_ymax=None, c_x̂min=None, c_x̂max=None,
                       Deltaumin=None, Deltaumax=None, xhatmin=None, xhatmax=None,
                       DeltaUmin=None, DeltaUmax=None, c_Deltaumin=None, c_Deltaumax=None,
-                      c_xhatmin=None, c_xhatmax=None):
-        """`setconstraint!` (src/controller/construct.jl:324-559), nw = 0 subset, with the ASCII
+                      c_xhatmin=None, c_xhatmax=None, wmin=None, wmax=None, Wmin=None, Wmax=None,
+                      c_wmin=None, c_wmax=None, C_wmin=None, C_wmax=None):
+        """`setconstraint!` (src/controller/construct.jl:324-559), with the ASCII
         aliases.  Bounds are engineering values (operating points are subtracted here, :356-435);
         per-channel vectors (n,) or (B,n) are repeated over the horizon, capitalised keywords take
         the whole horizon."""
@@ -482,8 +524,36 @@ class BatchLinMPC:
                 new_inf = np.isinf(new[k]) if new[k] is not None else True
                 if np.any(old_inf != new_inf):
                     raise RuntimeError("Cannot modify ±Inf constraints after calling moveinput!")
+        # custom linear constraints: wmin/wmax (nw,) repeated over the Hp+1 steps, or Wmin/Wmax
+        # (nw (Hp+1),) (construct.jl:411-426, 487-494)
+        neww = dict(self._wb)
+        nW = self.nw * (Hp + 1)
+        for key, per, whole, nm in (("Wmin", wmin, Wmin, "wmin"), ("Wmax", wmax, Wmax, "wmax"),
+                                    ("C_wmin", c_wmin, C_wmin, "c_wmin"), ("C_wmax", c_wmax, C_wmax, "c_wmax")):
+            if whole is not None:
+                neww[key] = full(whole, nW, nm.capitalize())
+            elif per is not None:
+                neww[key] = rep(per, self.nw, Hp + 1, nm)
+        for key in ("C_wmin", "C_wmax"):
+            if neww[key] is not self._wb[key]:
+                if self.neps != 1:
+                    raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
+                if self.solved_once:
+                    raise RuntimeError("Cannot set softness parameters after calling moveinput!")
+                if np.any(neww[key] < 0):
+                    raise ValueError(f"{key} weights should be non-negative")
+        if self.solved_once:
+            for key in ("Wmin", "Wmax"):
+                old_inf = np.isinf(self._wb[key]) if self._wb[key] is not None else True
+                new_inf = np.isinf(neww[key]) if neww[key] is not None else True
+                if np.any(old_inf != new_inf):
+                    raise RuntimeError("Cannot modify ±Inf constraints after calling moveinput!")
         self._b = new
         self.hd.set_bounds(**{k: v for k, v in new.items() if v is not None})
+        if self.nw > 0 and any(neww[k] is not self._wb[k] for k in neww):
+            fin = lambda a: None if a is None or np.all(np.isinf(a)) else a
+            self.hd.set_custom_bounds(fin(neww["Wmin"]), fin(neww["Wmax"]), neww["C_wmin"], neww["C_wmax"])
+        self._wb = neww
         return self
 
     # -- estimator steps on both sides of moveinput! (SteadyKalmanFilter) ---------------------
@@ -552,6 +622,7 @@ class BatchLinMPC:
         u0, self.status, self.iters = out[0], out[1], out[2]
         self._Yhat0 = out[3] if want_info else None
         self._lastu0_prev = lastu0
+        self._winfo = (xhat0, Rhaty, d0, Dh0)
         self.solved_once = True
         nerr = int(np.sum(self.status == STATUS_ERROR))
         nwarn = int(np.sum(self.status == STATUS_ITERATION_LIMIT))
@@ -586,4 +657,20 @@ class BatchLinMPC:
                 "u": self.lastu0 + self.uop, "U": U0 + self.Uop}
         if self._Yhat0 is not None:
             info["Ŷ"] = self._Yhat0 + self.Yop
+            if self.nw > 0:       # W = Wy ŷe + Wu ue + Wd d̂e + Wr r̂e   (execute.jl:221, relaxW)
+                xhat0, Rhaty, d0, Dh0 = self._winfo
+                Hp, ny, nd = self.Hp, self.ny, self.nd
+                yk = np.einsum("bij,bj->bi", self._Chat, xhat0) + self.yop
+                if nd > 0:
+                    yk = yk + np.einsum("bij,bj->bi", self._Dhd, d0)
+                ye = np.concatenate([yk, info["Ŷ"]], axis=1).reshape(self.B, Hp + 1, ny)
+                U = info["U"].reshape(self.B, Hp, nu)
+                ue = np.concatenate([U, U[:, -1:, :]], axis=1)
+                re = np.concatenate([Rhaty[:, :ny], Rhaty], axis=1).reshape(self.B, Hp + 1, ny)
+                Wv = (np.einsum("bij,btj->bti", self.Wy, ye) + np.einsum("bij,btj->bti", self.Wu, ue)
+                      + np.einsum("bij,btj->bti", self.Wr, re))
+                if nd > 0:
+                    de = np.concatenate([d0 + self.dop, Dh0 + self.Dop], axis=1).reshape(self.B, Hp + 1, nd)
+                    Wv = Wv + np.einsum("bij,btj->bti", self.Wd, de)
+                info["W"] = Wv.reshape(self.B, -1)
         return info

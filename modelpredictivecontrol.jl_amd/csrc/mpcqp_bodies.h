@@ -60,6 +60,7 @@ struct StaticDims {
     static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS;
     static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP;
     static constexpr int npk = pk_size(nZ);
+    static constexpr int nw = 0, nW = 0;            // custom constraints run on the runtime-dims kernel only
     // LDS stride of one Σ_m block: padded so the MFMA operand reads of E'DE (64 lanes = 4 block
     // columns x NY*NU entries) fall in distinct bank groups (see DESIGN.md "LDS layout")
     static constexpr int sp = (NY * NU) % 16 == 0 ? NY * NU + 8 : NY * NU;
@@ -69,7 +70,7 @@ struct StaticDims {
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
     MPCQP_HD static constexpr int cnt(int p) {
-        return p == P_BOX ? nZ : p == P_U ? nDU : p == P_DU ? nDU : p == P_Y ? nY : nxh;
+        return p == P_BOX ? nZ : p == P_U ? nDU : p == P_DU ? nDU : p == P_Y ? nY : p == P_X ? nxh : 0;
     }
     MPCQP_HD static constexpr int rowoff(int g) {
         int o = 0;
@@ -83,7 +84,7 @@ struct StaticDims {
           dual_reg(d.dual_reg), flags(d.flags) {}
     static bool matches_dims(const Dims& d) {
         return d.nu == NU && d.ny == NY && d.nxh == NXH && d.Hp == HP && d.Hc == HC &&
-               d.neps == NEPS && d.default_nb == DNB;
+               d.neps == NEPS && d.default_nb == DNB && d.nw == 0;
     }
     static bool matches(const Dims& d) { return matches_dims(d) && d.gmask == GMASK; }
 };
@@ -95,7 +96,7 @@ struct StaticDims {
 constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs (cs only stored with runtime dims)
 
 struct Carve {
-    int S, Phi, zero, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT;
+    int S, Phi, zero, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT, Wm;
     int rows[NROWARR];
     int jl, blk;               // int tables (offset in doubles, storage as int)
     int total;                 // doubles
@@ -122,7 +123,8 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     c.F = -1;                                     // placed below (aliases the Ŷ-row scratch when it exists)
     MPCQP_UNROLL
     for (int p = 0; p < NPAIR; ++p) {
-        const bool on = (d.gmask >> (2 * p)) & 3u;
+        const bool won = (d.gmask >> (2 * P_W)) & 3u;        // custom rows act through the Y and U primitives
+        const bool on = ((d.gmask >> (2 * p)) & 3u) || (won && (p == P_Y || p == P_U));
         // pair Y's tA doubles as the E*v scratch, so it always exists
         c.tA[p] = take((on || p == P_Y) ? d.cnt(p) : 0);
         c.tB[p] = take((on && p != P_BOX) ? d.cnt(p) : 0);
@@ -131,6 +133,7 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     // output parks it in the caller's Yhat0 buffer), so it shares the tB scratch of the Ŷ rows
     c.F = (((d.gmask >> (2 * P_Y)) & 3u) && c.tB[P_Y] >= 0) ? c.tB[P_Y] : take(d.nY);
     c.ucum = take(d.nDU);
+    c.Wm = take(((d.gmask >> (2 * P_W)) & 3u) ? d.nw * (d.ny + d.nu) : 0);   // Wy (nw x ny), Wu (nw x nu), column-major
     c.exT = take(((d.gmask >> (2 * P_X)) & 3u) ? d.Hc * d.nxh * d.nu : 0);
     const int M = DM::is_static ? 0 : d.nrows();
     MPCQP_UNROLL
@@ -183,7 +186,53 @@ struct Qp {
             const double* e = m.exT + (size_t)b * ne;
             for (int i = w.lane; i < ne; i += WAVE) sm[c.exT + i] = e[i];
         }
+        if constexpr (!DM::is_static) {
+            if (pair_on(P_W)) {
+                const int n1 = d.nw * d.ny, n2 = d.nw * d.nu;
+                for (int i = w.lane; i < n1; i += WAVE) sm[c.Wm + i] = m.Wy[(size_t)b * n1 + i];
+                for (int i = w.lane; i < n2; i += WAVE) sm[c.Wm + n1 + i] = m.Wu[(size_t)b * n2 + i];
+            }
+        }
         if (w.lane < 4) sm[c.zero + w.lane] = 0.0;
+        w.sync();
+    }
+
+    // custom linear constraints (relaxW, construct.jl:1086-1160): row (t, i), t = 0..Hp, of
+    //   E_w = W̄y [0; E] + W̄u [Pu; pu]
+    // acts on the output primitive of step t-1 (none for t = 0) and on the input of step
+    // min(t, Hp-1) (pu = last block row of Pu)
+    MPCQP_HD double Wy_(int i, int a) const { return sm[c.Wm + i + d.nw * a]; }
+    MPCQP_HD double Wu_(int i, int cc) const { return sm[c.Wm + d.nw * d.ny + i + d.nw * cc]; }
+    MPCQP_HD int blkW(int t) const { return blk(t < d.Hp ? t : d.Hp - 1); }
+    // E_w[(t,i), (j,c)]
+    MPCQP_HD double Ew_at(int t, int i, int j, int cc) const {
+        double g = 0.0;
+        if (t >= 1 && t - 1 >= jl(j)) {
+            const double* Sb = S + (t - 1 - jl(j)) * sp + cc;
+            for (int a = 0; a < d.ny; ++a) g += Wy_(i, a) * Sb[a * d.nu];
+        }
+        if (j <= blkW(t)) g += Wu_(i, cc);
+        return g;
+    }
+    // Y / U primitives += (their share of) E_w' wW:  tY[(t',a)] += sum_i Wy[i,a] wW[(t'+1, i)],
+    // tU[(j,c)] += sum_{t: block(t) = j} sum_i Wu[i,c] wW[(t, i)]; `fresh`: the scratch vector holds
+    // nothing yet (its own pair is off)
+    MPCQP_HD void W_fold(const double* wW, double* tY, bool freshY, double* tU, bool freshU) {
+        const int nw = d.nw, ny = d.ny, nu = d.nu;
+        for (int r = w.lane; r < d.nY; r += WAVE) {
+            const int t = r / ny, a = r - t * ny;
+            double acc = freshY ? 0.0 : tY[r];
+            for (int i = 0; i < nw; ++i) acc += Wy_(i, a) * wW[(t + 1) * nw + i];
+            tY[r] = acc;
+        }
+        for (int k = w.lane; k < d.nDU; k += WAVE) {
+            const int j = k / nu, cc = k - j * nu;
+            const int t1 = (j + 1 < d.Hc) ? jl(j + 1) : d.Hp + 1;      // step Hp repeats the last block
+            double acc = freshU ? 0.0 : tU[k];
+            for (int t = jl(j); t < t1; ++t)
+                for (int i = 0; i < nw; ++i) acc += Wu_(i, cc) * wW[t * nw + i];
+            tU[k] = acc;
+        }
         w.sync();
     }
 
@@ -717,6 +766,8 @@ struct Step {
             case 2 * P_Y + 1: p = m.C_ymax; def = 1.0; break;
             case 2 * P_X: p = m.c_x0min; def = 1.0; break;
             case 2 * P_X + 1: p = m.c_x0max; def = 1.0; break;
+            case 2 * P_W: p = m.C_wmin; def = 1.0; break;
+            case 2 * P_W + 1: p = m.C_wmax; def = 1.0; break;
             default: return 0.0;
         }
         if (!p) return def;
@@ -780,6 +831,46 @@ struct Step {
     }
 
     MPCQP_HD static bool fin(const Row& r) { return r.h < BIG; }
+
+    // F_w of linconstraint_custom! (execute.jl:337-364), row k = (t, i), t = 0..Hp:
+    //   Wy [ŷ(k); F + Yop] + Wu [Tu u(k-1) + Uop; u(k-1)] + Wd [d(k); D̂] + Wr [ry(k); R̂y]
+    // in deviation variables plus the operating-point part w_op = Wy yop + Wu uop + Wd dop + Wr yop.
+    // ŷ0(k) = Ĉ x̂0 + D̂d d0 (evaloutput); r̂e(k) is the first block of R̂y (the reference's default
+    // R̂y = repeat(ry)).
+    MPCQP_HD double Fw_at(int k, const StepIO& io, const double* x0, const double* lu) const {
+        const int nw = d.nw, ny = d.ny, nu = d.nu, nd = d.nd, nx = d.nxh;
+        const int t = k / nw, i = k - t * nw;
+        const bool rconst = d.flags & 1u;
+        double acc = m.w_op ? m.w_op[(size_t)b * nw + i] : 0.0;
+        for (int a = 0; a < ny; ++a) {
+            double ye;
+            if (t == 0) {
+                const double* Cm = m.C + (size_t)b * ny * nx;          // (ny,nx̂) column-major
+                ye = 0.0;
+                for (int kk = 0; kk < nx; ++kk) ye += Cm[a + ny * kk] * x0[kk];
+                if (nd > 0) {
+                    const double* Dd = m.Dd + (size_t)b * ny * nd;
+                    for (int e = 0; e < nd; ++e) ye += Dd[a + ny * e] * io.d0[(size_t)b * nd + e];
+                }
+            } else {
+                ye = F[(t - 1) * ny + a];
+            }
+            acc += qp.Wy_(i, a) * ye;
+            if (m.Wr) {
+                const int tr = t == 0 ? 0 : t - 1;
+                const double re = rconst ? io.Ry[(size_t)b * ny + a] : io.Ry[(size_t)b * d.nY + tr * ny + a];
+                acc += m.Wr[(size_t)b * nw * ny + i + nw * a] * re;
+            }
+        }
+        for (int cc = 0; cc < nu; ++cc) acc += qp.Wu_(i, cc) * lu[cc];
+        if (m.Wd && nd > 0) {
+            for (int e = 0; e < nd; ++e) {
+                const double de = t == 0 ? io.d0[(size_t)b * nd + e] : io.Dhat0[(size_t)b * d.nD + (t - 1) * nd + e];
+                acc += m.Wd[(size_t)b * nw * nd + i + nw * e] * de;
+            }
+        }
+        return acc;
+    }
 
     // ---- free response, gradient, right-hand sides (initpred!, linconstraint!) -------------
     MPCQP_HD void build(const StepIO& io) {
@@ -916,6 +1007,8 @@ struct Step {
                 case 2 * P_Y + 1: if (m.Y0max) bound = m.Y0max[o] - F[k]; break;
                 case 2 * P_X: if (m.x0min) bound = -m.x0min[o] + fx[k]; break;
                 case 2 * P_X + 1: if (m.x0max) bound = m.x0max[o] - fx[k]; break;
+                case 2 * P_W: if (m.Wmin) bound = -m.Wmin[o] + Fw_at(k, io, x0, lu); break;
+                case 2 * P_W + 1: if (m.Wmax) bound = m.Wmax[o] - Fw_at(k, io, x0, lu); break;
             }
             const bool ok = fabs(bound) < BIG && bound == bound;
             r.h = ok ? bound : 2.0 * BIG;
@@ -934,7 +1027,7 @@ struct Step {
     MPCQP_HD void primitives(const double* v) {
         const int nu = d.nu;
         const long long tic11_ = clock64_();
-        if (qp.pair_on(P_U)) {
+        if (qp.pair_on(P_U) || qp.pair_on(P_W)) {
             double* ucum = sm + c.ucum;
             for (int k = w.lane; k < d.nDU; k += WAVE) {
                 const int j = k / nu, cc = k - j * nu;
@@ -946,7 +1039,7 @@ struct Step {
         }
         prof_[11] += (double)(clock64_() - tic11_);
         const long long tic12_ = clock64_();
-        if (qp.pair_on(P_Y)) qp.E_apply(v, sm + c.tA[P_Y]);
+        if (qp.pair_on(P_Y) || qp.pair_on(P_W)) qp.E_apply(v, sm + c.tA[P_Y]);
         prof_[12] += (double)(clock64_() - tic12_);
         if (qp.pair_on(P_X)) {
             double* tX = sm + c.tA[P_X];
@@ -965,6 +1058,18 @@ struct Step {
             case P_U: return sm[c.ucum + k];
             case P_DU: return v[k];
             case P_Y: return sm[c.tA[P_Y] + k];
+            case P_W: {
+                if constexpr (DM::is_static) return 0.0;
+                else {
+                    const int t = k / d.nw, i = k - t * d.nw;
+                    double acc = 0.0;
+                    if (t >= 1)
+                        for (int a = 0; a < d.ny; ++a) acc += qp.Wy_(i, a) * sm[c.tA[P_Y] + (t - 1) * d.ny + a];
+                    const int jb = qp.blkW(t);
+                    for (int cc = 0; cc < d.nu; ++cc) acc += qp.Wu_(i, cc) * sm[c.ucum + jb * d.nu + cc];
+                    return acc;
+                }
+            }
             default: return sm[c.tA[P_X] + k];
         }
     }
@@ -1000,6 +1105,13 @@ struct Step {
         });
         eacc = w.sum(eacc);
         w.sync();
+        bool useY = qp.pair_on(P_Y), useU = qp.pair_on(P_U);
+        if constexpr (!DM::is_static) {
+            if (qp.pair_on(P_W)) {          // custom rows reach z through the Y and U primitives
+                qp.W_fold(sm + c.tA[P_W], sm + c.tA[P_Y], !useY, sm + c.tA[P_U], !useU);
+                useY = useU = true;
+            }
+        }
         prof_[8] += (double)(clock64_() - tic_gt_);
         const long long tic9_ = clock64_();
         for (int k = w.lane; k < d.nZ; k += WAVE) {
@@ -1007,7 +1119,7 @@ struct Step {
             if (qp.pair_on(P_BOX)) acc += sm[c.tA[P_BOX] + k];
             if (k < d.nDU) {
                 if (qp.pair_on(P_DU)) acc += sm[c.tA[P_DU] + k];
-                if (qp.pair_on(P_U)) {
+                if (useU) {
                     const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tA[P_U];
                     for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];
@@ -1023,7 +1135,7 @@ struct Step {
         }
         prof_[9] += (double)(clock64_() - tic9_);
         const long long tic10_ = clock64_();
-        if (qp.pair_on(P_Y)) qp.Et_apply_add(sm + c.tA[P_Y], gt);   // same lane owns gt[k]
+        if (useY) qp.Et_apply_add(sm + c.tA[P_Y], gt);   // same lane owns gt[k]
         w.sync();
         prof_[10] += (double)(clock64_() - tic10_);
         MPCQP_TOC(1);
@@ -1054,6 +1166,13 @@ struct Step {
         });
         ee = w.sum(ee);
         w.sync();
+        bool epsY = qp.pair_on(P_Y), epsU = qp.pair_on(P_U);     // who feeds the ϵ row below
+        if constexpr (!DM::is_static) {
+            if (qp.pair_on(P_W) && d.neps) {      // ϵ row of the custom rows: E_w' tB_W through Y and U
+                qp.W_fold(sm + c.tB[P_W], sm + c.tB[P_Y], !epsY, sm + c.tB[P_U], !epsU);
+                epsY = epsU = true;
+            }
+        }
         MPCQP_TOC(3);
         // dense E' dY E (+ the ϵ row of the Ŷ rows on the matrix-core path)
         bool eps_y_done = false;
@@ -1089,6 +1208,25 @@ struct Step {
                 Phi[pk(i, ip)] += acc;
             }
         }
+        if constexpr (!DM::is_static) {
+            if (qp.pair_on(P_W)) {        // E_w' dW E_w, rows formed on the fly (set-up-grade path)
+                w.sync();
+                const int ntri = nDU * (nDU + 1) / 2, nw = d.nw;
+                const double* dW = sm + c.tA[P_W];
+                for (int idx = w.lane; idx < ntri; idx += WAVE) {
+                    int i, ip;
+                    Qp<W, DM>::unpack_idx(idx, i, ip);
+                    const int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
+                    double acc = 0.0;
+                    for (int t = 0; t <= d.Hp; ++t)
+                        for (int iw = 0; iw < nw; ++iw) {
+                            const double dk = dW[t * nw + iw];
+                            if (dk != 0.0) acc += dk * qp.Ew_at(t, iw, j, cc) * qp.Ew_at(t, iw, j2, c2);
+                        }
+                    Phi[pk(i, ip)] += acc;
+                }
+            }
+        }
         w.sync();
         for (int k = w.lane; k < nZ; k += WAVE) {
             double acc = 0.0;
@@ -1103,7 +1241,7 @@ struct Step {
             for (int k = w.lane; k < nDU; k += WAVE) {
                 double acc = 0.0;
                 if (qp.pair_on(P_DU)) acc += sm[c.tB[P_DU] + k];
-                if (qp.pair_on(P_U)) {
+                if (epsU) {
                     const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tB[P_U];
                     MPCQP_UNROLL4
@@ -1115,7 +1253,7 @@ struct Step {
                 }
                 st[k] = acc;
             }
-            if (qp.pair_on(P_Y) && !eps_y_done) qp.Et_apply_add(sm + c.tB[P_Y], st);   // same lane owns st[k]
+            if (epsY && !eps_y_done) qp.Et_apply_add(sm + c.tB[P_Y], st);   // same lane owns st[k]
             for (int k = w.lane; k < nDU; k += WAVE) Phi[pk(nZ - 1, k)] += st[k];
         }
         w.sync();

@@ -41,6 +41,7 @@ struct mpcqp_handle_s {
     std::vector<void*> owned;
     // model / weights / bounds storage
     DBuf Ahat, Bu, C, Bd, Dd, dop, Mdiag, Ndiag, Ldiag, Cwt, Mblk;
+    DBuf Wy, Wu, Wd, Wr, w_op, Wmin, Wmax, C_wmin, C_wmax;
     DBuf bnd[16];
     // staging for the host-pointer step
     DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
@@ -96,6 +97,7 @@ const char* mpcqp_last_hip_error(void) { return g_hip_err.c_str(); }
 static void layout_rows(mpcqp_handle h) {
     Dims& d = h->d;
     d.cnt_[P_BOX] = d.nZ; d.cnt_[P_U] = d.nDU; d.cnt_[P_DU] = d.nDU; d.cnt_[P_Y] = d.nY; d.cnt_[P_X] = d.nxh;
+    d.cnt_[P_W] = d.nW;
     int o = 0;
     for (int g = 0; g < NGROUP; ++g) {
         d.rowoff_[g] = o;
@@ -136,6 +138,7 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     d.Hp = in->Hp; d.Hc = in->Hc; d.neps = in->neps;
     d.nZ = nZ; d.nDU = in->nu * in->Hc; d.nU = in->nu * in->Hp; d.nY = in->ny * in->Hp;
     d.nD = in->nd * in->Hp;
+    d.nw = 0; d.nW = 0;
     d.npk = pk_size(nZ);
     d.flags = in->flags;
     d.max_iter = in->max_iter > 0 ? in->max_iter : 100;
@@ -305,6 +308,64 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
     return MPCQP_OK;
 }
 
+int mpcqp_set_custom_constraints(mpcqp_handle h, int nw, const double* Wy, const double* Wu,
+                                 const double* Wd, const double* Wr, const double* w_op) {
+    if (!h) return MPCQP_ERR_NULL;
+    Dims& d = h->d;
+    if (nw < 0) return MPCQP_ERR_ARG;
+    if (nw > 0 && (!Wy || !Wu)) return MPCQP_ERR_NULL;
+    HIPCHK(hipSetDevice(h->device));
+    Model& m = h->m;
+    d.nw = nw; d.nW = nw * (d.Hp + 1);
+    d.gmask &= ~(3u << (2 * P_W));          // bounds of a previous definition are dropped
+    m.Wy = m.Wu = m.Wd = m.Wr = m.w_op = nullptr;
+    m.Wmin = m.Wmax = m.C_wmin = m.C_wmax = nullptr;
+    if (nw > 0) {
+        const size_t B = d.B, sz = sizeof(double);
+        int rc = upload(h, h->Wy, Wy, B * nw * d.ny * sz);
+        if (!rc) rc = upload(h, h->Wu, Wu, B * nw * d.nu * sz);
+        if (!rc && Wd && d.nd > 0) rc = upload(h, h->Wd, Wd, B * nw * d.nd * sz);
+        if (!rc && Wr) rc = upload(h, h->Wr, Wr, B * nw * d.ny * sz);
+        if (!rc && w_op) rc = upload(h, h->w_op, w_op, B * nw * sz);
+        if (rc) return rc;
+        m.Wy = (const double*)h->Wy.p; m.Wu = (const double*)h->Wu.p;
+        m.Wd = (Wd && d.nd > 0) ? (const double*)h->Wd.p : nullptr;
+        m.Wr = Wr ? (const double*)h->Wr.p : nullptr;
+        m.w_op = w_op ? (const double*)h->w_op.p : nullptr;
+    }
+    layout_rows(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_set_custom_bounds(mpcqp_handle h, const double* Wmin, const double* Wmax,
+                            const double* C_wmin, const double* C_wmax) {
+    if (!h) return MPCQP_ERR_NULL;
+    Dims& d = h->d;
+    if (d.nw < 1) return MPCQP_ERR_ORDER;               // mpcqp_set_custom_constraints first
+    if (!d.neps && (C_wmin || C_wmax)) return MPCQP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    Model& m = h->m;
+    const size_t n = (size_t)d.B * d.nW * sizeof(double);
+    const double* src[4] = {Wmin, Wmax, C_wmin, C_wmax};
+    DBuf* buf[4] = {&h->Wmin, &h->Wmax, &h->C_wmin, &h->C_wmax};
+    const double* dev[4];
+    for (int i = 0; i < 4; ++i) {
+        dev[i] = nullptr;
+        if (!src[i]) continue;
+        int rc = upload(h, *buf[i], src[i], n);
+        if (rc) return rc;
+        dev[i] = (const double*)buf[i]->p;
+    }
+    m.Wmin = dev[0]; m.Wmax = dev[1]; m.C_wmin = dev[2]; m.C_wmax = dev[3];
+    d.gmask &= ~(3u << (2 * P_W));
+    if (m.Wmin) d.gmask |= 1u << (2 * P_W);
+    if (m.Wmax) d.gmask |= 1u << (2 * P_W + 1);
+    layout_rows(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
 int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
     if (!h || !bin) return MPCQP_ERR_NULL;
     Dims& d = h->d;
@@ -354,6 +415,7 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
     if (m.Y0max) g |= 1u << (2 * P_Y + 1);
     if (m.x0min) g |= 1u << (2 * P_X);
     if (m.x0max) g |= 1u << (2 * P_X + 1);
+    g |= d.gmask & (3u << (2 * P_W));                    // custom rows: mpcqp_set_custom_bounds
     d.gmask = g;
     layout_rows(h);
     if (terminal_on(d) && !h->terminal_built && h->have_model) {

@@ -166,7 +166,8 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
         }
         MPCQP_SPECIALIZATIONS(X)
 #undef X
-        if (const SpecLib* sl = jit_specialise(d)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
+        if (d.nw == 0)       // (custom linear constraints run on the runtime-dims kernel)
+            if (const SpecLib* sl = jit_specialise(d)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
     }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_step, lds);

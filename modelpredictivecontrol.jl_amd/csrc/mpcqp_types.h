@@ -35,11 +35,11 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 2
+#define MPCQP_KERNEL_REV 3
 
 namespace mpcqp {
 
-enum { P_BOX = 0, P_U = 1, P_DU = 2, P_Y = 3, P_X = 4, NPAIR = 5, NGROUP = 10 };
+enum { P_BOX = 0, P_U = 1, P_DU = 2, P_Y = 3, P_X = 4, P_W = 5, NPAIR = 6, NGROUP = 12 };
 
 constexpr int WAVE = 64;          // gfx950 wavefront
 constexpr double BIG = 1e300;     // |h| >= BIG  <=>  row absent (bound was +-Inf)
@@ -49,10 +49,11 @@ constexpr double BIG = 1e300;     // |h| >= BIG  <=>  row absent (bound was +-In
 struct Dims {
     int B, nxh, nu, ny, nd, Hp, Hc, neps;
     int nZ, nDU, nU, nY, nD;
+    int nw, nW;              // custom linear constraints: rows per step, nw (Hp+1) in total (0: none)
     int npk;                 // pk_size(nZ): packed lower triangle, rows padded in groups of four
     uint32_t gmask;          // bit g set <=> row group g may hold finite rows (handle level)
     int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
-    int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh
+    int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh, nW
     int default_nb;          // 1 iff nb = [1,..,1,Hp-Hc+1]
     int max_iter;
     double gap_tol, res_tol, dual_reg;
@@ -85,6 +86,10 @@ struct Model {
     // bounds + softness (null = group absent / default softness)
     const double *U0min, *U0max, *DUmin, *DUmax, *Y0min, *Y0max, *x0min, *x0max;
     const double *C_umin, *C_umax, *C_dumin, *C_dumax, *C_ymin, *C_ymax, *c_x0min, *c_x0max;
+    // custom linear constraints (relaxW, construct.jl:1086-1160): W = Wy ŷe + Wu ue + Wd d̂e + Wr r̂e
+    const double *Wy, *Wu, *Wd, *Wr;   // [B][ny|nu|nd|ny][nw] (ABI (nw,·,B)); Wd, Wr may be null
+    const double* w_op;                // [B][nw] operating-point part of W, may be null
+    const double *Wmin, *Wmax, *C_wmin, *C_wmax;   // [B][nW]
     // horizon tables
     const int* jl;   // [Hc+1] block starts j_l (move_blocking, construct.jl:597-660)
     const int* blk;  // [Hp]   index of the block that holds step t

@@ -227,6 +227,18 @@ def relaxterminal(ex, c_xmin, c_xmax, neps):
     return A_min, A_max, ext
 
 
+def relaxW(E, Pu, Hp, Wby, Wbu, C_wmin, C_wmax, neps):
+    """`relaxW` -- src/controller/construct.jl:1138-1160: E_w = W̄y [0; E] + W̄u [Pu; pu] with
+    pu the last nu rows of Pu; A_Wmin = -[E_w C_wmin], A_Wmax = [E_w -C_wmax], Ẽ_w = [E_w 0]."""
+    nW = Wby.shape[0]
+    ny = Wby.shape[1] // (Hp + 1)
+    nu = Pu.shape[0] // Hp
+    Ew = Wby @ np.vstack([np.zeros((ny, E.shape[1])), E]) + Wbu @ np.vstack([Pu, Pu[-nu:, :]])
+    if neps == 1:
+        return -np.hstack([Ew, C_wmin[:, None]]), np.hstack([Ew, -C_wmax[:, None]]), np.hstack([Ew, np.zeros((nW, 1))])
+    return -Ew, Ew, Ew
+
+
 def init_boxconstraint(nDU, neps, DUmin, DUmax, A_DUmin, A_DUmax):
     """`init_boxconstraint_mpc` -- src/controller/construct.jl:1209-1234 (SingleShooting).
 
@@ -248,21 +260,25 @@ def init_boxconstraint(nDU, neps, DUmin, DUmax, A_DUmin, A_DUmax):
 
 
 def init_matconstraint(Zmin, Zmax, U0min, U0max, DUmin, DUmax, Y0min, Y0max, x0min, x0max,
-                       A_Umin, A_Umax, A_DUmin, A_DUmax, A_Ymin, A_Ymax, A_xmin, A_xmax):
+                       A_Umin, A_Umax, A_DUmin, A_DUmax, A_Ymin, A_Ymax, A_xmin, A_xmax,
+                       Wmin=None, Wmax=None, A_Wmin=None, A_Wmax=None):
     """`init_matconstraint_mpc(::LinModel)` + `deleteΔU_lincon!`.
 
-    src/controller/transcription.jl:667-703 and :783-789 (no custom W rows: nw = 0).  Row order
-    [Umin; Umax; ΔUmin; ΔUmax; Ymin; Ymax; x̂min; x̂max] -- the x̂ blocks in the *correct* order
+    src/controller/transcription.jl:667-703 and :783-789.  Row order
+    [Umin; Umax; ΔUmin; ΔUmax; Ymin; Ymax; Wmin; Wmax; x̂min; x̂max] -- the x̂ blocks in the *correct* order
     (SURVEY 9.4 item 2).
     """
-    A = np.vstack([A_Umin, A_Umax, A_DUmin, A_DUmax, A_Ymin, A_Ymax, A_xmin, A_xmax])
+    if Wmin is None:
+        Wmin = Wmax = np.zeros(0)
+        A_Wmin = A_Wmax = np.zeros((0, A_Umin.shape[1]))
+    A = np.vstack([A_Umin, A_Umax, A_DUmin, A_DUmax, A_Ymin, A_Ymax, A_Wmin, A_Wmax, A_xmin, A_xmax])
     fin = lambda v: ~np.isinf(v)
     i_DUmin, i_DUmax = fin(DUmin), fin(DUmax)
     nDU = len(DUmin)
     i_DUmin &= np.isinf(Zmin[:nDU])
     i_DUmax &= np.isinf(Zmax[:nDU])
     i_b = np.concatenate([fin(U0min), fin(U0max), i_DUmin, i_DUmax, fin(Y0min), fin(Y0max),
-                          fin(x0min), fin(x0max)])
+                          fin(Wmin), fin(Wmax), fin(x0min), fin(x0max)])
     return A, i_b
 
 
@@ -284,7 +300,7 @@ class LinMPCOracle:
 
     def __init__(self, Ah, Bhu, Ch, Bhd=None, Dhd=None, *, Hp, Hc=2, Mwt=None, Nwt=None, Lwt=None,
                  Cwt=1e5, M_Hp=None, N_Hc=None, L_Hp=None, uop=None, yop=None, dop=None,
-                 xhop=None, fhop=None):
+                 xhop=None, fhop=None, Wy=None, Wu=None, Wd=None, Wr=None):
         Ah, Bhu, Ch = (np.atleast_2d(np.asarray(m, float)) for m in (Ah, Bhu, Ch))
         self.nxh, self.nu = Bhu.shape
         self.ny = Ch.shape[0]
@@ -333,6 +349,20 @@ class LinMPCOracle:
         self.C_dumin, self.C_dumax = np.zeros(nDU), np.zeros(nDU)
         self.C_ymin, self.C_ymax = np.ones(ny * Hp), np.ones(ny * Hp)
         self.c_xmin, self.c_xmax = np.ones(nxh), np.ones(nxh)
+        # custom linear constraints -- validate_custom_lincon, src/controller/construct.jl:666-694
+        given = [np.atleast_2d(np.asarray(W, float)) for W in (Wy, Wu, Wd, Wr) if W is not None]
+        self.nw = given[0].shape[0] if given else 0
+        nw = self.nw
+        mat = lambda W, n: np.zeros((nw, n)) if W is None else np.atleast_2d(np.asarray(W, float))
+        self.Wy, self.Wu, self.Wd, self.Wr = mat(Wy, ny), mat(Wu, nu), mat(Wd, nd), mat(Wr, ny)
+        for W, n, name in ((self.Wy, ny, "Wy"), (self.Wu, nu, "Wu"), (self.Wd, nd, "Wd"), (self.Wr, ny, "Wr")):
+            if W.shape != (nw, n):
+                raise ValueError(f"{name} must have {nw} rows and {n} columns")
+        rd = lambda W: np.kron(np.eye(Hp + 1), W)                   # repeatdiag, src/general.jl:226
+        self.Wby, self.Wbu, self.Wbd, self.Wbr = rd(self.Wy), rd(self.Wu), rd(self.Wd), rd(self.Wr)
+        self.nW = nw * (Hp + 1)
+        self.Wmin, self.Wmax = np.full(self.nW, -INF), np.full(self.nW, INF)
+        self.C_wmin, self.C_wmax = np.ones(self.nW), np.ones(self.nW)
         self._rebuild_constraints()
         self.Ht = init_quadprog(self.Et, self.PDut, self.Put, self.M_Hp, self.Nt_Hc, self.L_Hp)
         # state carried between calls
@@ -350,19 +380,35 @@ class LinMPCOracle:
         self.Zmin, self.Zmax = init_boxconstraint(self.nDU, ne, self.DUmin, self.DUmax,
                                                   self.A_DUmin if ne else None,
                                                   self.A_DUmax if ne else None)
+        self.A_Wmin, self.A_Wmax, self.Ewt = relaxW(self.E, self.Pu, self.Hp, self.Wby, self.Wbu,
+                                                    self.C_wmin, self.C_wmax, ne)
         self.A, self.i_b = init_matconstraint(
             self.Zmin, self.Zmax, self.U0min, self.U0max, self.DUmin, self.DUmax,
             self.Y0min, self.Y0max, self.x0min, self.x0max,
             self.A_Umin, self.A_Umax, self.A_DUmin, self.A_DUmax,
-            self.A_Ymin, self.A_Ymax, self.A_xmin, self.A_xmax)
+            self.A_Ymin, self.A_Ymax, self.A_xmin, self.A_xmax,
+            self.Wmin, self.Wmax, self.A_Wmin, self.A_Wmax)
 
     def setconstraint(self, *, umin=None, umax=None, dumin=None, dumax=None, ymin=None, ymax=None,
                       xhatmin=None, xhatmax=None, Umin=None, Umax=None, DUmin=None, DUmax=None,
                       Ymin=None, Ymax=None, c_umin=None, c_umax=None, c_dumin=None, c_dumax=None,
-                      c_ymin=None, c_ymax=None, c_xhatmin=None, c_xhatmax=None):
-        """`setconstraint!` -- src/controller/construct.jl:324-559 (nw = 0 subset)."""
+                      c_ymin=None, c_ymax=None, c_xhatmin=None, c_xhatmax=None,
+                      wmin=None, wmax=None, Wmin=None, Wmax=None, c_wmin=None, c_wmax=None,
+                      C_wmin=None, C_wmax=None):
+        """`setconstraint!` -- src/controller/construct.jl:324-559."""
         Hp, Hc = self.Hp, self.Hc
         f = lambda v: np.asarray(v, float).ravel()
+        for v, name in ((wmin, "wmin"), (wmax, "wmax"), (c_wmin, "c_wmin"), (c_wmax, "c_wmax")):
+            if v is not None and f(v).shape != (self.nw,):
+                raise ValueError(f"{name} size must be ({self.nw},)")       # construct.jl:411,420
+        if Wmin is None and wmin is not None:
+            self.Wmin = np.tile(f(wmin), Hp + 1)
+        elif Wmin is not None:
+            self.Wmin = f(Wmin)
+        if Wmax is None and wmax is not None:
+            self.Wmax = np.tile(f(wmax), Hp + 1)
+        elif Wmax is not None:
+            self.Wmax = f(Wmax)
         if Umin is None and umin is not None:
             self.U0min = np.tile(f(umin), Hp) - self.Uop
         elif Umin is not None:
@@ -391,7 +437,8 @@ class LinMPCOracle:
             self.x0min = f(xhatmin) - self.xhop
         if xhatmax is not None:
             self.x0max = f(xhatmax) - self.xhop
-        ecrs = (c_umin, c_umax, c_dumin, c_dumax, c_ymin, c_ymax, c_xhatmin, c_xhatmax)
+        ecrs = (c_umin, c_umax, c_dumin, c_dumax, c_ymin, c_ymax, c_xhatmin, c_xhatmax,
+                c_wmin, c_wmax, C_wmin, C_wmax)
         if any(e is not None for e in ecrs):
             if self.neps != 1:
                 raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
@@ -413,6 +460,17 @@ class LinMPCOracle:
             self.c_xmin = f(c_xhatmin)
         if c_xhatmax is not None:
             self.c_xmax = f(c_xhatmax)
+        for v in (c_wmin, c_wmax, C_wmin, C_wmax):
+            if v is not None and np.any(f(v) < 0):
+                raise RuntimeError("softness parameters must be nonnegative")    # construct.jl:495-509
+        if C_wmin is None and c_wmin is not None:
+            self.C_wmin = np.tile(f(c_wmin), Hp + 1)
+        elif C_wmin is not None:
+            self.C_wmin = f(C_wmin)
+        if C_wmax is None and c_wmax is not None:
+            self.C_wmax = np.tile(f(c_wmax), Hp + 1)
+        elif C_wmax is not None:
+            self.C_wmax = f(C_wmax)
         old_ib, old_zmin, old_zmax = self.i_b.copy(), self.Zmin.copy(), self.Zmax.copy()
         self._rebuild_constraints()
         if self.solved_once:
@@ -453,6 +511,9 @@ class LinMPCOracle:
             r += Cu @ self.L_Hp @ Cu
         self.F, self.qt, self.r = F, 2.0 * q, r
         self.xhat0 = np.asarray(xhat0, float)
+        self.ry, self.Rhaty = ry, Rhaty
+        # ŷ(k) = evaloutput(estim, d) -- src/controller/execute.jl:304 (initpred_common!)
+        self.yhat = self.Ch @ self.xhat0 + self.yop + (self.Dhd @ self.d0 if self.nd > 0 else 0.0)
         return self.F, self.qt, self.r
 
     def linconstraint(self):
@@ -461,10 +522,20 @@ class LinMPCOracle:
         if self.nd > 0:
             fx = fx + self.gx @ self.d0 + self.jx @ self.D0
         self.fx = fx
+        # F_w -- linconstraint_custom!, src/controller/execute.jl:337-364 (engineering values)
+        Fw = np.zeros(self.nW)
+        if self.nw > 0:
+            Fw += self.Wbu @ np.concatenate([self.Tu_lastu0 + self.Uop, self.lastu0 + self.uop])
+            if self.nd > 0:
+                Fw += self.Wbd @ np.concatenate([self.d0 + self.dop, self.D0 + self.Dop])
+            Fw += self.Wbr @ np.concatenate([self.ry, self.Rhaty])
+            Fw += self.Wby @ np.concatenate([self.yhat, self.F + self.Yop])
+        self.Fw = Fw
         self.b = np.concatenate([
             -self.U0min + self.Tu_lastu0, self.U0max - self.Tu_lastu0,
             -self.DUmin, self.DUmax,
             -self.Y0min + self.F, self.Y0max - self.F,
+            -self.Wmin + Fw, self.Wmax - Fw,
             -self.x0min + fx, self.x0max - fx])
         return self.b
 
@@ -513,4 +584,5 @@ class LinMPCOracle:
         J = 0.5 * self.Zt @ self.Ht @ self.Zt + self.qt @ self.Zt + self.r
         return {"ΔU": self.Zt[:self.nDU].copy(), "ϵ": self.Zt[-1] if self.neps else 0.0,
                 "Ŷ": Y0 + self.Yop, "U": U0 + self.Uop, "x̂end": xend + self.xhop, "J": J,
+                "W": self.Ewt @ self.Zt + self.Fw,                     # execute.jl:221
                 "u": self.lastu0 + self.uop}

@@ -98,3 +98,82 @@ def run_lqr_terminal_cost(lib=None, B=3, steps=20):
         X_lqr[:, i] = x
         x = A @ x + Bu @ (-K @ x)
     return X_mpc, X_lqr
+
+
+def custom_constraint_cases():
+    """T9 (test/3_test_predictive_control.jl:466-495): custom linear constraints on
+    model2 = LinModel([tf(2,[10,1]) tf(0.1,[7,1])], 3.0, i_d=[2]), uop=25, dop=30, yop=50, default
+    SteadyKalmanFilter, LinMPC(Nwt=[0], Cwt=Inf, Hp=50, Hc=50, W..).  Returns the estimator and the
+    list of (keywords W.., wmin, wmax, [(ry, which info, expected value), ...])."""
+    from oracle import estim as es
+    (a1, b1, c1), (a2, b2, c2) = ([float(np.squeeze(v)) for v in es.tf1_zoh(g, tau, 3.0)]
+                                  for g, tau in ((2.0, 10.0), (0.1, 7.0)))
+    model = es.LinModelOracle(np.diag([a1, a2]), [[b1], [0.0]], [[c1, c2]], [[0.0], [b2]], [[0.0]], Ts=3.0)
+    model.setop(uop=[25], yop=[50], dop=[30])
+    kf = es.SteadyKalmanFilterOracle(model)
+    cases = [
+        (dict(Wy=[[1.0]]), [36.0], [75.0], [(0.0, "Ŷ", 36.0), (100.0, "Ŷ", 75.0)]),
+        (dict(Wu=[[1.0]]), [4.0], [20.0], [(0.0, "U", 4.0), (100.0, "U", 20.0)]),
+        (dict(Wd=[[1.0]], Wy=[[1.0]]), [56.0], [95.0], [(0.0, "Ŷ", 56.0 - 30.0), (100.0, "Ŷ", 95.0 - 30.0)]),
+        (dict(Wr=[[1.0]], Wy=[[1.0]]), [52.0], [175.0], [(21.0, "Ŷ", 52.0 - 21.0), (100.0, "Ŷ", 175.0 - 100.0)]),
+    ]
+    return model, kf, cases
+
+
+def run_custom_constraint_cases(lib=None, B=2):
+    """T9 through the C-ABI against the reference's expected values and the oracle."""
+    model, kf, cases = custom_constraint_cases()
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    worst = 0.0
+    for kwW, wmin, wmax, checks in cases:
+        kw = dict(Hp=50, Hc=50, Nwt=[0], Cwt=np.inf, uop=model.uop, yop=model.yop, dop=model.dop,
+                  xhop=kf.xhop, fhop=kf.fhop)
+        orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw, **kwW)
+        orc.setconstraint(wmin=wmin, wmax=wmax)
+        gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd), rep(kf.Dhd), lib=lib, **kw, **kwW)
+        gpu.setconstraint(wmin=wmin, wmax=wmax)
+        x0 = np.zeros(kf.nxh)
+        gpu.initstate([25.0]); orc.lastu0 = np.zeros(1)
+        for ry, key, want in checks:
+            ug = gpu.moveinput(np.tile(x0, (B, 1)), [ry], [30.0], want_info=True)
+            uo = orc.moveinput(x0, [ry], [30.0])
+            assert np.all(gpu.status == 0)
+            ig, io = gpu.getinfo(), orc.getinfo()
+            assert np.all(np.abs(ig[key][B - 1] - want) < 1e-1), (kwW, ry)
+            worst = max(worst, np.abs(gpu.Z[B - 1] - orc.Zt).max() / max(1.0, np.abs(orc.Zt).max()),
+                        np.abs(ig["W"][B - 1] - io["W"]).max() / max(1.0, np.abs(io["W"]).max()))
+    return worst
+
+
+def run_soft_custom_constraints(lib=None, B=2, seed=4):
+    """Two soft custom rows mixing outputs, inputs, a measured disturbance and the set point, on top
+    of ordinary u / y constraints, against the oracle (exercises the ϵ row of the custom block)."""
+    from oracle import estim as es
+    rng = np.random.default_rng(seed)
+    A = np.diag([0.85, 0.6, 0.3]); Bu = rng.standard_normal((3, 2)); C = rng.standard_normal((2, 3))
+    Bd = rng.standard_normal((3, 1)); Dd = rng.standard_normal((2, 1))
+    model = es.LinModelOracle(A, Bu, C, Bd, Dd).setop(uop=[0.5, -0.2], yop=[2.0, 1.0], dop=[0.3])
+    kf = es.SteadyKalmanFilterOracle(model)
+    Wy, Wu = rng.standard_normal((2, 2)), rng.standard_normal((2, 2))
+    Wd, Wr = rng.standard_normal((2, 1)), 0.3 * rng.standard_normal((2, 2))
+    kw = dict(Hp=8, Hc=[1, 2, 2], Lwt=[0.05, 0.02], uop=model.uop, yop=model.yop, dop=model.dop,
+              xhop=kf.xhop, fhop=kf.fhop, Wy=Wy, Wu=Wu, Wd=Wd, Wr=Wr)
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
+    gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd), rep(kf.Dhd), lib=lib, **kw)
+    con = dict(umin=[-0.6, -1.0], umax=[1.4, 0.9], ymax=[2.6, 1.8], wmin=[0.2, -np.inf], wmax=[1.5, 0.9],
+               c_wmin=[0.7, 1.0], c_wmax=[1.3, 0.4])
+    orc.setconstraint(**con); gpu.setconstraint(**con)
+    x0 = 0.3 * rng.standard_normal(kf.nxh)
+    gpu.initstate([0.6, 0.0]); orc.lastu0 = np.array([0.6, 0.0]) - model.uop
+    worst = 0.0
+    for k in range(3):
+        ry, d = [2.5 + 0.2 * k, 0.4], [0.5 - 0.1 * k]
+        ug = gpu.moveinput(np.tile(x0, (B, 1)), ry, d, want_info=True)
+        uo = orc.moveinput(x0, ry, d)
+        assert np.all(gpu.status == 0)
+        ig, io = gpu.getinfo(), orc.getinfo()
+        worst = max(worst, np.abs(gpu.Z[B - 1] - orc.Zt).max() / max(1.0, np.abs(orc.Zt).max()),
+                    np.abs(ug[B - 1] - uo).max(), np.abs(ig["W"][B - 1] - io["W"]).max())
+        x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop) * 0.5
+    return worst

@@ -81,6 +81,14 @@ def test_T6_terminal_cost_is_lqr_on_cpu_emulator(emulib):
         mpcqp.BatchLinMPC(rep(A), rep(Bu), rep(C), Hp=3, Hc=3, M_Hp=bad, lib=emulib)
 
 
+def test_custom_linear_constraints_on_cpu_emulator(emulib):
+    """mpcqp_set_custom_constraints / _bounds through the kernel bodies: the reference's four
+    known answers (test/3_test_predictive_control.jl:466-495) and a soft, mixed case vs the oracle."""
+    from tests.parity_util import run_custom_constraint_cases, run_soft_custom_constraints
+    assert run_soft_custom_constraints(lib=emulib) <= 1e-6
+    assert run_custom_constraint_cases(lib=emulib) <= 1e-5
+
+
 def test_maximum_size_nZ_64_on_cpu_emulator(emulib):
     """nZ~ = 64: every lane owns a row of the factor (index arithmetic of the packed layout, the
     chunked sweeps and the row store at their limits)."""

@@ -349,3 +349,12 @@ def test_maximum_size_nZ_64_on_gpu(hiplib):
     err = rel_err(got["Z"], ref["Z"], cfg.nu * cfg.Hc)
     assert ref["certified"].sum() >= B // 2
     assert err[ref["certified"]].max() <= TOL
+
+
+def test_custom_linear_constraints_on_gpu(hiplib):
+    """Wy / Wu / Wd / Wr custom linear constraints (mpcqp_set_custom_constraints,
+    mpcqp_set_custom_bounds): the reference's four known answers
+    (test/3_test_predictive_control.jl:466-495) and a soft, mixed case against the oracle."""
+    from tests.parity_util import run_custom_constraint_cases, run_soft_custom_constraints
+    assert run_soft_custom_constraints(B=33) <= 1e-6
+    assert run_custom_constraint_cases(B=5) <= TOL

@@ -178,3 +178,24 @@ def test_qp_certificate_and_bound():
                    constraints=[{"type": "ineq", "fun": lambda x: h - G @ x, "jac": lambda x: -G}],
                    method="SLSQP", options={"ftol": 1e-14, "maxiter": 500})
     assert np.abs(res.x - z).max() < 1e-6
+
+
+def test_T9_custom_linear_constraints():
+    # :466-495  Wy / Wu / Wd / Wr rows drive the whole horizon onto the custom bound (atol 1e-1 there)
+    from tests.parity_util import custom_constraint_cases
+    model, kf, cases = custom_constraint_cases()
+    for kwW, wmin, wmax, checks in cases:
+        mpc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, Hp=50, Hc=50, Nwt=[0], Cwt=np.inf,
+                              uop=model.uop, yop=model.yop, dop=model.dop, xhop=kf.xhop, fhop=kf.fhop, **kwW)
+        mpc.setconstraint(wmin=wmin, wmax=wmax)
+        assert mpc.Wby.shape == (51, 51) and mpc.nW == 51             # repeatdiag(W, Hp+1), :55
+        x0 = np.zeros(kf.nxh)                                         # preparestate!(mpc, [50], [30])
+        for ry, key, want in checks:
+            mpc.moveinput(x0, [ry], [30.0], lastu=[25.0])
+            info = mpc.getinfo()
+            assert np.all(np.abs(info[key] - want) < 1e-1), (kwW, ry, info[key][:5])
+            assert np.all(info["W"] >= wmin[0] - 1e-6) and np.all(info["W"] <= wmax[0] + 1e-6)
+    with pytest.raises(ValueError):
+        mpc.setconstraint(wmin=[0, 0, 0])                            # DimensionMismatch, :358
+    with pytest.raises(ValueError):
+        cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, Hp=5, Wy=np.ones((2, 2)))   # :85
