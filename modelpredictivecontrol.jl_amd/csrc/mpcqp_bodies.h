@@ -280,8 +280,9 @@ struct Qp {
     // out[k] += scale * sum_r E[r,k] wv[r]   (k < nDU).  The t loop is wave-uniform (lanes of
     // later block columns just start contributing later), so wv[t,a] is a broadcast LDS read and
     // there is no divergent branch in the loop.
-    MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0) {
+    MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0, int t_hi = -1) {
         const int ny = d.ny, nu = d.nu;
+        if (t_hi < 0) t_hi = d.Hp;          // only the steps t < t_hi contribute
         if constexpr (DM::is_static) {
             if (DM::ny == 4 && DM::nu == 4 && DM::nDU <= WAVE && d.default_nb) {
                 // lane (j, a) reads whole rows S_{t-j}[a][0..3] (two 16-byte loads instead of four
@@ -292,7 +293,7 @@ struct Qp {
                 const int zoff = c.zero - c.S;
                 double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
                 MPCQP_UNROLL4
-                for (int t = 0; t < DM::Hp; ++t) {
+                for (int t = 0; t < t_hi; ++t) {
                     const bool ok = t >= j && w.lane < DM::nDU;
                     const double* Sb = S + (ok ? (t - j) * sp + a * 4 : zoff);     // zero slot before the block column starts
                     const double wt = wv[t * 4 + a];
@@ -309,7 +310,7 @@ struct Qp {
             const double* Sk = S + cc;
             double acc0 = 0.0, acc1 = 0.0;
             MPCQP_UNROLL4
-            for (int t = 0; t < d.Hp; ++t) {
+            for (int t = 0; t < t_hi; ++t) {
                 const bool ok = t >= t0;
                 const double* Sb = Sk + (ok ? t - t0 : 0) * sp;
                 const double* wt = wv + t * ny;
@@ -339,7 +340,8 @@ struct Qp {
     // time; the 16-wide tiles run over the ΔU index; E is never formed -- operands come straight
     // from the block-Toeplitz table, and tiles whose block columns start after step t are skipped.
     typedef double v4d __attribute__((ext_vector_type(4)));
-    __device__ __forceinline__ void EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb) {
+    // returns the first step t whose rows the ϵ row (tb) has been accumulated for (-1: no ϵ row)
+    __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb) {
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp;
         constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
         const int li = w.lane & 15, lk = w.lane >> 4;
@@ -358,6 +360,7 @@ struct Qp {
         // then every further row on its own.  A pass starts at the first K step that reaches its
         // first block column (E is block lower triangular).
         constexpr int IE = NDU / 16, LE = NDU % 16;     // tile row / lane column of the ϵ row
+        int eps_t0 = -1;
         MPCQP_UNROLL
         for (int I0 = 0; I0 < NT; I0 += (I0 == 0 ? 2 : 1)) {
             constexpr int MAXT = NT + 1;
@@ -375,9 +378,12 @@ struct Qp {
             // its first column); the ϵ row needs every step.  The K loop is split at these points
             // so that its bodies are branch-free (accumulators stay in place across iterations).
             auto kfirst = [&](int I) {
-                if (erow && I == IE) return 0;
-                const int v = (jl((16 * I) / NU) * NY) / 4;           // first kk with (4kk+3)/NY >= j_l
-                return v < NK ? v : NK;
+                int v = (jl((16 * I) / NU) * NY) / 4;                 // first kk with (4kk+3)/NY >= j_l
+                v = v < NK ? v : NK;
+                // the ϵ row rides from its tile row's own start when that is a whole number of
+                // steps (the few steps before are left to the caller, Et_apply_add), else from 0
+                if (erow && I == IE) { if ((4 * v) % NY != 0) v = 0; eps_t0 = (4 * v) / NY; }
+                return v;
             };
             const int kB = (I1 > I0) ? kfirst(I1) : NK;               // second row of the pass joins here
             const int kA = kfirst(I0) < kB ? kfirst(I0) : kB;          // (an earlier start only adds zeros)
@@ -436,18 +442,16 @@ struct Qp {
                 }
             }
         }
+        return eps_t0;
     }
 #endif
 
     // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU).  When `tb` is given
-    // and the matrix-core path runs, the ϵ row P[pk(nDU, i')] += sum_r tb[r] E[r,i'] is added too
-    // and true is returned; otherwise the caller adds it (Et_apply_add).
-    MPCQP_HD bool EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr) {
+    // and the matrix-core path runs, the ϵ row P[pk(nDU, i')] += sum_r tb[r] E[r,i'] is added for the
+    // rows of the steps t >= the returned value; the caller adds the rest (Et_apply_add; -1: all of it).
+    MPCQP_HD int EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (DM::is_static) {
-            EtDE_add_mfma(dd, P, scale, tb);
-            return tb != nullptr && DM::neps;
-        }
+        if constexpr (DM::is_static) return EtDE_add_mfma(dd, P, scale, tb);
 #endif
         const int ny = d.ny, nu = d.nu, nDU = d.nDU;
         const int ntri = nDU * (nDU + 1) / 2;
@@ -465,7 +469,7 @@ struct Qp {
             }
             P[pk(i, ip)] += scale * acc;
         }
-        return false;
+        return -1;
     }
 
     // P[pk(i,i')] += scale * sum_t E_t[:,i]' M_t E_t[:,i']  for a block-diagonal weight
@@ -1175,10 +1179,10 @@ struct Step {
         }
         MPCQP_TOC(3);
         // dense E' dY E (+ the ϵ row of the Ŷ rows on the matrix-core path)
-        bool eps_y_done = false;
+        int eps_t0 = -1;          // first step whose Ŷ rows the matrix-core path put into the ϵ row
         if (qp.pair_on(P_Y)) {
             MPCQP_TIC();
-            eps_y_done = qp.EtDE_add(sm + c.tA[P_Y], Phi, 1.0, d.neps ? sm + c.tB[P_Y] : nullptr);
+            eps_t0 = qp.EtDE_add(sm + c.tA[P_Y], Phi, 1.0, d.neps ? sm + c.tB[P_Y] : nullptr);
             w.sync();      // the MFMA write-back uses its own entry->lane map
             MPCQP_TOC(4);
         }
@@ -1253,7 +1257,7 @@ struct Step {
                 }
                 st[k] = acc;
             }
-            if (epsY && !eps_y_done) qp.Et_apply_add(sm + c.tB[P_Y], st);   // same lane owns st[k]
+            if (epsY && eps_t0 != 0) qp.Et_apply_add(sm + c.tB[P_Y], st, 1.0, eps_t0);   // same lane owns st[k]
             for (int k = w.lane; k < nDU; k += WAVE) Phi[pk(nZ - 1, k)] += st[k];
         }
         w.sync();
