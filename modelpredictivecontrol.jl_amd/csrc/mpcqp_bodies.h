@@ -1598,23 +1598,18 @@ struct Step {
         // G'lam and one H̃ z per iteration.  A verification that fails simply continues from the
         // exact values.
         bool exact = true, verified = false;
+        double musum_c = 0.0, rpmax_c = 0.0, rdscale_c = 1.0;    // carried from the update pass
         while (it < d.max_iter) {
             if (exact) {
                 residuals(mu, rpn, rdn, ndd);      // also stages H̃ in Phi
                 exact = false;
                 verified = true;
             } else {
-                double musum = 0.0, rpmax = 0.0;
-                for_rows([&](int, int, Row& r) {
-                    if (!fin(r)) return;
-                    rpmax = fmax(rpmax, fabs(r.rp));
-                    musum += r.s * r.lam;
-                });
-                mu = w.sum(musum) / mact;
-                rpn = w.maxv(rpmax);
-                double mx = 0.0;
-                for (int k = w.lane; k < n; k += WAVE) mx = fmax(mx, fabs(rd[k]));
-                rdn = w.maxv(mx);
+                // sum s lam and max |r_p| were accumulated by the update pass of the previous
+                // iteration; max |r_d| scales with the dual residual itself
+                mu = w.sum(musum_c) / mact;
+                rpn = w.maxv(rpmax_c);
+                rdn *= rdscale_c;
                 verified = false;
             }
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
@@ -1678,11 +1673,14 @@ struct Step {
             pmin = w.minv(pmin);
             psum = w.sum(psum);
             const double alpha = (pmin * mact >= 0.01 * psum) ? ahi : fmin(1.0, 0.99 * amin);
+            musum_c = 0.0; rpmax_c = 0.0; rdscale_c = 1.0 - alpha;
             for_rows([&](int, int, Row& r) {
                 if (!fin(r)) return;
                 r.s += alpha * r.pp;
                 r.lam += alpha * r.gd;
                 r.rp = fma(alpha, delta * r.gd - r.rp, r.rp);
+                musum_c += r.s * r.lam;
+                rpmax_c = fmax(rpmax_c, fabs(r.rp));
             });
             for (int k = w.lane; k < n; k += WAVE) { z[k] += alpha * dz[k]; rd[k] *= (1.0 - alpha); }
             w.sync();
