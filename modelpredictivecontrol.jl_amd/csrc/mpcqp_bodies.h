@@ -1525,23 +1525,23 @@ struct Step {
         MPCQP_TOC(2);
     }
 
-    // Row part of one Newton step of the dual-regularised system (D~ = D w, w = 1/(1+δD)):
-    //   dl = w (D (rp + G dz) - rc/s),   ds = -(rc + s dl)/lam = -w ((rp + G dz) + δ rc/s)
-    // (the second form has no division by lam and no cancellation on inactive rows).  The rows
-    // satisfy  s dl + lam ds = -rc  and  rp + G dz + ds = δ dl.
+    // Row part of one Newton step of the dual-regularised system.  With D = lam/s, w = 1/(1+δD) and
+    // D~ = D w, everything a row needs is one reciprocal  wi = w/s = 1/(s + δ lam):
+    //   D~ = lam wi,   dl = w (D (rp + G dz) - rc/s) = wi (lam a - rc),   a = rp + G dz
+    //   ds = -(rc + s dl)/lam = -wi (s a + δ rc)            (no division by lam, no cancellation)
+    // The rows satisfy  s dl + lam ds = -rc  and  rp + G dz + ds = δ dl.
+    MPCQP_HD double row_wi(const Row& r) const { return rcp(fma(delta, r.lam, r.s)); }
     MPCQP_HD void row_step(const Row& r, double rc, double& ds, double& dl) const {
-        const double is = rcp(r.s), D = r.lam * is, ww = rcp(fma(delta, D, 1.0));
-        const double a = r.rp + r.gd, bb = rc * is;
-        dl = ww * fma(D, a, -bb);
-        ds = -ww * fma(delta, bb, a);
+        const double wi = row_wi(r), a = r.rp + r.gd;
+        dl = wi * fma(r.lam, a, -rc);
+        ds = -wi * fma(r.s, a, delta * rc);
     }
 
     // (H + G'D~G) dz = -rd + G'(w rc/s - D~ rp); then gd = G dz.  rc(Row&) given by functor.
     template <class Fn>
     MPCQP_HD void newton(Fn rc) {
         apply_Gt([&](Row& r) {
-            const double is = rcp(r.s), ww = rcp(1.0 + delta * r.lam * is);
-            return ww * is * (rc(r) - r.lam * r.rp);
+            return row_wi(r) * (rc(r) - r.lam * r.rp);
         });
         for (int k = w.lane; k < d.nZ; k += WAVE) gt[k] -= rd[k];
         w.sync();
@@ -1620,8 +1620,7 @@ struct Step {
             }
             if (!verified) load_H();
             add_GtDG([&](Row& r) {
-                const double D = r.lam * rcp(r.s);
-                return D * rcp(1.0 + delta * D);
+                return r.lam * row_wi(r);                   // D~ = D / (1 + δ D)
             });
             cholesky();
             // predictor: rc = s lam
