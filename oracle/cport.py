@@ -51,7 +51,7 @@ class RefBatch:
         self.h = lib().linmpc_ref_create(self.B, self.nxh, self.nu, self.ny, Hp, Hc, _p(nbv), neps,
                                          *[_p(a) for a in self._keep])
 
-    def step(self, xhat0, lastu0, ry, Z=None, cold=True, nthreads=0, gap_tol=1e-12, res_tol=1e-9,
+    def step(self, xhat0, lastu0, ry, Z=None, cold=True, nthreads=0, gap_tol=1e-12, res_tol=1e-11,
              delta=1e-12, max_iter=100):
         B = self.B
         x, lu, r = (np.ascontiguousarray(a, dtype=np.float64) for a in (xhat0, lastu0, ry))

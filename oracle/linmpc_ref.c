@@ -308,7 +308,10 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                 {
                     it = pass;
                     if (!(mu == mu)) { st = 2; break; }
-                    if (mu <= gap_tol && rdn <= res_tol * ndd && rpn <= res_tol * nh) { st = 0; break; }
+                    /* converged: gap, residuals, and strict complementarity resolved on every row */
+                    double sc = 0;
+                    for (int i = 0; i < m; ++i) { double v = fmin(s[i], lam[i]); if (v > sc) sc = v; }
+                    if (mu <= gap_tol && rdn <= res_tol * ndd && rpn <= 100.0 * res_tol * nh && (sc <= 1e-7 || mu <= 1e-16)) { st = 0; break; }
                 }
                 /* Phi = H + G' D~ G */
                 for (int i = 0; i < m; ++i) {
