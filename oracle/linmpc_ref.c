@@ -268,6 +268,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                 zs[k] = z[k] = v;
             }
             int st = 1, it = 0;
+            double laststep = 1e300;     /* alpha |dU|_inf / max(1, |dU|_inf) of the previous iteration */
             double nh = 1.0, rpn = 0;
             for (int i = 0; i < m; ++i) {       /* starting point: s = max(h - G z, 1), lam = 10 / s */
                 double a = 0;
@@ -308,10 +309,8 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                 {
                     it = pass;
                     if (!(mu == mu)) { st = 2; break; }
-                    /* converged: gap, residuals, and strict complementarity resolved on every row */
-                    double sc = 0;
-                    for (int i = 0; i < m; ++i) { double v = fmin(s[i], lam[i]); if (v > sc) sc = v; }
-                    if (mu <= gap_tol && rdn <= res_tol * ndd && rpn <= 100.0 * res_tol * nh && (sc <= 1e-7 || mu <= 1e-16)) { st = 0; break; }
+                    /* converged: gap, residuals, and a last Newton step that no longer moves the inputs */
+                    if (mu <= gap_tol && rdn <= res_tol * ndd && rpn <= 100.0 * res_tol * nh && laststep <= 1e-6) { st = 0; break; }
                 }
                 /* Phi = H + G' D~ G */
                 for (int i = 0; i < m; ++i) {
@@ -376,6 +375,11 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                         }
                         if (!(pmin * m >= 0.01 * psum)) alpha = fmin(1.0, 0.99 * amin);
                         for (int i = 0; i < m; ++i) { s[i] += alpha * dsv[i]; lam[i] += alpha * dlv[i]; }
+                        {
+                            double zm = 1.0, dm = 0.0;
+                            for (int k = 0; k < nDU; ++k) { zm = fmax(zm, fabs(z[k])); dm = fmax(dm, fabs(alpha * dz[k])); }
+                            laststep = dm / zm;
+                        }
                         for (int k = 0; k < nZ; ++k) z[k] += alpha * dz[k];
                     }
                 }
