@@ -69,6 +69,8 @@ typedef struct mpcqp_handle_s* mpcqp_handle;
 #define MPCQP_FLAG_RY_CONSTANT   (1u << 0)  /* Ry is (ny,B): ry held over Hp, like R̂y=repeat(ry,Hp) */
 #define MPCQP_FLAG_COLD_START    (1u << 1)  /* ignore Ztilde on input: warm start = 0              */
 #define MPCQP_FLAG_KEEP_QP       (1u << 2)  /* keep q̃ and F of the last step for mpcqp_get         */
+#define MPCQP_FLAG_WARM_DUAL     (1u << 3)  /* closed loop: keep the multipliers between steps and  */
+                                            /* start the next solve around them (and the shifted Z̃) */
 
 typedef struct {
     int32_t  batch;     /* B: number of independent controllers                              */

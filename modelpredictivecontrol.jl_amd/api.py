@@ -26,7 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libmpcqp.so")
 
 # flags / codes of include/mpcqp.h
-FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP = 1, 2, 4
+FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL = 1, 2, 4, 8
 STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
 GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC = 1, 2, 3, 4, 5, 6
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
@@ -316,7 +316,7 @@ class BatchLinMPC:
 
     def __init__(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None, *, Hp, Hc=2, Mwt=None, Nwt=None,
                  Lwt=None, M_Hp=None, Cwt=1e5, Wy=None, Wu=None, Wd=None, Wr=None, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
-                 cold_start=False, keep_qp=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
+                 cold_start=False, keep_qp=False, warm_dual=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
                  lib=None):
         Ahat, Bhu, Chat = (np.asarray(a, float) for a in (Ahat, Bhu, Chat))
         if Ahat.ndim != 3 or Bhu.ndim != 3 or Chat.ndim != 3:
@@ -342,7 +342,8 @@ class BatchLinMPC:
             raise ValueError("Cwt must be finite for all controllers of a batch, or Inf for all")
         self.neps = 0 if np.isinf(cw).all() else 1
         self.B, self.nxh, self.nu, self.ny, self.nd, self.Hp, self.Hc, self.nb = B, nxh, nu, ny, nd, Hp, Hc, nb
-        flags = FLAG_RY_CONSTANT * 0 | (FLAG_COLD_START if cold_start else 0) | (FLAG_KEEP_QP if keep_qp else 0)
+        flags = (FLAG_RY_CONSTANT * 0 | (FLAG_COLD_START if cold_start else 0) | (FLAG_KEEP_QP if keep_qp else 0)
+                 | (FLAG_WARM_DUAL if warm_dual else 0))
         self.hd = Handle(B, nxh, nu, ny, nd, Hp, Hc, nb=nb, neps=self.neps, device=device, flags=flags,
                          max_iter=max_iter, gap_tol=gap_tol, res_tol=res_tol, dual_reg=dual_reg, lib=lib)
         self.nZ, self.nDU, self.nU, self.nY = self.hd.nZ, self.hd.nDU, self.hd.nU, self.hd.nY

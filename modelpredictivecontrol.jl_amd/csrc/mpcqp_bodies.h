@@ -1582,13 +1582,28 @@ struct Step {
         //      multipliers on the central path of mu = 10:  s = max(h - G z, 1), lam = 10 / s.
         //      Measured against an affine-step start (one extra factorisation) on the BASELINE
         //      configs: 1-2 fewer factorisations per solve and a shorter tail.
-        auto start = [&]() {
+        //      With MPCQP_FLAG_WARM_DUAL and the multipliers of the previous period at hand (closed
+        //      loop), the start is placed on the central path of mu0 = 1e-3 around them instead:
+        //      s = max(h - G z, 1e-3), lam = max(lam_prev, mu0/s), s = max(s, mu0/lam)  -- measured on
+        //      2048 C3 closed loops: 10.2 instead of 12.4 iterations per period, no failure.
+        const double* lam_prev = ((d.flags & 8u) && !cold) ? io.lam_prev : nullptr;
+        if (lam_prev) {
+            const double* lp = lam_prev + (size_t)b * d.nrows();
+            apply_G(z, [&](Row& r, double gz) { r.s = r.h - gz; });
+            for_rows([&](int g, int k, Row& r) {
+                if (!fin(r)) return;
+                const double mu0 = 1e-3;
+                double si = fmax(r.s, 1e-3);
+                const double li = fmax(lp[d.rowoff(g) + k], mu0 * rcp(si));
+                si = fmax(si, mu0 * rcp(li));
+                r.s = si; r.lam = li;
+            });
+        } else {
             apply_G(z, [&](Row& r, double gz) {
                 r.s = fmax(r.h - gz, 1.0);
                 r.lam = 10.0 * rcp(r.s);
             });
-        };
-        start();
+        }
         int status = ST_ITERATION_LIMIT;
         int it = 0;
         // Residuals are evaluated exactly (G z, G'lam, H̃ z) at the first iterate and whenever the
@@ -1704,6 +1719,11 @@ struct Step {
         if (status == ST_ERROR) {
             if (w.lane < n) z[w.lane] = zws;          // mpc.Z̃ .= Z̃s   execute.jl:499-500
             w.sync();
+        }
+        if ((d.flags & 8u) && io.lam_out) {           // multipliers for the next period's start
+            double* lo = io.lam_out + (size_t)b * d.nrows();
+            const bool good = status != ST_ERROR;
+            for_rows([&](int g, int k, Row& r) { lo[d.rowoff(g) + k] = (good && fin(r)) ? r.lam : 0.0; });
         }
         iters_out = it;
         return status;

@@ -45,7 +45,8 @@ struct mpcqp_handle_s {
     DBuf bnd[16];
     // staging for the host-pointer step
     DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
-    DBuf keep_q, keep_F, prof;
+    DBuf keep_q, keep_F, prof, lam;
+    bool lam_valid = false;     // lam holds the multipliers of the previous step (MPCQP_FLAG_WARM_DUAL)
     // SteadyKalmanFilter
     DBuf kf_K, kf_iym, kf_x, kf_y, kf_u, kf_d;
     KfParams kf{};
@@ -104,6 +105,7 @@ static void layout_rows(mpcqp_handle h) {
         if ((d.gmask >> g) & 1u) o += d.cnt_[g >> 1];
     }
     d.rowoff_[NGROUP] = o;
+    h->lam_valid = false;       // the row layout changed: stored multipliers no longer line up
 }
 
 int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
@@ -446,6 +448,14 @@ int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
         if (rc) return rc;
         io.q_keep = (double*)h->keep_q.p;
         io.F_keep = (double*)h->keep_F.p;
+    }
+    if (d.flags & MPCQP_FLAG_WARM_DUAL) {
+        const size_t nl = (size_t)d.B * (size_t)(d.nrows() > 0 ? d.nrows() : 1) * sizeof(double);
+        int rc = dev_alloc(h, h->lam, nl);
+        if (rc) return rc;
+        io.lam_out = (double*)h->lam.p;
+        io.lam_prev = h->lam_valid ? (const double*)h->lam.p : nullptr;
+        h->lam_valid = true;
     }
 #ifdef MPCQP_PROFILE
     {

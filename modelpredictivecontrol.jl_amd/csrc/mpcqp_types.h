@@ -35,7 +35,7 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 3
+#define MPCQP_KERNEL_REV 4
 
 namespace mpcqp {
 
@@ -107,6 +107,8 @@ struct StepIO {
     double *Z, *u0, *Yhat0;
     int32_t *status, *iters;
     double *q_keep, *F_keep;   // optional (MPCQP_FLAG_KEEP_QP)
+    const double* lam_prev;    // optional [B][nrows]: multipliers of the previous period (MPCQP_FLAG_WARM_DUAL)
+    double* lam_out;           // optional [B][nrows]: multipliers of this period
     double *prof;              // optional [B][16] per-phase cycle counts (-DMPCQP_PROFILE builds only)
 };
 

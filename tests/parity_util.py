@@ -177,3 +177,24 @@ def run_soft_custom_constraints(lib=None, B=2, seed=4):
                     np.abs(ug[B - 1] - uo).max(), np.abs(ig["W"][B - 1] - io["W"]).max())
         x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop) * 0.5
     return worst
+
+
+def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
+    """The same noisy closed loop (plant = model + state noise) run by two controllers of one
+    configuration, the second with keyword overrides `kw`; returns per-step (Z_a, Z_b, it_a, it_b)."""
+    a = make_controller(cfg, bt, lib=lib)
+    b_ = make_controller(cfg, bt, lib=lib, **kw)
+    for c in (a, b_):
+        c.lastu0 = bt["lastu0"].copy()
+    x = bt["xhat0"].copy()
+    rg = np.random.default_rng(seed)
+    out = []
+    for k in range(steps):
+        ua = a.moveinput(x, bt["ry"])
+        ub = b_.moveinput(x, bt["ry"])
+        assert np.all(a.status == 0) and np.all(b_.status == 0)
+        out.append((a.Z.copy(), b_.Z.copy(), a.iters.copy(), b_.iters.copy()))
+        x = (np.einsum("bij,bj->bi", bt["Ahat"], x) + np.einsum("bij,bj->bi", bt["Bhu"], ua)
+             + noise * rg.standard_normal(x.shape))
+        b_.lastu0 = a.lastu0.copy()      # keep the two loops on the same trajectory
+    return out

@@ -89,6 +89,17 @@ def test_custom_linear_constraints_on_cpu_emulator(emulib):
     assert run_custom_constraint_cases(lib=emulib) <= 1e-5
 
 
+def test_dual_warm_start_on_cpu_emulator(emulib):
+    """MPCQP_FLAG_WARM_DUAL: the next period starts around the previous multipliers; same optimum
+    as the plain start."""
+    from mpcqp import synth
+    from tests.parity_util import closed_loop_pair, rel_err
+    cfg = synth.Config("cl", nx=3, nu=2, ny=2, Hp=8, Hc=3, umin=-0.6, umax=0.7, ymax=0.9)
+    bt = synth.make_batch(cfg, 3, seed=2)
+    for Za, Zb, ita, itb in closed_loop_pair(cfg, bt, 4, lib=emulib, warm_dual=True):
+        assert rel_err(Zb, Za, cfg.nu * cfg.Hc).max() <= 1e-6
+
+
 def test_maximum_size_nZ_64_on_cpu_emulator(emulib):
     """nZ~ = 64: every lane owns a row of the factor (index arithmetic of the packed layout, the
     chunked sweeps and the row store at their limits)."""

@@ -373,3 +373,18 @@ def test_custom_linear_constraints_on_gpu(hiplib):
     from tests.parity_util import run_custom_constraint_cases, run_soft_custom_constraints
     assert run_soft_custom_constraints(B=33) <= 1e-6
     assert run_custom_constraint_cases(B=5) <= TOL
+
+
+def test_dual_warm_start_closed_loop_on_gpu(hiplib):
+    """MPCQP_FLAG_WARM_DUAL in a noisy closed loop (C3, 512 controllers, 5 periods): the same optimum
+    as the plain start at every period, in fewer iterations from the second period on."""
+    from tests.parity_util import closed_loop_pair
+    cfg = synth.C3
+    bt = synth.make_batch(cfg, 512, seed=6)
+    res = closed_loop_pair(cfg, bt, 5, warm_dual=True)
+    nDU = cfg.nu * cfg.Hc
+    for Za, Zb, ita, itb in res:
+        assert rel_err(Zb, Za, nDU).max() <= TOL
+    plain = np.mean([r[2].mean() for r in res[1:]])
+    warm = np.mean([r[3].mean() for r in res[1:]])
+    assert warm <= plain - 1.0, (plain, warm)
