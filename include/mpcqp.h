@@ -82,7 +82,7 @@ typedef struct {
     int32_t  neps;      /* 1 iff Cwt is finite (slack variable ϵ present, construct.jl:903)   */
     int32_t  device;    /* HIP device ordinal                                                 */
     uint32_t flags;     /* MPCQP_FLAG_*                                                       */
-    int32_t  max_iter;  /* interior-point iteration cap, 0 = default (100)                     */
+    int32_t  max_iter;  /* interior-point iteration cap, 0 = default (80)                      */
     double   gap_tol;   /* absolute mean complementarity target, 0 = default (1e-12)          */
     double   res_tol;   /* relative primal/dual residual target, 0 = default (1e-11)          */
     double   dual_reg;  /* dual proximal regularisation δ, 0 = default (1e-12)                */

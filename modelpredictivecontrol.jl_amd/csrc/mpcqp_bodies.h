@@ -1584,14 +1584,16 @@ struct Step {
         //      configs: 1-2 fewer factorisations per solve and a shorter tail.
         //      With MPCQP_FLAG_WARM_DUAL and the multipliers of the previous period at hand (closed
         //      loop), the start is placed on the central path of mu0 = 1e-3 around them instead:
-        //      s = max(h - G z, 1e-3), lam = max(lam_prev, mu0/s), s = max(s, mu0/lam)  -- measured on
-        //      2048 C3 closed loops: 10.2 instead of 12.4 iterations per period, no failure.
         const double* lam_prev = ((d.flags & 8u) && !cold) ? io.lam_prev : nullptr;
         if (lam_prev) {
             const double* lp = lam_prev + (size_t)b * d.nrows();
             apply_G(z, [&](Row& r, double gz) { r.s = r.h - gz; });
             for_rows([&](int g, int k, Row& r) {
                 if (!fin(r)) return;
+                // s = max(h - G z, 1e-3), lam = max(lam_prev, mu0/s), s = max(s, mu0/lam), mu0 = 1e-3.
+                // (Measured on C3 closed loops: -2.3 iterations per period once the loop has settled,
+                // +4 in the period after a large estimate correction; clamping the multipliers to a
+                // band around the central path made the tail worse.)
                 const double mu0 = 1e-3;
                 double si = fmax(r.s, 1e-3);
                 const double li = fmax(lp[d.rowoff(g) + k], mu0 * rcp(si));

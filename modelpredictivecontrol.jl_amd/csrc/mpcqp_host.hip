@@ -143,7 +143,7 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     d.nw = 0; d.nW = 0;
     d.npk = pk_size(nZ);
     d.flags = in->flags;
-    d.max_iter = in->max_iter > 0 ? in->max_iter : 100;
+    d.max_iter = in->max_iter > 0 ? in->max_iter : 80;
     d.gap_tol = in->gap_tol > 0 ? in->gap_tol : 1e-12;
     d.res_tol = in->res_tol > 0 ? in->res_tol : 1e-11;
     d.dual_reg = in->dual_reg > 0 ? in->dual_reg : 1e-12;

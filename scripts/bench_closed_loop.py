@@ -13,9 +13,11 @@ from mpcqp import synth
 cfg = synth.C3
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+WARM_DUAL = (sys.argv[3] != "0") if len(sys.argv) > 3 else True      # MPCQP_FLAG_WARM_DUAL
 bt = synth.make_batch(cfg, B, seed=0)
 nxh, nu, ny, Hp, Hc = cfg.nxh, cfg.nu, cfg.ny, cfg.Hp, cfg.Hc
-hd = mpcqp.Handle(B, nxh, nu, ny, 0, Hp, Hc, neps=1, flags=mpcqp.FLAG_RY_CONSTANT)   # warm start on
+hd = mpcqp.Handle(B, nxh, nu, ny, 0, Hp, Hc, neps=1,
+                  flags=mpcqp.FLAG_RY_CONSTANT | (mpcqp.FLAG_WARM_DUAL if WARM_DUAL else 0))   # warm start on
 hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
 hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt))
 hd.set_bounds(U0min=np.full((B, hd.nU), cfg.umin), U0max=np.full((B, hd.nU), cfg.umax), Y0max=np.full((B, hd.nY), cfg.ymax))
@@ -56,9 +58,11 @@ for k in range(N):
     torch.cuda.synchronize()
     t_kf += ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3]); t_step += ev[1].elapsed_time(ev[2])
     iters.append(float(it.double().mean()))
+    if len(sys.argv) > 4:
+        print(f"period {k}: mean {iters[-1]:.2f} max {int(it.max())} not-optimal {int((st != 0).sum())} iters>40 {int((it > 40).sum())} step {ev[1].elapsed_time(ev[2]):.2f} ms", file=sys.stderr)
 torch.cuda.synchronize(); wall = time.perf_counter() - t0
 kf_bytes = 8 * B * (nxh * nxh + nxh * nu + ny * nxh + nxh * ny + 4 * nxh + ny + nu)   # both kernels, per period
-out = {"workload": cfg.name, "batch": B, "periods": N, "periods_per_s": N / wall, "controller_steps_per_s": B * N / wall,
+out = {"workload": cfg.name, "batch": B, "periods": N, "warm_dual": WARM_DUAL, "periods_per_s": N / wall, "controller_steps_per_s": B * N / wall,
        "ms_per_period": {"kalman_correct+predict": t_kf / N, "moveinput": t_step / N, "wall": wall / N * 1e3},
        "ipm_iters_first_last": [iters[0], iters[-1]], "all_optimal_last": bool((st == 0).all()),
        "kalman_roofline": {"bound": "hbm", "achieved": kf_bytes / (t_kf / N * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
