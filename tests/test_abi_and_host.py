@@ -170,6 +170,26 @@ def test_host_argument_validation(emulib):
         mpc.setconstraint(c_umax=[0.1])                  # construct.jl:443
     with pytest.raises(RuntimeError, match="Inf"):
         mpc.setconstraint(umax=[np.inf])                 # construct.jl:549-551
+    # custom linear constraints and block weights: argument checks of the mirror and of the ABI
+    with pytest.raises(ValueError, match="columns"):
+        mk(Wy=np.ones((2, 3)))                           # DimensionMismatch, construct.jl:686
+    with pytest.raises(ValueError, match="same number of rows"):
+        mk(Wy=np.ones((2, 1)), Wu=np.ones((3, 1)))       # construct.jl:690
+    mpc = mk(Wy=np.ones((2, 1)))
+    with pytest.raises(ValueError, match="size must be"):
+        mpc.setconstraint(wmin=[0.0, 0.0, 0.0])          # test/3...:358
+    with pytest.raises(ValueError, match="non-negative"):
+        mpc.setconstraint(c_wmin=[-1.0, -1.0])           # test/3...:374
+    with pytest.raises(ValueError, match="Hermitian"):
+        mk(M_Hp=np.triu(np.ones((6, 6))))
+    hd = mpcqp.Handle(2, 3, 1, 1, 0, 6, 2, lib=emulib)
+    with pytest.raises(mpcqp.api.MpcqpError):
+        hd.set_custom_bounds(np.zeros((2, 7)))           # before mpcqp_set_custom_constraints
+    with pytest.raises(mpcqp.api.MpcqpError):
+        hd.set_output_weight_blocks(np.ones((2, 6, 1, 1)))   # before mpcqp_set_weights
+    with pytest.raises(mpcqp.api.MpcqpError):
+        hd.set_custom_constraints(1, None, None)          # nw > 0 needs Wy and Wu
+    hd.close()
 
 
 @pytest.mark.slow
