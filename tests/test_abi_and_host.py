@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in ctypes.c_char_p(ctypes.cast(lib.mpcqp_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()).value
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/mpcqp.h compiles as C and every declared entry point links (tests/abi_c_client.c)."""
+    import subprocess
+    lib = mpcqp.DEFAULT_LIB
+    exe = str(tmp_path / "abi_c_client")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_c_client.c"), lib, "-o", exe,
+                           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "entry points" in out.stdout, out.stdout + out.stderr
+
+
 def test_library_is_a_gfx950_code_object():
     out = subprocess.run(["strings", "-a", mpcqp.DEFAULT_LIB], capture_output=True, text=True).stdout
     assert "gfx950" in out and "k_step" in out
