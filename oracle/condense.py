@@ -8,7 +8,7 @@ check on the HIP kernels (which never materialise any of those).
 
 Parity pin: the reference is Julia (no toolchain in this image, JuMP/OSQP not vendored), so it
 cannot be executed here.  This oracle is pinned instead against the reference's own
-known-answer tests (tests/test_oracle_known_answers.py: T1..T8 of SURVEY.md section 8c,
+known-answer tests (tests/test_oracle_known_answers.py: T1..T9, SURVEY.md section 8c and 8(f3),
 including the 6-digit doctest golden u = 17.577311 of ext/LinearMPCext.jl:255-269 and the
 LQR-equivalence test at atol 1e-5 of test/3_test_predictive_control.jl:498-527).
 
