@@ -96,7 +96,7 @@ struct StaticDims {
 constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs (cs only stored with runtime dims)
 
 struct Carve {
-    int S, Phi, zero, invd, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT, Wm;
+    int S, Phi, zero, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT, Wm;
     int rows[NROWARR];
     int jl, blk;               // int tables (offset in doubles, storage as int)
     int total;                 // doubles
@@ -116,7 +116,6 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     c.S = take(d.Hp * stride_S(d));
     c.Phi = take(d.npk);
     c.zero = take(4);                             // four zeros: where masked lanes of a chunk read point
-    c.invd = 0;                                   // (1/L[k][k] lives in a register of lane k)
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
     c.gt = take(d.nZ); c.rd = take(d.nZ);
     c.zlo = c.dz; c.zhi = c.gt;                   // only live while the rows are being set up
@@ -740,7 +739,7 @@ struct Step {
     double* sm;
     const Carve& c;
     RowStore<DM> rows;
-    double *z, *dz, *q, *zlo, *zhi, *gt, *rd, *F, *invd, *Phi;
+    double *z, *dz, *q, *zlo, *zhi, *gt, *rd, *F, *Phi;
     int mact;           // number of finite rows
     double nh;          // 1 + max |h|
     double delta;
@@ -752,7 +751,7 @@ struct Step {
           rows(qp_.d, qp_.sm, qp_.c, qp_.w.lane) {
         z = sm + c.z; dz = sm + c.dz; q = sm + c.q; zlo = sm + c.zlo; zhi = sm + c.zhi;
         gt = sm + c.gt; rd = sm + c.rd; F = sm + c.F;
-        invd = sm + c.invd; Phi = qp.Phi;
+        Phi = qp.Phi;
         delta = d.dual_reg;
     }
 
