@@ -120,13 +120,14 @@ def custom_constraint_cases():
     return model, kf, cases
 
 
-def run_custom_constraint_cases(lib=None, B=2):
-    """T9 through the C-ABI against the reference's expected values and the oracle."""
+def run_custom_constraint_cases(lib=None, B=2, Hp=50, which=(0, 1, 2, 3)):
+    """T9 through the C-ABI against the oracle and (at the reference's horizon Hp = Hc = 50) the
+    reference's expected values."""
     model, kf, cases = custom_constraint_cases()
     rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
     worst = 0.0
-    for kwW, wmin, wmax, checks in cases:
-        kw = dict(Hp=50, Hc=50, Nwt=[0], Cwt=np.inf, uop=model.uop, yop=model.yop, dop=model.dop,
+    for kwW, wmin, wmax, checks in [cases[i] for i in which]:
+        kw = dict(Hp=Hp, Hc=Hp, Nwt=[0], Cwt=np.inf, uop=model.uop, yop=model.yop, dop=model.dop,
                   xhop=kf.xhop, fhop=kf.fhop)
         orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw, **kwW)
         orc.setconstraint(wmin=wmin, wmax=wmax)
@@ -139,7 +140,8 @@ def run_custom_constraint_cases(lib=None, B=2):
             uo = orc.moveinput(x0, [ry], [30.0])
             assert np.all(gpu.status == 0)
             ig, io = gpu.getinfo(), orc.getinfo()
-            assert np.all(np.abs(ig[key][B - 1] - want) < 1e-1), (kwW, ry)
+            if Hp == 50:
+                assert np.all(np.abs(ig[key][B - 1] - want) < 1e-1), (kwW, ry)
             worst = max(worst, np.abs(gpu.Z[B - 1] - orc.Zt).max() / max(1.0, np.abs(orc.Zt).max()),
                         np.abs(ig["W"][B - 1] - io["W"]).max() / max(1.0, np.abs(io["W"]).max()))
     return worst
