@@ -200,3 +200,81 @@ def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
              + noise * rg.standard_normal(x.shape))
         b_.lastu0 = a.lastu0.copy()      # keep the two loops on the same trajectory
     return out
+
+
+def run_random_case(seed, lib=None, B=3, small=False):
+    """One randomly drawn controller family (dimensions, move blocking, which bounds exist, hard /
+    soft mix, terminal bounds, measured disturbance, weights, Cwt finite or Inf) stepped twice
+    through the C-ABI and through the oracle; returns the worst relative ΔU error over the steps
+    whose oracle optimum carries an exact certificate (None if none did)."""
+    from oracle import estim as es
+    rng = np.random.default_rng(1000 + seed)
+    nx = int(rng.integers(2, 4 if small else 7)); nu = int(rng.integers(1, 3 if small else 5))
+    ny = int(rng.integers(1, 3 if small else 4)); nd = int(rng.integers(0, 2))
+    Hp = int(rng.integers(4, 9 if small else 24))
+    if rng.random() < 0.5:
+        Hc = int(rng.integers(1, min(Hp, (60 // nu)) + 1))
+    else:                                   # a move-blocking vector (sums to <= Hp, construct.jl:629-660)
+        parts = []
+        while sum(parts) < Hp - 1 and len(parts) * nu < 56 and len(parts) < 6:
+            parts.append(int(rng.integers(1, 4)))
+            if sum(parts) > Hp:
+                parts[-1] -= sum(parts) - Hp
+        Hc = [p for p in parts if p > 0] or 1
+    lam = rng.uniform(0.3, 0.97, nx)
+    Q, _ = np.linalg.qr(rng.standard_normal((nx, nx)))
+    A = Q @ np.diag(lam) @ Q.T
+    Bu = rng.standard_normal((nx, nu)) / np.sqrt(nx); C = rng.standard_normal((ny, nx)) / np.sqrt(nx)
+    Bd = rng.standard_normal((nx, nd)); Dd = 0.3 * rng.standard_normal((ny, nd))
+    model = es.LinModelOracle(A, Bu, C, Bd, Dd).setop(uop=0.2 * rng.standard_normal(nu),
+                                                      yop=rng.standard_normal(ny), dop=0.3 * rng.standard_normal(nd))
+    kf = es.SteadyKalmanFilterOracle(model)
+    soft = rng.random() < 0.75
+    kw = dict(Hp=Hp, Hc=Hc, Mwt=rng.uniform(0.5, 2.0, ny), Nwt=rng.uniform(0.02, 0.3, nu),
+              Lwt=rng.uniform(0.0, 0.1, nu) * (rng.random() < 0.5), Cwt=10 ** rng.uniform(3, 5.5) if soft else np.inf,
+              uop=model.uop, yop=model.yop, dop=model.dop, xhop=kf.xhop, fhop=kf.fhop)
+    orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd) if nd else None,
+                            rep(kf.Dhd) if nd else None, lib=lib, **kw)
+    inf_some = lambda v: np.where(rng.random(v.shape) < 0.25, np.inf * np.sign(v), v)
+    con, cong = {}, {}
+    def put(name, gname, val):
+        con[name] = val; cong[gname] = val
+    if rng.random() < 0.8:
+        put("umin", "umin", inf_some(model.uop - rng.uniform(0.3, 1.2, nu)))
+        put("umax", "umax", inf_some(model.uop + rng.uniform(0.3, 1.2, nu)))
+    if rng.random() < 0.6:
+        put("dumin", "Δumin", inf_some(-rng.uniform(0.1, 0.6, nu)))
+        put("dumax", "Δumax", inf_some(rng.uniform(0.1, 0.6, nu)))
+    if soft and rng.random() < 0.8:
+        put("ymin", "ymin", inf_some(model.yop - rng.uniform(0.2, 1.5, ny)))
+        put("ymax", "ymax", inf_some(model.yop + rng.uniform(0.2, 1.5, ny)))
+    if soft and rng.random() < 0.4:
+        xm = np.full(kf.nxh, np.inf); xm[int(rng.integers(0, kf.nxh))] = 0.6
+        put("xhatmax", "x̂max", kf.xhop + xm)
+    if soft:                                # softness: some rows hard (0), some soft
+        for base, gbase, n in (("c_umin", "c_umin", nu), ("c_umax", "c_umax", nu), ("c_dumin", "c_Δumin", nu),
+                               ("c_dumax", "c_Δumax", nu), ("c_ymin", "c_ymin", ny), ("c_ymax", "c_ymax", ny)):
+            if base[2:] in con and rng.random() < 0.5:
+                put(base, gbase, rng.uniform(0.2, 1.5, n) * (rng.random(n) < 0.6 if base[2] != "y" else 1.0))
+    orc.setconstraint(**con); gpu.setconstraint(**cong)
+    x0 = 0.5 * rng.standard_normal(kf.nxh)
+    u_prev = model.uop + 0.2 * rng.standard_normal(nu)
+    gpu.initstate(u_prev); orc.lastu0 = u_prev - model.uop
+    worst = None
+    for k in range(2):
+        ry = model.yop + rng.standard_normal(ny) * (1.5 if k == 0 else 0.5)
+        d = model.dop + 0.3 * rng.standard_normal(nd) if nd else None
+        Dhat = (np.tile(d, Hp) + 0.05 * rng.standard_normal(nd * Hp)) if nd else None
+        gpu.moveinput(np.tile(x0, (B, 1)), ry, d, Dhat=Dhat)
+        orc.initpred(x0, orc.lastu0 + model.uop, ry, d, Dhat); orc.linconstraint()
+        z, st, info = qp.solve_qp(*orc.qp_data(), orc.warmstart(), return_info=True)
+        if st == 0:
+            assert np.all(gpu.status == 0), (seed, gpu.status)
+        if st == 0 and info["certificate"] == "active-set":
+            e = rel_err(gpu.Z[B - 1:B], z[None, :], orc.nDU).max()
+            worst = e if worst is None else max(worst, e)
+        uo = orc.moveinput(x0, ry, d, Dhat=Dhat)
+        x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop)
+    return worst

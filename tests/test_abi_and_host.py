@@ -238,3 +238,12 @@ def test_kalman_steps_on_cpu_emulator(nd, emulib):
         kf.updatestate(uo, y, dd)
         plant.updatestate(uo, dd)
         assert np.abs(gpu.xhat0[0] - kf.x0).max() < 1e-6
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_controller_families_on_cpu_emulator(seed, emulib):
+    """Randomly drawn dimensions / move blocking / bound patterns / softness / terminal bounds /
+    measured disturbance, two periods, against the certified oracle optimum."""
+    from tests.parity_util import run_random_case
+    e = run_random_case(seed, lib=emulib, B=1, small=True)
+    assert e is None or e <= 1e-5

@@ -388,3 +388,14 @@ def test_dual_warm_start_closed_loop_on_gpu(hiplib):
     plain = np.mean([r[2].mean() for r in res[1:]])
     warm = np.mean([r[3].mean() for r in res[1:]])
     assert warm <= plain - 1.0, (plain, warm)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_controller_families_on_gpu(seed, hiplib):
+    """Randomly drawn dimensions (nu ≤ 4, ny ≤ 3, Hp ≤ 23), move-blocking vectors, bound patterns
+    with ±Inf holes, hard/soft mixes, terminal bounds, measured disturbances with preview, finite or
+    infinite Cwt: each family gets its own on-demand specialisation and is stepped twice (the second
+    step from the shifted warm start) against the certified oracle optimum."""
+    from tests.parity_util import run_random_case
+    e = run_random_case(seed, B=5)
+    assert e is None or e <= TOL
