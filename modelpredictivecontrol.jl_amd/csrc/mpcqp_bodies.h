@@ -684,6 +684,7 @@ MPCQP_HD void hessian_body(W& w, const DM& d, const Model& m, int b, double* sm)
 struct Row {
     double &h, &s, &lam, &rp, &gd, &pp;
     double cs;       // softness of the row (stored with runtime dims, re-derived otherwise)
+    double wt = 1.0; // multiplicity of the row in the barrier (re-derived on every pass, see rowweight())
 };
 
 template <class DM, bool STATIC = DM::is_static>
@@ -741,6 +742,7 @@ struct Step {
     RowStore<DM> rows;
     double *z, *dz, *q, *zlo, *zhi, *gt, *rd, *F, *Phi;
     int mact;           // number of finite rows
+    double wsum;        // their total multiplicity (rowweight), the m of mu = s'lam / m
     double nh;          // 1 + max |h|
     double delta;
     double prof_[16] = {0};   // phase cycle counters (profiling builds)
@@ -781,6 +783,18 @@ struct Step {
         return p[(size_t)b * d.cnt(g >> 1) + k];
     }
 
+    // Multiplicity of a row in the barrier.  The U rows of one move-blocking interval are merged
+    // into one (see build()); the reference's QP holds nb_j identical copies of it, and k copies of
+    // a row act on an interior-point iteration like one row whose complementarity target is k mu
+    // (same Phi, same step lengths).  Carrying that weight keeps the merged problem on the
+    // reference problem's central path: measured on 8192 C3 instances, 13.5 instead of 14.4
+    // iterations (the last interval of C3 holds 21 steps).  The optimum does not depend on it.
+    MPCQP_HD double rowweight(int p, int k) const {
+        if (p != P_U) return 1.0;
+        const int j = k / d.nu;
+        return (double)((j + 1 < d.Hc ? qp.jl(j + 1) : d.Hp) - qp.jl(j));
+    }
+
     // fn(group, local index, Row&) for every row owned by this lane
     template <class Fn>
     MPCQP_HD void for_rows(Fn fn) {
@@ -794,6 +808,7 @@ struct Step {
                 if (k < n) {
                     Row r = rows.at(g, qq);
                     if (!RowStore<DM>::stores_cs) r.cs = soft_init(g, k);
+                    r.wt = rowweight(g >> 1, k);
                     fn(g, k, r);
                 }
                 MPCQP_SCHED_FENCE();
@@ -817,14 +832,17 @@ struct Step {
                     if (gmin && gmax) {
                         Row r0 = rows.at(2 * p, qq), r1 = rows.at(2 * p + 1, qq);
                         if (live) { r0.cs = soft_init(2 * p, k); r1.cs = soft_init(2 * p + 1, k); }
+                        r0.wt = r1.wt = rowweight(p, k);
                         fn(p, k, &r0, &r1);
                     } else if (gmin) {
                         Row r0 = rows.at(2 * p, qq);
                         if (live) r0.cs = soft_init(2 * p, k);
+                        r0.wt = rowweight(p, k);
                         fn(p, k, &r0, (Row*)nullptr);
                     } else {
                         Row r1 = rows.at(2 * p + 1, qq);
                         if (live) r1.cs = soft_init(2 * p + 1, k);
+                        r1.wt = rowweight(p, k);
                         fn(p, k, (Row*)nullptr, &r1);
                     }
                 }
@@ -975,7 +993,7 @@ struct Step {
         }
         // b vector, finite rows only (linconstraint!, transcription.jl:824-842 and i_b :692-700)
         int cntl = 0;
-        double hmax = 0.0;
+        double hmax = 0.0, wacc = 0.0;
         for_rows([&](int g, int k, Row& r) {
             double bound = INFINITY;
             const size_t o = (size_t)b * d.cnt(g >> 1) + k;
@@ -1019,9 +1037,10 @@ struct Step {
             r.lam = ok ? 1.0 : 0.0;
             r.rp = 0.0; r.gd = 0.0; r.pp = 0.0;
             rows.set_cs(g, k / WAVE, soft_init(g, k));
-            if (ok) { ++cntl; hmax = fmax(hmax, fabs(bound)); }
+            if (ok) { ++cntl; wacc += rowweight(g >> 1, k); hmax = fmax(hmax, fabs(bound)); }
         });
         mact = w.isum(cntl);
+        wsum = w.sum(wacc);
         nh = 1.0 + w.maxv(hmax);
         w.sync();
     }
@@ -1495,7 +1514,7 @@ struct Step {
             rpmax = fmax(rpmax, fabs(v));
             musum += r.s * r.lam;
         });
-        mu = w.sum(musum) / mact;
+        mu = w.sum(musum) / wsum;
         rpn = w.maxv(rpmax);
         apply_Gt([&](Row& r) { return r.lam; });
         MPCQP_TIC();
@@ -1595,14 +1614,14 @@ struct Step {
                 // band around the central path made the tail worse.)
                 const double mu0 = 1e-3;
                 double si = fmax(r.s, 1e-3);
-                const double li = fmax(lp[d.rowoff(g) + k], mu0 * rcp(si));
-                si = fmax(si, mu0 * rcp(li));
+                const double li = fmax(lp[d.rowoff(g) + k], r.wt * mu0 * rcp(si));
+                si = fmax(si, r.wt * mu0 * rcp(li));
                 r.s = si; r.lam = li;
             });
         } else {
             apply_G(z, [&](Row& r, double gz) {
                 r.s = fmax(r.h - gz, 1.0);
-                r.lam = 10.0 * rcp(r.s);
+                r.lam = 10.0 * r.wt * rcp(r.s);
             });
         }
         int status = ST_ITERATION_LIMIT;
@@ -1624,7 +1643,7 @@ struct Step {
             } else {
                 // sum s lam and max |r_p| were accumulated by the update pass of the previous
                 // iteration; max |r_d| scales with the dual residual itself
-                mu = w.sum(musum_c) / mact;
+                mu = w.sum(musum_c) / wsum;
                 rpn = w.maxv(rpmax_c);
                 rdn *= rdscale_c;
                 verified = false;
@@ -1662,19 +1681,19 @@ struct Step {
             const double aaff = w.minv(amin);
             // mu after the affine step: sum (s + a ds)(lam + a dl) = sum s lam (1 - a) + a^2 sum ds dl,
             // because s dl + lam ds = -s lam on every row of the predictor
-            const double muaff = (1.0 - aaff) * mu + aaff * aaff * w.sum(ppsum) / mact;
+            const double muaff = (1.0 - aaff) * mu + aaff * aaff * w.sum(ppsum) / wsum;
             double sig = muaff / mu;
             sig = sig * sig * sig;
             const double smu = sig * mu;
             // corrector: rc = s lam + ds_aff dl_aff - sigma mu.  The step is kept in the row
             // (pp <- ds, gd <- dl): the update below needs nothing else, since the primal residual
             // follows r_p <- (1 - alpha) r_p + alpha δ dl.
-            newton([&](Row& r) { return r.s * r.lam + r.pp - smu; });
+            newton([&](Row& r) { return r.s * r.lam + r.pp - r.wt * smu; });
             amin = 1e300;
             for_rows([&](int, int, Row& r) {
                 if (!fin(r)) return;
                 double ds, dl;
-                row_step(r, r.s * r.lam + r.pp - smu, ds, dl);
+                row_step(r, r.s * r.lam + r.pp - r.wt * smu, ds, dl);
                 if (ds < 0.0) amin = fmin(amin, -r.s * rcp(ds));
                 if (dl < 0.0) amin = fmin(amin, -r.lam * rcp(dl));
                 r.pp = ds;
@@ -1690,12 +1709,12 @@ struct Step {
             for_rows([&](int, int, Row& r) {
                 if (!fin(r)) return;
                 const double p = (r.s + ahi * r.pp) * (r.lam + ahi * r.gd);
-                pmin = fmin(pmin, p);
+                pmin = fmin(pmin, p * rcp(r.wt));           // per copy of a merged row
                 psum += p;
             });
             pmin = w.minv(pmin);
             psum = w.sum(psum);
-            const double alpha = (pmin * mact >= 0.01 * psum) ? ahi : fmin(1.0, 0.99 * amin);
+            const double alpha = (pmin * wsum >= 0.01 * psum) ? ahi : fmin(1.0, 0.99 * amin);
             musum_c = 0.0; rpmax_c = 0.0; rdscale_c = 1.0 - alpha;
             for_rows([&](int, int, Row& r) {
                 if (!fin(r)) return;
