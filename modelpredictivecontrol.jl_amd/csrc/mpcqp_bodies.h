@@ -64,6 +64,11 @@ struct StaticDims {
     // LDS stride of one Σ_m block: padded so the MFMA operand reads of E'DE (64 lanes = 4 block
     // columns x NY*NU entries) fall in distinct bank groups (see DESIGN.md "LDS layout")
     static constexpr int sp = (NY * NU) % 16 == 0 ? NY * NU + 8 : NY * NU;
+    // row stride inside a block.  4 x 4 blocks: rows padded 4 -> 6 doubles (the block still takes
+    // 24): with it the row reads of E v / E'w (quarter-waves of 4 steps x 4 rows, 16 B per lane) and,
+    // with the K rows of a step taken in the order 0,2,1,3, the MFMA operand reads (half-waves of 4
+    // block columns x 2 rows x 4 entries) all fall in distinct LDS banks
+    static constexpr int rs = (NY == 4 && NU == 4) ? 6 : NU;
     static constexpr uint32_t gmask = GMASK;
     static constexpr int default_nb = DNB;          // 1: nb = [1,..,1,Hp-Hc+1]; 0: table in LDS
     int B, nd, nD, max_iter;
@@ -106,6 +111,12 @@ template <class DM>
 MPCQP_HD inline int stride_S(const DM& d) {
     if constexpr (DM::is_static) return DM::sp;
     else return d.ny * d.nu;
+}
+
+template <class DM>
+MPCQP_HD inline int rowstride_S(const DM& d) {
+    if constexpr (DM::is_static) return DM::rs;
+    else return d.nu;
 }
 
 template <class DM>
@@ -157,9 +168,10 @@ struct Qp {
     int *jlt, *blkt;
     double *S, *Phi;
     int sp;             // LDS stride of one Σ_m block (>= ny*nu)
+    int rs;             // LDS stride of one row of a block (>= nu)
 
     MPCQP_HD Qp(W& w_, const DM& d_, const Model& m_, int b_, double* sm_)
-        : w(w_), d(d_), m(m_), b(b_), sm(sm_), c(make_carve(d_)), sp(stride_S(d_)) {
+        : w(w_), d(d_), m(m_), b(b_), sm(sm_), c(make_carve(d_)), sp(stride_S(d_)), rs(rowstride_S(d_)) {
         jlt = reinterpret_cast<int*>(sm + c.jl);
         blkt = reinterpret_cast<int*>(sm + c.blk);
         S = sm + c.S;
@@ -175,7 +187,10 @@ struct Qp {
     MPCQP_HD void load_tables() {
         const int nb_ = d.ny * d.nu, ns = d.Hp * nb_;
         const double* g = m.Stab + (size_t)b * ns;
-        for (int i = w.lane; i < ns; i += WAVE) S[(i / nb_) * sp + (i % nb_)] = g[i];
+        for (int i = w.lane; i < ns; i += WAVE) {
+            const int blk_ = i / nb_, e = i - blk_ * nb_, a = e / d.nu;
+            S[blk_ * sp + a * rs + (e - a * d.nu)] = g[i];
+        }
         if (!d.default_nb) {
             for (int i = w.lane; i <= d.Hc; i += WAVE) jlt[i] = m.jl[i];
             for (int i = w.lane; i < d.Hp; i += WAVE) blkt[i] = m.blk[i];
@@ -208,7 +223,7 @@ struct Qp {
         double g = 0.0;
         if (t >= 1 && t - 1 >= jl(j)) {
             const double* Sb = S + (t - 1 - jl(j)) * sp + cc;
-            for (int a = 0; a < d.ny; ++a) g += Wy_(i, a) * Sb[a * d.nu];
+            for (int a = 0; a < d.ny; ++a) g += Wy_(i, a) * Sb[a * rs];
         }
         if (j <= blkW(t)) g += Wu_(i, cc);
         return g;
@@ -252,8 +267,8 @@ struct Qp {
                 for (int j = 0; j < DM::Hc; ++j) {
                     const double* vj = v + j * 4;
                     const double v0 = vj[0], v1 = vj[1], v2 = vj[2], v3 = vj[3];
-                    const double* Sa = S + ((ok0 && j <= t0) ? (t0 - j) * sp + a0 * 4 : zoff);
-                    const double* Sb = S + ((ok1 && j <= t1) ? (t1 - j) * sp + a1 * 4 : zoff);
+                    const double* Sa = S + ((ok0 && j <= t0) ? (t0 - j) * sp + a0 * rs : zoff);
+                    const double* Sb = S + ((ok1 && j <= t1) ? (t1 - j) * sp + a1 * rs : zoff);
                     x0 = fma(Sa[0], v0, x0); x1 = fma(Sa[1], v1, x1);
                     y0 = fma(Sb[0], v0, y0); y1 = fma(Sb[1], v1, y1);
                     x0 = fma(Sa[2], v2, x0); x1 = fma(Sa[3], v3, x1);
@@ -268,7 +283,7 @@ struct Qp {
             const int t = r / ny, a = r - t * ny;
             double acc0 = 0.0;
             for (int j = 0; j < d.Hc && jl(j) <= t; ++j) {
-                const double* Sb = S + (t - jl(j)) * sp + a * nu;
+                const double* Sb = S + (t - jl(j)) * sp + a * rs;
                 const double* vj = v + j * nu;
                 for (int cc = 0; cc < nu; ++cc) acc0 += Sb[cc] * vj[cc];
             }
@@ -294,7 +309,7 @@ struct Qp {
                 MPCQP_UNROLL4
                 for (int t = 0; t < t_hi; ++t) {
                     const bool ok = t >= j && w.lane < DM::nDU;
-                    const double* Sb = S + (ok ? (t - j) * sp + a * 4 : zoff);     // zero slot before the block column starts
+                    const double* Sb = S + (ok ? (t - j) * sp + a * rs : zoff);    // zero slot before the block column starts
                     const double wt = wv[t * 4 + a];
                     p0 = fma(Sb[0], wt, p0); p1 = fma(Sb[1], wt, p1); p2 = fma(Sb[2], wt, p2); p3 = fma(Sb[3], wt, p3);
                 }
@@ -315,8 +330,8 @@ struct Qp {
                 const double* wt = wv + t * ny;
                 double p0 = 0.0, p1 = 0.0;
                 int a = 0;
-                for (; a + 1 < ny; a += 2) { p0 += Sb[a * nu] * wt[a]; p1 += Sb[(a + 1) * nu] * wt[a + 1]; }
-                if (a < ny) p0 += Sb[a * nu] * wt[a];
+                for (; a + 1 < ny; a += 2) { p0 += Sb[a * rs] * wt[a]; p1 += Sb[(a + 1) * rs] * wt[a + 1]; }
+                if (a < ny) p0 += Sb[a * rs] * wt[a];
                 acc0 += ok ? p0 : 0.0;
                 acc1 += ok ? p1 : 0.0;
             }
@@ -341,9 +356,12 @@ struct Qp {
     typedef double v4d __attribute__((ext_vector_type(4)));
     // returns the first step t whose rows the ϵ row (tb) has been accumulated for (-1: no ϵ row)
     __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb) {
-        constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp;
+        constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp, RS = DM::rs;
         constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
         const int li = w.lane & 15, lk = w.lane >> 4;
+        // the four K rows of an aligned step in the order 0,2,1,3 (see StaticDims::rs); any order works,
+        // A and B operands use the same
+        const int lkp = (NY % 4 == 0) ? (((lk & 1) << 1) | (lk >> 1)) : lk;
         int offI[NT], offL[NT], jI[NT];
         MPCQP_UNROLL
         for (int I = 0; I < NT; ++I) {
@@ -352,7 +370,7 @@ struct Qp {
             const int tj = jl(i < NDU ? j : 0);        // first step of block column j
             jI[I] = i < NDU ? tj : (1 << 20);          // padding columns never become valid
             offI[I] = -tj * SP + cc;
-            offL[I] = offI[I] + lk * NU;               // + the lane's row inside an aligned K step
+            offL[I] = offI[I] + lkp * RS;              // + the lane's row inside an aligned K step
         }
         // Tile rows are processed in passes whose accumulators fit the register budget of two
         // waves per SIMD: rows {0,1} together (3 tiles, 3 independent MFMA chains per K step),
@@ -394,9 +412,9 @@ struct Qp {
                 double dv, tbv = 0.0, e[NT];
                 if constexpr (NY % 4 == 0) {
                     const int t = (4 * kk) / NY, a0 = 4 * kk - t * NY;         // uniform
-                    const int base = t * SP + a0 * NU;
-                    dv = dd[4 * kk + lk];
-                    if (erow) tbv = tb[4 * kk + lk];
+                    const int base = t * SP + a0 * RS;
+                    dv = dd[4 * kk + lkp];
+                    if (erow) tbv = tb[4 * kk + lkp];
                     MPCQP_UNROLL
                     for (int J = 0; J <= I1; ++J) e[J] = S[t >= jI[J] ? base + offL[J] : zoff];
                 } else {
@@ -406,7 +424,7 @@ struct Qp {
                     const int t = rr / NY, a = rr - t * NY;
                     dv = rok ? dd[rr] : 0.0;
                     if (erow) tbv = rok ? tb[rr] : 0.0;
-                    const int base = t * SP + a * NU;
+                    const int base = t * SP + a * RS;
                     MPCQP_UNROLL
                     for (int J = 0; J <= I1; ++J) e[J] = S[(rok && t >= jI[J]) ? base + offI[J] : zoff];
                 }
@@ -464,7 +482,7 @@ struct Qp {
                 const double* S1 = S + (t - t0) * sp + cc;
                 const double* S2 = S + (t - t0 + off2) * sp + c2;
                 const double* dt = dd + t * ny;
-                for (int a = 0; a < ny; ++a) acc += S1[a * nu] * dt[a] * S2[a * nu];
+                for (int a = 0; a < ny; ++a) acc += S1[a * rs] * dt[a] * S2[a * rs];
             }
             P[pk(i, ip)] += scale * acc;
         }
@@ -488,8 +506,8 @@ struct Qp {
                 const double* Mt = Mb + (size_t)t * ny * ny;
                 for (int a = 0; a < ny; ++a) {
                     double ms = 0.0;
-                    for (int a2 = 0; a2 < ny; ++a2) ms += Mt[a + ny * a2] * S2[a2 * nu];
-                    acc += S1[a * nu] * ms;
+                    for (int a2 = 0; a2 < ny; ++a2) ms += Mt[a + ny * a2] * S2[a2 * rs];
+                    acc += S1[a * rs] * ms;
                 }
             }
             P[pk(i, ip)] += scale * acc;
@@ -906,7 +924,7 @@ struct Step {
             double acc = Bv[r];
             MPCQP_UNROLL4
             for (int k = 0; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
-            const double* Sb = qp.S + t * qp.sp + a * nu;       // V block t = Σ_t
+            const double* Sb = qp.S + t * qp.sp + a * qp.rs;    // V block t = Σ_t
             for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * lu[cc];
             if (nd > 0) {
                 const double* Gd = m.Gdtab + (size_t)b * d.Hp * ny * nd;
