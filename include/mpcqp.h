@@ -119,6 +119,11 @@ int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const 
 int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
                       const double* Ldiag, const double* Cwt);
 
+/* Replace the MPCQP_FLAG_* set of the handle (they are read at every step): e.g. switch between a
+ * set point held over the horizon (Ry (ny,B), MPCQP_FLAG_RY_CONSTANT) and a full R̂y (nY,B), or
+ * between cold and warm starts.  Unknown bits: MPCQP_ERR_ARG.                                    */
+int mpcqp_set_flags(mpcqp_handle h, uint32_t flags);
+
 /* Block-diagonal output weight M_Hp = blkdiag(M_1, ..., M_Hp) with symmetric ny x ny blocks,
  * Mblk (ny,ny,Hp,B); replaces Mdiag of mpcqp_set_weights (call that first: N, L, C come from it).
  * This is the `M_Hp=` keyword of LinMPC (src/controller/linmpc.jl:205-214) for the weights the

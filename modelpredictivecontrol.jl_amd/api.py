@@ -34,7 +34,8 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_recondense_device",
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
-           "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds")
+           "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
+           "mpcqp_set_flags")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -90,6 +91,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_weights.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_set_bounds.argtypes = [C.c_void_p, C.POINTER(Bounds)]
     lib.mpcqp_set_output_weight_blocks.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpcqp_set_flags.argtypes = [C.c_void_p, C.c_uint32]
     lib.mpcqp_set_custom_constraints.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     lib.mpcqp_set_custom_bounds.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
@@ -174,6 +176,10 @@ class Handle:
         """Mblk (B, Hp, ny, ny), symmetric blocks, or None (back to the diagonal weight)."""
         a = None if Mblk is None else _f64(np.asarray(Mblk, float).transpose(0, 1, 3, 2))
         _chk(self.lib, self.lib.mpcqp_set_output_weight_blocks(self.h, _ptr(a)))
+
+    def set_flags(self, flags):
+        _chk(self.lib, self.lib.mpcqp_set_flags(self.h, int(flags)))
+        self.flags = int(flags)
 
     def set_custom_constraints(self, nw, Wy=None, Wu=None, Wd=None, Wr=None, w_op=None):
         args = [None if a is None else _f64(a) for a in (Wy, Wu, Wd, Wr, w_op)]
@@ -607,7 +613,11 @@ class BatchLinMPC:
             raise ValueError(f"xhat0 size must be ({B},{self.nxh})")
         bc = lambda v, n, name: self._bc(v, n, name)
         ry = self.yop if ry is None else bc(ry, self.ny, "ry")
-        Rhaty = np.tile(ry, Hp) if Rhaty is None else bc(Rhaty, self.nY, "R̂y")
+        held = Rhaty is None                      # R̂y = repeat(ry, Hp): send ry once (MPCQP_FLAG_RY_CONSTANT)
+        Rhaty = None if held else bc(Rhaty, self.nY, "R̂y")
+        want = (self.hd.flags | FLAG_RY_CONSTANT) if held else (self.hd.flags & ~FLAG_RY_CONSTANT)
+        if want != self.hd.flags:
+            self.hd.set_flags(want)
         Rhatu = None if Rhatu is None else bc(Rhatu, self.nU, "R̂u")
         lastu0 = self.lastu0 if lastu is None else bc(lastu, self.nu, "lastu") - self.uop
         d0 = Dh0 = None
@@ -617,13 +627,13 @@ class BatchLinMPC:
             d0, Dh0 = d - self.dop, Dhat - self.Dop
         elif d is not None and np.size(d) != 0:
             raise ValueError("d size must be (0,)")
-        out = self.hd.step(xhat0, lastu0, Rhaty - self.Yop, self.Z,
+        out = self.hd.step(xhat0, lastu0, (ry - self.yop) if held else (Rhaty - self.Yop), self.Z,
                            Ru=None if Rhatu is None else Rhatu - self.Uop, d0=d0, Dhat0=Dh0,
                            want_Yhat=want_info)
         u0, self.status, self.iters = out[0], out[1], out[2]
         self._Yhat0 = out[3] if want_info else None
         self._lastu0_prev = lastu0
-        self._winfo = (xhat0, Rhaty, d0, Dh0)
+        self._winfo = (xhat0, np.tile(ry, Hp) if (held and self.nw > 0) else Rhaty, d0, Dh0)
         self.solved_once = True
         nerr = int(np.sum(self.status == STATUS_ERROR))
         nwarn = int(np.sum(self.status == STATUS_ITERATION_LIMIT))

@@ -310,6 +310,15 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
     return MPCQP_OK;
 }
 
+int mpcqp_set_flags(mpcqp_handle h, uint32_t flags) {
+    if (!h) return MPCQP_ERR_NULL;
+    const uint32_t known = MPCQP_FLAG_RY_CONSTANT | MPCQP_FLAG_COLD_START | MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL;
+    if (flags & ~known) return MPCQP_ERR_ARG;
+    if ((flags ^ h->d.flags) & MPCQP_FLAG_WARM_DUAL) h->lam_valid = false;
+    h->d.flags = flags;
+    return MPCQP_OK;
+}
+
 int mpcqp_set_custom_constraints(mpcqp_handle h, int nw, const double* Wy, const double* Wu,
                                  const double* Wd, const double* Wr, const double* w_op) {
     if (!h) return MPCQP_ERR_NULL;
