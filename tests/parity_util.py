@@ -270,8 +270,9 @@ def run_random_case(seed, lib=None, B=3, small=False):
         gpu.moveinput(np.tile(x0, (B, 1)), ry, d, Dhat=Dhat)
         orc.initpred(x0, orc.lastu0 + model.uop, ry, d, Dhat); orc.linconstraint()
         z, st, info = qp.solve_qp(*orc.qp_data(), orc.warmstart(), return_info=True)
-        if st == 0:
-            assert np.all(gpu.status == 0), (seed, gpu.status)
+        if st != 0:                       # the oracle gave up on this one (it would take its error
+            break                         # branch and the two loops would no longer see the same inputs)
+        assert np.all(gpu.status == 0), (seed, gpu.status)
         if st == 0 and info["certificate"] == "active-set":
             e = rel_err(gpu.Z[B - 1:B], z[None, :], orc.nDU).max()
             worst = e if worst is None else max(worst, e)
