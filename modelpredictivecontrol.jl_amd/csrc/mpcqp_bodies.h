@@ -675,18 +675,15 @@ MPCQP_HD void hessian_body(W& w, const DM& d, const Model& m, int b, double* sm)
     w.sync();
     const int nu = d.nu;
     // 2 Pu'L Pu: entry ((j,c),(j',c)) = sum_{t >= j_max(j,j')} L[t,c]   (construct.jl:797-806)
+    // (the suffix sum of a (block, channel) is formed once, by its own lane, and added along the
+    // lane's row of the lower triangle: entry (i, i') with j >= j' takes the sum from j_j on)
     const double* L = m.Ldiag + (size_t)b * d.nU;
-    const int ntri = d.nDU * (d.nDU + 1) / 2;
-    for (int idx = w.lane; idx < ntri; idx += WAVE) {
-        int i, ip;
-        Qp<W, DM>::unpack_idx(idx, i, ip);
-        int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
-        (void)j2;
-        double acc = 0.0;
-        if (cc == c2)
-            for (int t = qp.jl(j); t < d.Hp; ++t) acc += L[t * nu + cc];
-        if (i == ip) acc += m.Ndiag[(size_t)b * d.nDU + i];     // 2 N
-        P[pk(i, ip)] += 2.0 * acc;
+    for (int i = w.lane; i < d.nDU; i += WAVE) {
+        const int j = i / nu, cc = i - j * nu;
+        double suf = 0.0;
+        for (int t = qp.jl(j); t < d.Hp; ++t) suf += L[t * nu + cc];
+        for (int j2 = 0; j2 <= j; ++j2) P[pk(i, j2 * nu + cc)] += 2.0 * suf;
+        P[pk(i, i)] += 2.0 * m.Ndiag[(size_t)b * d.nDU + i];    // 2 N
     }
     if (d.neps && w.lane == 0) P[pk(d.nZ - 1, d.nZ - 1)] = 2.0 * m.Cwt[b];    // Ñ = blkdiag(N, C)
     w.sync();
