@@ -1650,17 +1650,27 @@ struct Step {
         bool exact = true, verified = false;
         double musum_c = 0.0, rpmax_c = 0.0, rdscale_c = 1.0;    // carried from the update pass
         double step_c = 1e300, zabs_c = 0.0;                     // |alpha dU_k|, |dU_k| of this lane's entry
+        double rd_exact_prev = 1e300, scale_since_exact = 1.0;   // stall detection of the exact dual residual
+        bool rd_stalled = false;
         while (it < d.max_iter) {
             if (exact) {
                 residuals(mu, rpn, rdn, ndd);      // also stages H̃ in Phi
                 exact = false;
                 verified = true;
+                // The dual residual has hit the floor of the float64 normal equations when an exact
+                // evaluation finds it where the previous exact evaluation left it although the
+                // steps in between were (nearly) full: rows held at D = 1/δ make Phi's condition
+                // number ~1e13 and r_d stops near 1e-16 * 1e12 * |dz| however long one iterates.
+                rd_stalled = rdn >= 0.5 * rd_exact_prev && scale_since_exact <= 0.1;
+                rd_exact_prev = rdn;
+                scale_since_exact = 1.0;
             } else {
                 // sum s lam and max |r_p| were accumulated by the update pass of the previous
                 // iteration; max |r_d| scales with the dual residual itself
                 mu = w.sum(musum_c) / wsum;
                 rpn = w.maxv(rpmax_c);
                 rdn *= rdscale_c;
+                scale_since_exact *= rdscale_c;
                 verified = false;
             }
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
@@ -1670,8 +1680,10 @@ struct Step {
             // 4084 certified C3 optima: worst dU error 6.7e-6 -> 3.1e-8 for +0.26 iterations.)
             // The dual residual is measured against a gradient scale that reaches 1e5 (soft rows):
             // its target is res_tol; the primal one (rounding floor ~1e-10 nh there) is 100 res_tol.
-            if (mu <= d.gap_tol && rdn <= d.res_tol * ndd && rpn <= 100.0 * d.res_tol * nh &&
-                w.maxv(step_c) <= 1e-6 * fmax(1.0, w.maxv(zabs_c))) {
+            // A dual residual stalled at its floor counts as converged (the step criterion is what
+            // vouches for z then).
+            if (mu <= d.gap_tol && (rdn <= d.res_tol * ndd || (verified && rd_stalled)) &&
+                rpn <= 100.0 * d.res_tol * nh && w.maxv(step_c) <= 1e-6 * fmax(1.0, w.maxv(zabs_c))) {
                 if (verified) { status = ST_OPTIMAL; break; }
                 exact = true;                      // re-evaluate exactly at the same iterate
                 continue;

@@ -269,6 +269,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
             }
             int st = 1, it = 0;
             double laststep = 1e300;     /* alpha |dU|_inf / max(1, |dU|_inf) of the previous iteration */
+            double rdn_prev = 1e300, lastscale = 1.0;   /* previous dual residual, 1 - alpha of the previous step */
             double nh = 1.0, rpn = 0;
             for (int i = 0; i < m; ++i) {       /* starting point: s = max(h - G z, 1), lam = 10 / s */
                 double a = 0;
@@ -310,7 +311,11 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                     it = pass;
                     if (!(mu == mu)) { st = 2; break; }
                     /* converged: gap, residuals, and a last Newton step that no longer moves the inputs */
-                    if (mu <= gap_tol && rdn <= res_tol * ndd && rpn <= 100.0 * res_tol * nh && laststep <= 1e-6) { st = 0; break; }
+                    /* (a dual residual stuck at the float64 floor of the normal equations although the last
+                       step was nearly full counts as converged; the step criterion vouches for z) */
+                    int stalled = rdn >= 0.5 * rdn_prev && lastscale <= 0.1;
+                    rdn_prev = rdn;
+                    if (mu <= gap_tol && (rdn <= res_tol * ndd || stalled) && rpn <= 100.0 * res_tol * nh && laststep <= 1e-6) { st = 0; break; }
                 }
                 /* Phi = H + G' D~ G */
                 for (int i = 0; i < m; ++i) {
@@ -379,6 +384,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                             double zm = 1.0, dm = 0.0;
                             for (int k = 0; k < nDU; ++k) { zm = fmax(zm, fabs(z[k])); dm = fmax(dm, fabs(alpha * dz[k])); }
                             laststep = dm / zm;
+                            lastscale = 1.0 - alpha;
                         }
                         for (int k = 0; k < nZ; ++k) z[k] += alpha * dz[k];
                     }

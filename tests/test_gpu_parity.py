@@ -390,7 +390,7 @@ def test_dual_warm_start_closed_loop_on_gpu(hiplib):
     assert warm <= plain - 1.0, (plain, warm)
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
+@pytest.mark.parametrize("seed", list(range(10)) + [355])   # 355: dual residual stalls at its float64 floor
 def test_random_controller_families_on_gpu(seed, hiplib):
     """Randomly drawn dimensions (nu ≤ 4, ny ≤ 3, Hp ≤ 23), move-blocking vectors, bound patterns
     with ±Inf holes, hard/soft mixes, terminal bounds, measured disturbances with preview, finite or
