@@ -279,3 +279,75 @@ def run_random_case(seed, lib=None, B=3, small=False):
         uo = orc.moveinput(x0, ry, d, Dhat=Dhat)
         x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop)
     return worst
+
+
+def run_random_case2(seed, lib=None, B=2, small=False):
+    """Like run_random_case, for the horizon-wide forms: time-varying Umin/Umax/Ymin/Ymax vectors
+    (with ±Inf holes), R̂y / R̂u / D̂ trajectories, a block-diagonal M_Hp, and (every other seed)
+    custom linear constraints Wy/Wu/Wd/Wr.  Returns the worst relative ΔU error over certified steps."""
+    from oracle import estim as es
+    rng = np.random.default_rng(5000 + seed)
+    nx = int(rng.integers(2, 4 if small else 6)); nu = int(rng.integers(1, 3 if small else 4))
+    ny = int(rng.integers(1, 3 if small else 4)); nd = int(rng.integers(0, 2))
+    Hp = int(rng.integers(4, 8 if small else 16)); Hc = int(rng.integers(1, min(Hp, 6) + 1))
+    lam = rng.uniform(0.3, 0.95, nx)
+    Q, _ = np.linalg.qr(rng.standard_normal((nx, nx)))
+    A = Q @ np.diag(lam) @ Q.T
+    Bu = rng.standard_normal((nx, nu)) / np.sqrt(nx); C = rng.standard_normal((ny, nx)) / np.sqrt(nx)
+    Bd = rng.standard_normal((nx, nd)); Dd = 0.3 * rng.standard_normal((ny, nd))
+    model = es.LinModelOracle(A, Bu, C, Bd, Dd).setop(uop=0.2 * rng.standard_normal(nu),
+                                                      yop=rng.standard_normal(ny), dop=0.3 * rng.standard_normal(nd))
+    kf = es.SteadyKalmanFilterOracle(model)
+    kw = dict(Hp=Hp, Hc=Hc, Nwt=rng.uniform(0.02, 0.3, nu), Lwt=rng.uniform(0.0, 0.1, nu),
+              Cwt=10 ** rng.uniform(3, 5), uop=model.uop, yop=model.yop, dop=model.dop, xhop=kf.xhop, fhop=kf.fhop)
+    if rng.random() < 0.5:                        # block-diagonal M_Hp with a dense terminal block
+        M = np.zeros((ny * Hp, ny * Hp))
+        for t in range(Hp):
+            R = rng.standard_normal((ny, ny)) * (0.3 if t < Hp - 1 else 1.0)
+            M[t * ny:(t + 1) * ny, t * ny:(t + 1) * ny] = np.eye(ny) * rng.uniform(0.5, 2.0) + (R @ R.T if t == Hp - 1 else 0.0)
+        kw["M_Hp"] = M
+    else:
+        kw["Mwt"] = rng.uniform(0.5, 2.0, ny)
+    if seed % 2 == 1:
+        nw = int(rng.integers(1, 3))
+        kw.update(Wy=rng.standard_normal((nw, ny)), Wu=rng.standard_normal((nw, nu)),
+                  Wr=0.3 * rng.standard_normal((nw, ny)))
+        if nd:
+            kw["Wd"] = rng.standard_normal((nw, nd))
+    orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd) if nd else None,
+                            rep(kf.Dhd) if nd else None, lib=lib, **kw)
+    holes = lambda v, sgn: np.where(rng.random(v.shape) < 0.3, sgn * np.inf, v)
+    con = dict(Umin=holes(np.tile(model.uop, Hp) - rng.uniform(0.3, 1.2, nu * Hp), -1),
+               Umax=holes(np.tile(model.uop, Hp) + rng.uniform(0.3, 1.2, nu * Hp), +1),
+               Ymin=holes(np.tile(model.yop, Hp) - rng.uniform(0.3, 1.5, ny * Hp), -1),
+               Ymax=holes(np.tile(model.yop, Hp) + rng.uniform(0.3, 1.5, ny * Hp), +1))
+    if seed % 2 == 1:
+        con.update(wmin=np.where(rng.random(nw) < 0.3, -np.inf, -rng.uniform(0.5, 2.0, nw)),
+                   wmax=rng.uniform(0.5, 2.0, nw), c_wmax=rng.uniform(0.3, 1.5, nw))
+    orc.setconstraint(**con); gpu.setconstraint(**con)
+    x0 = 0.5 * rng.standard_normal(kf.nxh)
+    u_prev = model.uop + 0.2 * rng.standard_normal(nu)
+    gpu.initstate(u_prev); orc.lastu0 = u_prev - model.uop
+    worst = None
+    for k in range(2):
+        ry = model.yop + rng.standard_normal(ny)
+        Rhaty = np.tile(ry, Hp) + 0.2 * rng.standard_normal(ny * Hp) if seed % 2 == 0 else None
+        Rhatu = np.tile(model.uop, Hp) + 0.1 * rng.standard_normal(nu * Hp)
+        d = model.dop + 0.3 * rng.standard_normal(nd) if nd else None
+        Dhat = (np.tile(d, Hp) + 0.05 * rng.standard_normal(nd * Hp)) if nd else None
+        gpu.moveinput(np.tile(x0, (B, 1)), ry, d, Dhat=Dhat, Rhaty=Rhaty, Rhatu=Rhatu, want_info=True)
+        orc.initpred(x0, orc.lastu0 + model.uop, ry, d, Dhat, Rhaty, Rhatu); orc.linconstraint()
+        z, st, info = qp.solve_qp(*orc.qp_data(), orc.warmstart(), return_info=True)
+        if st != 0:
+            break
+        assert np.all(gpu.status == 0), (seed, gpu.status)
+        if info["certificate"] == "active-set":
+            e = rel_err(gpu.Z[B - 1:B], z[None, :], orc.nDU).max()
+            worst = e if worst is None else max(worst, e)
+        uo = orc.moveinput(x0, ry, d, Dhat=Dhat, Rhaty=Rhaty, Rhatu=Rhatu)
+        if seed % 2 == 1:
+            assert np.abs(gpu.getinfo()["W"][B - 1] - orc.getinfo()["W"]).max() <= 1e-5
+        x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop)
+    return worst

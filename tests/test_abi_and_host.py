@@ -247,3 +247,12 @@ def test_random_controller_families_on_cpu_emulator(seed, emulib):
     from tests.parity_util import run_random_case
     e = run_random_case(seed, lib=emulib, B=1, small=True)
     assert e is None or e <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_horizon_wide_forms_on_cpu_emulator(seed, emulib):
+    """Time-varying bound vectors with holes, R̂y / R̂u / D̂ trajectories, block-diagonal M_Hp and
+    (odd seed) custom linear constraints, against the certified oracle optimum."""
+    from tests.parity_util import run_random_case2
+    e = run_random_case2(seed, lib=emulib, B=1, small=True)
+    assert e is None or e <= 1e-5

@@ -399,3 +399,12 @@ def test_random_controller_families_on_gpu(seed, hiplib):
     from tests.parity_util import run_random_case
     e = run_random_case(seed, B=5)
     assert e is None or e <= TOL
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_horizon_wide_forms_on_gpu(seed, hiplib):
+    """Time-varying Umin/Umax/Ymin/Ymax vectors with ±Inf holes, R̂y / R̂u / D̂ trajectories, a
+    block-diagonal M_Hp with a dense terminal block and (odd seeds) custom linear constraints."""
+    from tests.parity_util import run_random_case2
+    e = run_random_case2(seed, B=4)
+    assert e is None or e <= TOL
