@@ -1651,7 +1651,8 @@ struct Step {
         double musum_c = 0.0, rpmax_c = 0.0, rdscale_c = 1.0;    // carried from the update pass
         double step_c = 1e300, zabs_c = 0.0;                     // |alpha dU_k|, |dU_k| of this lane's entry
         double rd_exact_prev = 1e300, scale_since_exact = 1.0;   // stall detection of the exact dual residual
-        bool rd_stalled = false;
+        bool rd_stalled = false, rp_stalled = false;
+        double rpn_last = 1e300;
         while (it < d.max_iter) {
             if (exact) {
                 residuals(mu, rpn, rdn, ndd);      // also stages H̃ in Phi
@@ -1672,6 +1673,10 @@ struct Step {
                 rdn *= rdscale_c;
                 scale_since_exact *= rdscale_c;
                 verified = false;
+                // a primal residual that no longer follows (1 - alpha) -- it sits on alpha δ dlam, a
+                // few 1e-9 nh on rows with 1e6-size multipliers -- has stalled too, once below 1e-7 nh
+                rp_stalled = rpn >= 0.5 * rpn_last && rdscale_c <= 0.1 && rpn <= 1e-7 * nh;
+                rpn_last = rpn;
             }
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
             // Converged: gap and residuals below their targets AND the last Newton step no longer moves
@@ -1683,7 +1688,8 @@ struct Step {
             // A dual residual stalled at its floor counts as converged (the step criterion is what
             // vouches for z then).
             if (mu <= d.gap_tol && (rdn <= d.res_tol * ndd || (verified && rd_stalled)) &&
-                rpn <= 100.0 * d.res_tol * nh && w.maxv(step_c) <= 1e-6 * fmax(1.0, w.maxv(zabs_c))) {
+                (rpn <= 100.0 * d.res_tol * nh || rp_stalled) &&
+                w.maxv(step_c) <= 1e-6 * fmax(1.0, w.maxv(zabs_c))) {
                 if (verified) { status = ST_OPTIMAL; break; }
                 exact = true;                      // re-evaluate exactly at the same iterate
                 continue;

@@ -269,7 +269,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
             }
             int st = 1, it = 0;
             double laststep = 1e300;     /* alpha |dU|_inf / max(1, |dU|_inf) of the previous iteration */
-            double rdn_prev = 1e300, lastscale = 1.0;   /* previous dual residual, 1 - alpha of the previous step */
+            double rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0;   /* previous dual residual, 1 - alpha of the previous step */
             double nh = 1.0, rpn = 0;
             for (int i = 0; i < m; ++i) {       /* starting point: s = max(h - G z, 1), lam = 10 / s */
                 double a = 0;
@@ -315,7 +315,9 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                        step was nearly full counts as converged; the step criterion vouches for z) */
                     int stalled = rdn >= 0.5 * rdn_prev && lastscale <= 0.1;
                     rdn_prev = rdn;
-                    if (mu <= gap_tol && (rdn <= res_tol * ndd || stalled) && rpn <= 100.0 * res_tol * nh && laststep <= 1e-6) { st = 0; break; }
+                    int pstalled = rpn >= 0.5 * rpn_prev && lastscale <= 0.1 && rpn <= 1e-7 * nh;
+                    rpn_prev = rpn;
+                    if (mu <= gap_tol && (rdn <= res_tol * ndd || stalled) && (rpn <= 100.0 * res_tol * nh || pstalled) && laststep <= 1e-6) { st = 0; break; }
                 }
                 /* Phi = H + G' D~ G */
                 for (int i = 0; i < m; ++i) {
