@@ -195,7 +195,7 @@ struct Qp {
             for (int i = w.lane; i <= d.Hc; i += WAVE) jlt[i] = m.jl[i];
             for (int i = w.lane; i < d.Hp; i += WAVE) blkt[i] = m.blk[i];
         }
-        if (pair_on(P_X)) {
+        if (pair_on(P_X) && m.exT) {      // (K2 of a specialisation with terminal rows runs before they are built)
             const int ne = d.Hc * d.nxh * d.nu;
             const double* e = m.exT + (size_t)b * ne;
             for (int i = w.lane; i < ne; i += WAVE) sm[c.exT + i] = e[i];

@@ -401,6 +401,17 @@ def test_random_controller_families_on_gpu(seed, hiplib):
     assert e is None or e <= TOL
 
 
+@pytest.mark.parametrize("seed", [2000, 2004, 2014, 2021, 2028, 2083])
+def test_families_near_wave_limit(seed, hiplib):
+    """Families drawn at 49 <= nZ̃ <= 64 (four 16-wide tiles on the matrix-core paths, the largest
+    specialisations the library builds).  2028 (nu=2, ny=3, Hp=Hc=30) and 2083 (nu=3, ny=3, Hp=26,
+    Hc=21, nZ̃ = 64) are the two that exposed the out-of-line cholesky()/EtDE_add() miscompilation
+    (csrc/mpcqp_types.h, MPCQP_HD)."""
+    from tests.parity_util import run_random_case
+    e = run_random_case(seed, B=3, large=True)
+    assert e is None or e <= TOL
+
+
 @pytest.mark.parametrize("seed", list(range(6)))
 def test_random_horizon_wide_forms_on_gpu(seed, hiplib):
     """Time-varying Umin/Umax/Ymin/Ymax vectors with ±Inf holes, R̂y / R̂u / D̂ trajectories, a
