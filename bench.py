@@ -80,7 +80,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    cfg = synth.CONFIGS[args.config]
+    cfg = synth.get_config(args.config)
     B = args.batch
     bt = synth.make_batch(cfg, B, seed=args.seed, lo=rank * B)      # this rank's shard
     neps = 0 if np.isinf(cfg.Cwt) else 1

@@ -101,7 +101,7 @@ struct StaticDims {
 constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs (cs only stored with runtime dims)
 
 struct Carve {
-    int S, Phi, zero, z, dz, q, zlo, zhi, gt, rd, F, tA[NPAIR], tB[NPAIR], ucum, exT, Wm;
+    int S, Phi, zero, z, dz, q, zlo, zhi, gt, rd, dinv, F, tA[NPAIR], tB[NPAIR], ucum, exT, Wm;
     int rows[NROWARR];
     int jl, blk;               // int tables (offset in doubles, storage as int)
     int total;                 // doubles
@@ -129,6 +129,7 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     c.zero = take(4);                             // four zeros: where masked lanes of a chunk read point
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
     c.gt = take(d.nZ); c.rd = take(d.nZ);
+    c.dinv = take(d.nZ > WAVE ? d.nZ : 0);        // 1/L[k][k] of the several-rows-per-lane factorisation
     c.zlo = c.dz; c.zhi = c.gt;                   // only live while the rows are being set up
     c.F = -1;                                     // placed below (aliases the Ŷ-row scratch when it exists)
     MPCQP_UNROLL
@@ -762,6 +763,7 @@ struct Step {
     double delta;
     double prof_[16] = {0};   // phase cycle counters (profiling builds)
     double myinvd = 0.0;      // 1/L[lane][lane] of the current factor
+    bool chol_broke = false;  // the last factorisation met a pivot below its threshold (wave-uniform)
 
     MPCQP_HD Step(Qp<W, DM>& qp_)
         : qp(qp_), w(qp_.w), d(qp_.d), m(qp_.m), b(qp_.b), sm(qp_.sm), c(qp_.c),
@@ -1381,6 +1383,9 @@ struct Step {
     // Pivot guard: a non-positive pivot (float64 breakdown of the normal equations) freezes that
     // coordinate for this Newton step (zero column, 1/L = 1e-32) instead of poisoning the factor.
     MPCQP_HD void cholesky() {
+        if constexpr (!DM::is_static) {
+            if (d.nZ > WAVE) { cholesky_big(); return; }
+        }
         MPCQP_TIC();
         const int n = d.nZ;
         const int i = w.lane;
@@ -1439,6 +1444,7 @@ struct Step {
             }
             w.sync();
         }
+        chol_broke = w.any(act && myinvd <= 1e-32);
         MPCQP_TOC(6);
     }
 
@@ -1457,6 +1463,9 @@ struct Step {
     // block the zero diagonal slot / pad entries do the masking.  The chunk of the next group is fetched ahead of the dependent chain, which is then
     // v_mul -> v_readlane -> v_fma per column.
     MPCQP_HD void solve_into_dz() {
+        if constexpr (!DM::is_static) {
+            if (d.nZ > WAVE) { solve_big(); return; }
+        }
         MPCQP_TIC();
         const int n = d.nZ;
         const int i = w.lane;
@@ -1516,6 +1525,71 @@ struct Step {
         }
         if (act) dz[i] = r;
         w.sync();
+        MPCQP_TOC(7);
+    }
+
+    // ---- nZ > 64 (runtime-dims kernel only): lane l owns the rows l, l + 64, ...  ----------------
+    // Right-looking column Cholesky in place: the factor is stored strictly below the diagonal,
+    // 1/L[k][k] goes to the LDS vector dinv (same pivot guard as cholesky()).  Column k is scaled
+    // by its owners, then every lane removes it from the rows it owns; L[j][k] is a broadcast read
+    // (all lanes walk j = k+1.. in step), the row entries Phi[i][j] are contiguous in j.
+    MPCQP_HD void cholesky_big() {
+        MPCQP_TIC();
+        const int n = d.nZ;
+        double* dinv = sm + c.dinv;
+        for (int k = w.lane; k < n; k += WAVE) dinv[k] = 1e-14 * fabs(Phi[pk(k, k)]);   // pivot thresholds
+        w.sync();
+        chol_broke = false;
+        MPCQP_NOUNROLL
+        for (int k = 0; k < n; ++k) {
+            const double pv = Phi[pk(k, k)];
+            const double idl = (pv > dinv[k]) ? 1.0 / sqrt(pv) : 0.0;
+            chol_broke = chol_broke || idl == 0.0;
+            w.sync();                                    // every lane has read the threshold
+            for (int i = w.lane; i < n; i += WAVE) {
+                if (i > k) Phi[pk(i, k)] *= idl;
+                else if (i == k) dinv[k] = fmax(idl, 1e-32);
+            }
+            w.sync();
+            for (int i = w.lane; i < n; i += WAVE) {
+                if (i <= k) continue;
+                const double lik = Phi[pk(i, k)];
+                double* Pi = Phi + pk(i, 0);
+                for (int j = k + 1; j <= i; ++j) Pi[j] -= lik * Phi[pk(j, k)];
+            }
+            w.sync();
+        }
+        MPCQP_TOC(6);
+    }
+
+    // dz <- Phi^{-1} gt with the factor of cholesky_big(): column sweeps on the LDS vector dz
+    MPCQP_HD void solve_big() {
+        MPCQP_TIC();
+        const int n = d.nZ;
+        const double* dinv = sm + c.dinv;
+        for (int i = w.lane; i < n; i += WAVE) dz[i] = gt[i];
+        w.sync();
+        MPCQP_NOUNROLL
+        for (int k = 0; k < n; ++k) {                    // L y = g
+            const double yk = dz[k] * dinv[k];
+            w.sync();
+            for (int i = w.lane; i < n; i += WAVE) {
+                if (i > k) dz[i] -= Phi[pk(i, k)] * yk;
+                else if (i == k) dz[i] = yk;
+            }
+            w.sync();
+        }
+        MPCQP_NOUNROLL
+        for (int k = n - 1; k >= 0; --k) {               // L' x = y
+            const double xk = dz[k] * dinv[k];
+            w.sync();
+            const double* Lk = Phi + pk(k, 0);
+            for (int j = w.lane; j <= k; j += WAVE) {
+                if (j < k) dz[j] -= Lk[j] * xk;
+                else dz[j] = xk;
+            }
+            w.sync();
+        }
         MPCQP_TOC(7);
     }
 
@@ -1608,7 +1682,8 @@ struct Step {
             iters_out = 0;
             return ST_OPTIMAL;
         }
-        // warm start kept in a register for the error path (nZ <= 64: one entry per lane)
+        // warm start kept in a register for the error path (nZ <= 64: one entry per lane; larger
+        // problems read it again from the caller's Z̃, which is only overwritten after the solve)
         const double zws = (w.lane < n) ? z[w.lane] : 0.0;
         double mu, rpn, rdn, ndd;
         // ---- starting point (no factorisation): slacks of the warm start pushed to >= 1,
@@ -1678,6 +1753,9 @@ struct Step {
                 rp_stalled = rpn >= 0.5 * rpn_last && rdscale_c <= 0.1 && rpn <= 1e-7 * nh;
                 rpn_last = rpn;
             }
+#ifdef MPCQP_EMU_TRACE
+            if (w.lane == 0) printf("it %d mu %.3e rp %.3e rd %.3e (nd %.2e nh %.2e) exact %d ver %d rdst %d rpst %d step %.2e\n", it, mu, rpn, rdn, ndd, nh, (int)exact, (int)verified, (int)rd_stalled, (int)rp_stalled, step_c);
+#endif
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
             // Converged: gap and residuals below their targets AND the last Newton step no longer moves
             // the inputs, alpha |dU|_inf <= 1e-6 max(1, |dU|_inf).  (Residual targets alone leave 1e-6-size
@@ -1694,11 +1772,20 @@ struct Step {
                 exact = true;                      // re-evaluate exactly at the same iterate
                 continue;
             }
-            if (!verified) load_H();
-            add_GtDG([&](Row& r) {
-                return r.lam * row_wi(r);                   // D~ = D / (1 + δ D)
-            });
-            cholesky();
+            // A pivot below its threshold means Phi = H̃ + G'D~G left float64's range (rows held at
+            // D~ = 1/δ stack up to 1e14 on the diagonal of long horizons): the factorisation is redone
+            // with a 100 times larger dual regularisation, which caps D~ lower and biases nothing -- δ
+            // multiplies the multiplier step, which vanishes at the optimum.  (Not met on the BASELINE
+            // configs; about one family in 20 at nZ~ ~ 100.)
+            for (int attempt = 0;; ++attempt) {
+                if (!verified || attempt) load_H();
+                add_GtDG([&](Row& r) {
+                    return r.lam * row_wi(r);               // D~ = D / (1 + δ D)
+                });
+                cholesky();
+                if (!chol_broke || attempt == 2 || delta >= 1e-8) break;
+                delta *= 100.0;
+            }
             // predictor: rc = s lam
             newton([&](Row& r) { return r.s * r.lam; });
             double amin = 1.0, ppsum = 0.0;
@@ -1771,6 +1858,8 @@ struct Step {
         if (status == ST_ITERATION_LIMIT && !(rpn <= 1e-6 * nh)) status = ST_ERROR;
         if (status == ST_ERROR) {
             if (w.lane < n) z[w.lane] = zws;          // mpc.Z̃ .= Z̃s   execute.jl:499-500
+            for (int k = w.lane + WAVE; k < n; k += WAVE)
+                z[k] = cold ? 0.0 : (k < d.nDU - d.nu) ? Zg[k + d.nu] : (k >= d.nDU) ? Zg[k] : 0.0;
             w.sync();
         }
         if ((d.flags & 8u) && io.lam_out) {           // multipliers for the next period's start

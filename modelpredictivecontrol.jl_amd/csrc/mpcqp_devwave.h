@@ -63,6 +63,7 @@ struct DevWave {
         return v;
     }
     __device__ __forceinline__ double bcast(double v, int src) { return lane_value(v, src); }
+    __device__ __forceinline__ bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 };
 
 extern __shared__ __attribute__((aligned(16))) double mpcqp_smem[];

@@ -128,7 +128,9 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
         nb[in->Hc - 1] = in->Hp - in->Hc + 1;          // construct.jl:653-660
     }
     const int nZ = in->nu * in->Hc + in->neps;
-    if (nZ > WAVE) return MPCQP_ERR_UNSUPPORTED;       // one Cholesky row per lane
+    // nZ~ <= 64: one Cholesky row per lane (specialised kernels); above that the runtime-dims kernel
+    // gives every lane several rows, as long as the problem fits the 160 KB of LDS (checked in layout_rows)
+    if (nZ > 4 * WAVE) return MPCQP_ERR_UNSUPPORTED;
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (in->device < 0 || in->device >= ndev) return MPCQP_ERR_ARG;

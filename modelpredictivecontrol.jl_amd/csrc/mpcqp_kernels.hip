@@ -166,7 +166,7 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
         }
         MPCQP_SPECIALIZATIONS(X)
 #undef X
-        if (d.nw == 0)       // (custom linear constraints run on the runtime-dims kernel)
+        if (d.nw == 0 && d.nZ <= WAVE)   // (custom linear constraints and nZ~ > 64 run on the runtime-dims kernel)
             if (const SpecLib* sl = jit_specialise(d)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
     }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);

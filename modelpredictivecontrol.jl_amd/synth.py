@@ -49,6 +49,16 @@ C3 = Config("C3: nx=12 nu=4 ny=4 Hp=30 Hc=10, soft ymax + hard umin/umax", nx=12
 CONFIGS = {"C2": C2, "C3": C3}
 
 
+def get_config(name: str) -> Config:
+    """A named BASELINE config, or "nx,nu,ny,Hp,Hc" for a C3-style workload (soft ymax, hard
+    umin/umax) of other dimensions -- used to time specialisations other than the headline one."""
+    if name in CONFIGS:
+        return CONFIGS[name]
+    nx, nu, ny, Hp, Hc = (int(v) for v in name.split(","))
+    return Config(f"custom: nx={nx} nu={nu} ny={ny} Hp={Hp} Hc={Hc}, soft ymax + hard umin/umax",
+                  nx=nx, nu=nu, ny=ny, Hp=Hp, Hc=Hc, umin=-1.0, umax=1.0, ymax=1.0)
+
+
 def _stable_A(rng, n, nb):
     """nb random stable matrices: real block-diagonal (1x1 and 2x2 rotation blocks) with moduli
     U(0.5, 0.98), rotated by a random orthogonal similarity."""

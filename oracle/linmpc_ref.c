@@ -142,8 +142,9 @@ void linmpc_ref_destroy(void* p) {
 static int chol(double* A, int n) {     /* in place, lower, row-major full */
     for (int k = 0; k < n; ++k) {
         double v = A[k * n + k];
+        const double thr = 1e-14 * fabs(v);   /* same pivot threshold as the kernels (Step::cholesky) */
         for (int j = 0; j < k; ++j) v -= A[k * n + j] * A[k * n + j];
-        if (!(v > 0)) return -1;
+        if (!(v > thr)) return -1;
         double d = sqrt(v);
         A[k * n + k] = d;
         for (int i = k + 1; i < n; ++i) {
@@ -172,7 +173,7 @@ static void chol_solve(const double* L, double* x, int n) {
  * out = optimum (or shifted warm start on status 2).  Returns the number of status != 0. */
 int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const double* Ry,
                     double* Z, double* u0, int* status, int* iters, int cold, int nthreads,
-                    double gap_tol, double res_tol, double delta, int max_iter) {
+                    double gap_tol, double res_tol, double delta0, int max_iter) {
     ref_t* r = (ref_t*)p;
     const int B = r->B, nxh = r->nxh, nu = r->nu, ny = r->ny, Hp = r->Hp, Hc = r->Hc;
     const int nZ = r->nZ, nDU = r->nDU, nU = r->nU, nY = r->nY, neps = r->neps, mmax = r->m;
@@ -201,6 +202,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
         double *rd = (double*)malloc(nZ * sizeof(double)), *gt = (double*)malloc(nZ * sizeof(double));
 #pragma omp for schedule(dynamic, 8)
         for (int b = 0; b < B; ++b) {
+            double delta = delta0;       /* may be raised for this controller, see the factorisation */
             const double* Eb = r->E + (size_t)b * nY * nDU;
             const double* Kb = r->K + (size_t)b * nY * nxh;
             const double* Hb = r->H + (size_t)b * nZ * nZ;
@@ -319,22 +321,30 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                     rpn_prev = rpn;
                     if (mu <= gap_tol && (rdn <= res_tol * ndd || stalled) && (rpn <= 100.0 * res_tol * nh || pstalled) && laststep <= 1e-6) { st = 0; break; }
                 }
-                /* Phi = H + G' D~ G */
-                for (int i = 0; i < m; ++i) {
-                    double D = lam[i] / s[i];
-                    wv[i] = 1.0 / (1.0 + delta * D);
-                    Dt[i] = D * wv[i];
-                }
-                memcpy(Phi, Hb, (size_t)nZ * nZ * sizeof(double));
-                for (int i = 0; i < m; ++i) {
-                    const double* g = G + (size_t)i * nZ;
-                    for (int k = 0; k < nZ; ++k) {
-                        double gk = Dt[i] * g[k];
-                        if (gk == 0) continue;
-                        for (int j = 0; j <= k; ++j) Phi[k * nZ + j] += gk * g[j];
+                /* a pivot below its threshold: Phi left float64's range; redo the factorisation with a
+                   100x larger dual regularisation (same rule as Step::run of the kernels) */
+                int broke = 0;
+                for (int attempt = 0;; ++attempt) {
+                    /* Phi = H + G' D~ G */
+                    for (int i = 0; i < m; ++i) {
+                        double D = lam[i] / s[i];
+                        wv[i] = 1.0 / (1.0 + delta * D);
+                        Dt[i] = D * wv[i];
                     }
+                    memcpy(Phi, Hb, (size_t)nZ * nZ * sizeof(double));
+                    for (int i = 0; i < m; ++i) {
+                        const double* g = G + (size_t)i * nZ;
+                        for (int k = 0; k < nZ; ++k) {
+                            double gk = Dt[i] * g[k];
+                            if (gk == 0) continue;
+                            for (int j = 0; j <= k; ++j) Phi[k * nZ + j] += gk * g[j];
+                        }
+                    }
+                    broke = chol(Phi, nZ);
+                    if (!broke || attempt == 2 || delta >= 1e-8) break;
+                    delta *= 100.0;
                 }
-                if (chol(Phi, nZ)) { st = 2; break; }
+                if (broke) { st = 2; break; }
                 double smu = 0;
                 for (int phase = 0; phase < 2; ++phase) {
                     /* rhs = -rd + G'(w rc/s - D~ rp) */

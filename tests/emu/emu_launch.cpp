@@ -65,6 +65,7 @@ struct EmuWave {
         sync();
         return s;
     }
+    bool any(bool p) { return isum(p ? 1 : 0) != 0; }
     double bcast(double v, int src) {
         sh->xd[lane] = v; sync();
         double s = sh->xd[src];

@@ -202,7 +202,7 @@ def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
     return out
 
 
-def run_random_case(seed, lib=None, B=3, small=False, large=False):
+def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False):
     """One randomly drawn controller family (dimensions, move blocking, which bounds exist, hard /
     soft mix, terminal bounds, measured disturbance, weights, Cwt finite or Inf) stepped twice
     through the C-ABI and through the oracle; returns the worst relative ΔU error over the steps
@@ -212,7 +212,10 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False):
     nx = int(rng.integers(2, 4 if small else 7)); nu = int(rng.integers(1, 3 if small else 5))
     ny = int(rng.integers(1, 3 if small else 4)); nd = int(rng.integers(0, 2))
     Hp = int(rng.integers(4, 9 if small else 24))
-    if large:                               # close to the one-wavefront limit nZ~ = 64
+    if huge:                                # beyond one row per lane: 64 < nZ~ <= ~130
+        nu = int(rng.integers(2, 5)); Hp = int(rng.integers(32, 46))
+        Hc = min(Hp, int(rng.integers(66, 130)) // nu)
+    elif large:                             # close to the one-wavefront limit nZ~ = 64
         nu = int(rng.integers(2, 5)); Hp = int(rng.integers(16, 31))
         Hc = min(Hp, 63 // nu) - int(rng.integers(0, 3))
     elif rng.random() < 0.5:

@@ -249,6 +249,14 @@ def test_random_controller_families_on_cpu_emulator(seed, emulib):
     assert e is None or e <= 1e-5
 
 
+def test_family_beyond_one_row_per_lane_on_cpu_emulator(emulib):
+    """nZ̃ = 76 > 64 (nu = 3, Hc = 25): several factorisation rows per lane (Step::cholesky_big /
+    solve_big of the runtime-dimension kernel)."""
+    from tests.parity_util import run_random_case
+    e = run_random_case(3004, lib=emulib, B=1, huge=True)
+    assert e is not None and e <= 1e-5
+
+
 @pytest.mark.parametrize("seed", [0, 1])
 def test_random_horizon_wide_forms_on_cpu_emulator(seed, emulib):
     """Time-varying bound vectors with holes, R̂y / R̂u / D̂ trajectories, block-diagonal M_Hp and

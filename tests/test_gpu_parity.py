@@ -269,7 +269,7 @@ def test_abi_error_codes(hiplib):
     with pytest.raises(mpcqp.MpcqpError, match="dimension"):
         H(4, 3, 1, 1, 0, Hp=5, Hc=2, nb=[1, 2])         # sum(nb) != Hp
     with pytest.raises(mpcqp.MpcqpError, match="not supported"):
-        H(4, 3, 4, 1, 0, Hp=30, Hc=20)                  # nZ > 64
+        H(4, 3, 4, 1, 0, Hp=80, Hc=70)                  # nZ > 256
     h = H(4, 3, 1, 1, 0, Hp=5, Hc=2)
     with pytest.raises(mpcqp.MpcqpError, match="must be set before"):
         h.step(np.zeros((4, 3)), np.zeros((4, 1)), np.zeros((4, 5)), np.zeros((4, 3)))
@@ -409,6 +409,16 @@ def test_families_near_wave_limit(seed, hiplib):
     (csrc/mpcqp_types.h, MPCQP_HD)."""
     from tests.parity_util import run_random_case
     e = run_random_case(seed, B=3, large=True)
+    assert e is None or e <= TOL
+
+
+@pytest.mark.parametrize("seed", [3000, 3004, 3008, 3010])
+def test_families_beyond_one_row_per_lane(seed, hiplib):
+    """64 < nZ̃ <= ~130 (e.g. nu = 3, Hc = 35): the runtime-dimension kernel gives every lane several
+    rows of the factorisation (Step::cholesky_big / solve_big); same families, same oracle, same
+    tolerance as the one-row-per-lane kernels."""
+    from tests.parity_util import run_random_case
+    e = run_random_case(seed, B=3, huge=True)
     assert e is None or e <= TOL
 
 
