@@ -471,21 +471,42 @@ struct Qp {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (DM::is_static) return EtDE_add_mfma(dd, P, scale, tb);
 #endif
+        // Strips of four: the packed layout (pk) stores row i as (i/4 + 1) aligned chunks of four
+        // columns, chunk s of the whole triangle at P[4s..4s+3].  A lane takes a strip (i, ip0..ip0+3):
+        // the product E[r,i] dd[r] is formed once per row r of E and feeds four accumulators.
         const int ny = d.ny, nu = d.nu, nDU = d.nDU;
-        const int ntri = nDU * (nDU + 1) / 2;
-        for (int idx = w.lane; idx < ntri; idx += WAVE) {
-            int i, ip;
-            unpack_idx(idx, i, ip);
-            const int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
-            const int t0 = jl(j), off2 = jl(j) - jl(j2);       // j >= j2  =>  jl[j] >= jl[j2]
-            double acc = 0.0;
-            for (int t = t0; t < d.Hp; ++t) {
-                const double* S1 = S + (t - t0) * sp + cc;
-                const double* S2 = S + (t - t0 + off2) * sp + c2;
-                const double* dt = dd + t * ny;
-                for (int a = 0; a < ny; ++a) acc += S1[a * rs] * dt[a] * S2[a * rs];
+        const int nstrip = pk_size(nDU) / 4;
+        for (int st = w.lane; st < nstrip; st += WAVE) {
+            int g = (int)((sqrt(1.0 + 2.0 * st) - 1.0) * 0.5);      // 2g(g+1) <= st < 2(g+1)(g+2)
+            while (2 * g * (g + 1) > st) --g;
+            while (2 * (g + 1) * (g + 2) <= st) ++g;
+            const int rem = st - 2 * g * (g + 1);
+            const int i = 4 * g + rem / (g + 1), ip0 = 4 * (rem % (g + 1));
+            if (i >= nDU) continue;
+            const int j = i / nu, cc = i - j * nu, t0 = jl(j);
+            const double* S2[4];
+            MPCQP_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const int ip = ip0 + u <= i ? ip0 + u : i;          // pad columns: any valid one, not stored
+                const int j2 = ip / nu, c2 = ip - j2 * nu;
+                S2[u] = S + (t0 - jl(j2)) * sp + c2;                // j >= j2  =>  jl[j] >= jl[j2]
             }
-            P[pk(i, ip)] += scale * acc;
+            const double* S1 = S + cc;
+            const double* dt = dd + t0 * ny;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int t = t0; t < d.Hp; ++t) {
+                for (int a = 0; a < ny; ++a) {
+                    const double pr = S1[a * rs] * dt[a];
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 4; ++u) acc[u] = fma(pr, S2[u][a * rs], acc[u]);
+                }
+                S1 += sp; dt += ny;
+                MPCQP_UNROLL
+                for (int u = 0; u < 4; ++u) S2[u] += sp;
+            }
+            MPCQP_UNROLL
+            for (int u = 0; u < 4; ++u)
+                if (ip0 + u <= i) P[4 * st + u] += scale * acc[u];
         }
         return -1;
     }
@@ -1529,36 +1550,49 @@ struct Step {
     }
 
     // ---- nZ > 64 (runtime-dims kernel only): lane l owns the rows l, l + 64, ...  ----------------
-    // Right-looking column Cholesky in place: the factor is stored strictly below the diagonal,
-    // 1/L[k][k] goes to the LDS vector dinv (same pivot guard as cholesky()).  Column k is scaled
-    // by its owners, then every lane removes it from the rows it owns; L[j][k] is a broadcast read
-    // (all lanes walk j = k+1.. in step), the row entries Phi[i][j] are contiguous in j.
+    // Left-looking column Cholesky in place.  For column k every lane forms, for each of its rows
+    // i >= k, the dot product of row i and row k over the finished columns j < k (both contiguous in
+    // the packed layout, row k a broadcast read; register accumulation, no LDS read-modify-write
+    // chain) and stores Phi[i][k] - dot; the owner of row k turns its entry into 1/L[k][k] (LDS vector
+    // dinv, same pivot guard as cholesky()), then the column is scaled.  The factor is stored
+    // strictly below the diagonal.
     MPCQP_HD void cholesky_big() {
         MPCQP_TIC();
         const int n = d.nZ;
         double* dinv = sm + c.dinv;
-        for (int k = w.lane; k < n; k += WAVE) dinv[k] = 1e-14 * fabs(Phi[pk(k, k)]);   // pivot thresholds
-        w.sync();
-        chol_broke = false;
+        bool broke = false;
         MPCQP_NOUNROLL
         for (int k = 0; k < n; ++k) {
-            const double pv = Phi[pk(k, k)];
-            const double idl = (pv > dinv[k]) ? 1.0 / sqrt(pv) : 0.0;
-            chol_broke = chol_broke || idl == 0.0;
-            w.sync();                                    // every lane has read the threshold
-            for (int i = w.lane; i < n; i += WAVE) {
-                if (i > k) Phi[pk(i, k)] *= idl;
-                else if (i == k) dinv[k] = fmax(idl, 1e-32);
+            const double* Lk = Phi + pk(k, 0);
+            const int k4 = k & ~3;
+            for (int i = w.lane + ((k - w.lane + WAVE - 1) / WAVE) * WAVE; i < n; i += WAVE) {   // first owned row >= k
+                const double* Li = Phi + pk(i, 0);
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                for (int j = 0; j < k4; j += 4) {
+                    double x[4], y[4];
+                    load4(Li + j, x); load4(Lk + j, y);
+                    a0 = fma(x[0], y[0], a0); a1 = fma(x[1], y[1], a1);
+                    a2 = fma(x[2], y[2], a2); a3 = fma(x[3], y[3], a3);
+                }
+                for (int j = k4; j < k; ++j) a0 = fma(Li[j], Lk[j], a0);
+                const double orig = Li[k];
+                const double v = orig - ((a0 + a1) + (a2 + a3));
+                if (i == k) {
+                    const bool ok = v > 1e-14 * fabs(orig);
+                    broke = broke || !ok;
+                    dinv[k] = ok ? 1.0 / sqrt(v) : 0.0;
+                } else {
+                    Phi[pk(i, k)] = v;
+                }
             }
             w.sync();
-            for (int i = w.lane; i < n; i += WAVE) {
-                if (i <= k) continue;
-                const double lik = Phi[pk(i, k)];
-                double* Pi = Phi + pk(i, 0);
-                for (int j = k + 1; j <= i; ++j) Pi[j] -= lik * Phi[pk(j, k)];
-            }
+            const double idl = dinv[k];
+            for (int i = w.lane + ((k + 1 - w.lane + WAVE - 1) / WAVE) * WAVE; i < n; i += WAVE) Phi[pk(i, k)] *= idl;
             w.sync();
+            if (w.lane == 0) dinv[k] = fmax(idl, 1e-32);
         }
+        w.sync();
+        chol_broke = w.any(broke);
         MPCQP_TOC(6);
     }
 

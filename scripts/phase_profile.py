@@ -7,7 +7,7 @@ from tests.parity_util import make_controller
 lib = mpcqp.api.load_library(os.path.join('modelpredictivecontrol.jl_amd', 'lib', 'libmpcqp_prof.so'))
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-cfg = synth.CONFIGS[name]; bt = synth.make_batch(cfg, B, seed=0)
+cfg = synth.get_config(name); bt = synth.make_batch(cfg, B, seed=0)
 mpc = make_controller(cfg, bt, lib=lib, cold_start=True)
 mpc.lastu0 = bt["lastu0"].copy()
 for rep in range(2):
