@@ -1763,6 +1763,18 @@ struct Step {
         bool rd_stalled = false, rp_stalled = false;
         double rpn_last = 1e300;
         while (it < d.max_iter) {
+            // A pivot below its threshold in the last factorisation means Phi = H̃ + G'D~G left
+            // float64's range (rows held at D~ = 1/δ stack up to 1e14 on the diagonal of long
+            // horizons).  The guarded factor kept that step finite (and the step-length rules kept
+            // s, lam positive); from here on the dual regularisation is 100 times larger (at most
+            // twice), which caps D~ lower and biases nothing -- δ multiplies the multiplier step,
+            // which vanishes at the optimum -- and the residuals are re-evaluated exactly.  (Not met
+            // on the BASELINE configs; about one family in 20 at nZ~ ~ 100.)
+            if (chol_broke && delta < 1e-8) {
+                delta *= 100.0;
+                exact = true;
+                chol_broke = false;
+            }
             if (exact) {
                 residuals(mu, rpn, rdn, ndd);      // also stages H̃ in Phi
                 exact = false;
@@ -1787,9 +1799,6 @@ struct Step {
                 rp_stalled = rpn >= 0.5 * rpn_last && rdscale_c <= 0.1 && rpn <= 1e-7 * nh;
                 rpn_last = rpn;
             }
-#ifdef MPCQP_EMU_TRACE
-            if (w.lane == 0) printf("it %d mu %.3e rp %.3e rd %.3e (nd %.2e nh %.2e) exact %d ver %d rdst %d rpst %d step %.2e\n", it, mu, rpn, rdn, ndd, nh, (int)exact, (int)verified, (int)rd_stalled, (int)rp_stalled, step_c);
-#endif
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn)) { status = ST_ERROR; break; }
             // Converged: gap and residuals below their targets AND the last Newton step no longer moves
             // the inputs, alpha |dU|_inf <= 1e-6 max(1, |dU|_inf).  (Residual targets alone leave 1e-6-size
@@ -1806,20 +1815,11 @@ struct Step {
                 exact = true;                      // re-evaluate exactly at the same iterate
                 continue;
             }
-            // A pivot below its threshold means Phi = H̃ + G'D~G left float64's range (rows held at
-            // D~ = 1/δ stack up to 1e14 on the diagonal of long horizons): the factorisation is redone
-            // with a 100 times larger dual regularisation, which caps D~ lower and biases nothing -- δ
-            // multiplies the multiplier step, which vanishes at the optimum.  (Not met on the BASELINE
-            // configs; about one family in 20 at nZ~ ~ 100.)
-            for (int attempt = 0;; ++attempt) {
-                if (!verified || attempt) load_H();
-                add_GtDG([&](Row& r) {
-                    return r.lam * row_wi(r);               // D~ = D / (1 + δ D)
-                });
-                cholesky();
-                if (!chol_broke || attempt == 2 || delta >= 1e-8) break;
-                delta *= 100.0;
-            }
+            if (!verified) load_H();
+            add_GtDG([&](Row& r) {
+                return r.lam * row_wi(r);                   // D~ = D / (1 + δ D)
+            });
+            cholesky();
             // predictor: rc = s lam
             newton([&](Row& r) { return r.s * r.lam; });
             double amin = 1.0, ppsum = 0.0;

@@ -106,16 +106,24 @@ def ipm(H, q, G, h, z0=None, mu_tol=1e-14, res_tol=1e-10, maxit=200):
                 stall += 1
             if best is None or mu < best[0]:
                 best = (mu, z.copy(), lam.copy(), s.copy())
-            if mu <= mu_tol or stall >= 3:
+            if mu <= mu_tol or (stall >= 3 and best[0] <= 1e-9):   # stalled at the float64 floor
                 status = OPTIMAL
                 it -= 1
                 break
+        # jammed well above the floor (products s_i lam_i spread over many decades, steps cut short
+        # by the boundary): a pure centring step (sigma = 1) restores the neighbourhood
+        centre = stall >= 3 and mu > 1e-9
+        if centre:
+            stall = 0
         try:
-            dz, ds, dl = newton(s, lam, rd, rp, s * lam)          # predictor
-            a = _maxstep(s, ds, lam, dl)
-            mu_aff = (s + a * ds) @ (lam + a * dl) / m
-            sigma = (mu_aff / mu) ** 3
-            dz, ds, dl = newton(s, lam, rd, rp, s * lam + ds * dl - sigma * mu)   # corrector
+            if centre:
+                dz, ds, dl = newton(s, lam, rd, rp, s * lam - mu)
+            else:
+                dz, ds, dl = newton(s, lam, rd, rp, s * lam)          # predictor
+                a = _maxstep(s, ds, lam, dl)
+                mu_aff = (s + a * ds) @ (lam + a * dl) / m
+                sigma = (mu_aff / mu) ** 3
+                dz, ds, dl = newton(s, lam, rd, rp, s * lam + ds * dl - sigma * mu)   # corrector
         except np.linalg.LinAlgError:
             break
         a = min(1.0, 0.995 * _maxstep(s, ds, lam, dl))
