@@ -7,6 +7,7 @@
 
 #include <dlfcn.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <map>
@@ -107,9 +108,9 @@ static const SpecLib* jit_specialise(const Dims& d) {
         char cmd[2048];
         snprintf(cmd, sizeof cmd,
                  "%s --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -w -I%s "
-                 "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu,%d %s/mpcqp_spec.hip -o %s.tmp 2>&1 && mv %s.tmp %s",
+                 "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu,%d %s/mpcqp_spec.hip -o %s.tmp%d 2>&1 && mv %s.tmp%d %s",
                  hipcc, src.c_str(), d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb, src.c_str(),
-                 so.c_str(), so.c_str(), so.c_str());
+                 so.c_str(), (int)getpid(), so.c_str(), (int)getpid(), so.c_str());   // (ranks of one job may build the same object)
         fprintf(stderr, "[mpcqp] specialising the step kernel for nu=%d ny=%d nxhat=%d Hp=%d Hc=%d "
                         "neps=%d rows=0x%x (one-time, cached in %s)\n",
                 d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, cache.c_str());
