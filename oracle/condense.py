@@ -10,7 +10,9 @@ Parity pin: the reference is Julia (no toolchain in this image, JuMP/OSQP not ve
 cannot be executed here.  This oracle is pinned instead against the reference's own
 known-answer tests (tests/test_oracle_known_answers.py: T1..T9, SURVEY.md section 8c and 8(f3),
 including the 6-digit doctest golden u = 17.577311 of ext/LinearMPCext.jl:255-269 and the
-LQR-equivalence test at atol 1e-5 of test/3_test_predictive_control.jl:498-527).
+LQR-equivalence test at atol 1e-5 of test/3_test_predictive_control.jl:498-527), and against the
+40-sample closed-loop series of the reference's README example taken from its own result figure
+(docs/src/assets/readme_result.svg -> tests/golden/readme_result_series.json).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
 """

@@ -361,3 +361,50 @@ def run_random_case2(seed, lib=None, B=2, small=False):
             assert np.abs(gpu.getinfo()["W"][B - 1] - orc.getinfo()["W"]).max() <= 1e-5
         x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop)
     return worst
+
+
+def readme_example(lib=None, B=2, steps=40):
+    """BASELINE config 0, the reference's README example (README.md:47-74): G(s) = [2 e^{-20s}/(10s+1);
+    10/(4s+1)], Ts = 1, `LinMPC(model, Mwt=[1, 0], Nwt=[0.1])` (defaults Hp = 10 + 20 delays,
+    construct.jl:569-591, Hc = 2, Cwt = 1e5, SteadyKalmanFilter), `setconstraint!(ymax=[Inf, 35])`,
+    `sim!(mpc, 40, [5, 0])` (plot_sim.jl:291-311: evaloutput, preparestate!, moveinput!, both
+    updatestate!).  The oracle loop drives the plant; the batch goes through the C-ABI (estimator
+    steps included) on the same measurements.  Returns the worst |u_abi - u_oracle| and the
+    trajectories (u, y)."""
+    from oracle import estim as es
+    (a1, b1, c1), (a2, b2, c2) = ([float(np.squeeze(v)) for v in es.tf1_zoh(g, tau, 1.0)]
+                                  for g, tau in ((2.0, 10.0), (10.0, 4.0)))
+    nk = 20
+    nx = nk + 2
+    A = np.zeros((nx, nx)); Bu = np.zeros((nx, 1)); C = np.zeros((2, nx))
+    A[0, 0] = a1; Bu[0, 0] = b1
+    A[1, 0] = c1                                  # w_1(k+1) = c1 x1(k); w_{i+1}(k+1) = w_i(k); y1 = w_20
+    for i in range(2, nk + 1):
+        A[i, i - 1] = 1.0
+    C[0, nk] = 1.0
+    A[nk + 1, nk + 1] = a2; Bu[nk + 1, 0] = b2; C[1, nk + 1] = c2
+    model = es.LinModelOracle(A, Bu, C, Ts=1.0)
+    plant = es.LinModelOracle(A, Bu, C, Ts=1.0)
+    kf = es.SteadyKalmanFilterOracle(model)
+    Hp = 10 + int(np.sum(np.abs(np.linalg.eigvals(A)) < 1e-3))
+    kw = dict(Hp=Hp, Hc=2, Mwt=[1.0, 0.0], Nwt=[0.1])
+    orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), lib=lib, **kw)
+    orc.setconstraint(ymax=[np.inf, 35.0]); gpu.setconstraint(ymax=[np.inf, 35.0])
+    gpu.setestimator(rep(kf.Khat))
+    ry = np.array([5.0, 0.0])
+    worst, U, Y = 0.0, [], []
+    for k in range(steps):
+        y = plant.evaloutput()
+        xh = kf.preparestate(y)
+        gpu.preparestate(y)
+        uo = orc.moveinput(xh, ry)
+        ug = gpu.moveinput(None, ry)
+        worst = max(worst, float(np.abs(ug - uo).max()))
+        assert np.all(gpu.status == 0), gpu.status
+        plant.updatestate(uo)
+        kf.updatestate(uo, y)
+        gpu.updatestate(np.tile(uo, (B, 1)), y)
+        U.append(uo.copy()); Y.append(y.copy())
+    return worst, np.array(U), np.array(Y), Hp, kf.nxh

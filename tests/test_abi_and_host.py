@@ -249,6 +249,37 @@ def test_random_controller_families_on_cpu_emulator(seed, emulib):
     assert e is None or e <= 1e-5
 
 
+def _check_readme_example(worst, U, Y, Hp, nxh):
+    assert (Hp, nxh) == (30, 24)                       # 10 + 20 delays; 22 states + 2 output integrators
+    assert worst <= 1e-6                               # ABI vs oracle, every period
+    assert Y[:, 1].max() <= 35.0 + 1e-3                # "y2 should never exceed 35" (README.md:58-59)
+    assert np.all(np.abs(Y[2:8, 1] - 35.0) <= 1e-3)    # ... and the constraint is what limits the transient
+    assert np.all(Y[:21, 0] == 0.0)                    # 20 samples of dead time on y1
+    assert abs(Y[-1, 0] - 5.0) <= 1e-2 and abs(U[-1, 0] - 2.5) <= 1e-2   # ry = [5, 0]: u -> 5/2
+    # The reference's own result figure of this run (docs/src/assets/readme_result.svg; series
+    # extracted by tests/golden/make_readme_series.py).  Pixel -> value through anchors the figure
+    # holds itself (y = 0 during the dead time / at k = 0, the set-point line, the bound line); u has
+    # no anchor, so its 40 samples are compared through the best affine pixel map.  Tolerances are
+    # the reference's: its solve is OSQP at default tolerances (u(0) = 11.195 vs the optimum 11.2).
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "readme_result_series.json")))
+    y1, y2, up = (np.array(g[k]) for k in ("y1_px", "y2_px", "u_px"))
+    y1 = (y1[0] - y1) / (y1[0] - g["ry1_px"]) * 5.0
+    y2 = (y2[0] - y2) / (y2[0] - g["y2max_px"]) * 35.0
+    assert np.abs(y1 - Y[:, 0]).max() <= 5e-3
+    assert np.abs(y2 - Y[:, 1]).max() <= 5e-2
+    A = np.c_[up, np.ones(len(up))]
+    coef = np.linalg.lstsq(A, U[:, 0], rcond=None)[0]
+    assert np.abs(A @ coef - U[:, 0]).max() <= 3e-2
+
+
+def test_readme_example_closed_loop_on_cpu_emulator(emulib):
+    """BASELINE config 0: the reference's README example, `sim!(mpc, 40, [5, 0])`, estimator steps
+    and moveinput! through the C-ABI against the oracle loop."""
+    from tests.parity_util import readme_example
+    _check_readme_example(*readme_example(lib=emulib, B=1))
+
+
 def test_family_beyond_one_row_per_lane_on_cpu_emulator(emulib):
     """nZ̃ = 76 > 64 (nu = 3, Hc = 25): several factorisation rows per lane (Step::cholesky_big /
     solve_big of the runtime-dimension kernel)."""

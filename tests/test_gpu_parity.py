@@ -317,6 +317,15 @@ def test_kalman_closed_loop_on_gpu(hiplib):
         xp = np.einsum("bij,bj->bi", bt["Ahat"], xp) + np.einsum("bij,bj->bi", bt["Bhu"], ug)
 
 
+def test_readme_example_closed_loop_on_gpu(hiplib):
+    """BASELINE config 0: the reference's README example (README.md:47-74), `sim!(mpc, 40, [5, 0])`
+    with the estimator steps and moveinput! on the GPU, against the oracle loop; y2 rides its
+    bound of 35 during the transient, y1 reaches the set point after the 20-sample delay."""
+    from tests.parity_util import readme_example
+    from tests.test_abi_and_host import _check_readme_example
+    _check_readme_example(*readme_example(B=3))
+
+
 def test_on_demand_specialisation(hiplib):
     """Dimensions outside the ahead-of-time list get a compile-time-dims kernel built at first use
     (csrc/mpcqp_spec.hip through the installation's hipcc, cached under lib/spec_cache): odd sizes
