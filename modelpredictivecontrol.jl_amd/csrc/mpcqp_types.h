@@ -17,9 +17,10 @@
 // always_inline: a real call inside the one-wave kernels puts the solver state (the Step / Qp objects
 // the callee reaches through `this`) into scratch memory, and the inliner's size heuristics left
 // cholesky() / EtDE_add() out of line in the larger specialisations (nZ~ > 48).  Those out-of-line
-// builds also returned wrong results on gfx950 (rows of lanes >= 5 corrupted from the first
-// iteration on; the callee's MFMA accumulators live in AGPRs that the kernel's two-waves-per-SIMD
-// register budget does not cover) -- see tests/test_gpu_parity.py::test_families_near_wave_limit.
+// builds also returned wrong results on gfx950 (register state of the lanes >= nx^ corrupted from
+// the first iteration on; not root-caused further -- the callee keeps its MFMA accumulators in AGPRs,
+// which the kernel's two-waves-per-SIMD register budget may not cover) -- see
+// tests/test_gpu_parity.py::test_families_near_wave_limit.
 #define MPCQP_HD __host__ __device__ __attribute__((always_inline))
 #define MPCQP_UNROLL _Pragma("unroll")
 #define MPCQP_UNROLL4 _Pragma("unroll 4")
