@@ -71,6 +71,10 @@ struct StaticDims {
     static constexpr int rs = (NY == 4 && NU == 4) ? 6 : NU;
     static constexpr uint32_t gmask = GMASK;
     static constexpr int default_nb = DNB;          // 1: nb = [1,..,1,Hp-Hc+1]; 0: table in LDS
+    // Zero blocks Σ_{-1} .. Σ_{-(Hc-1)} in front of the table (default move blocking, j_l = l): block
+    // (t - j) of E then exists for every step t and block column j, and the Toeplitz products
+    // (E v, E'w, the matrix-core operands of E'DE) address it without a select on t >= j.
+    static constexpr int zpad = DNB == 1 ? HC - 1 : 0;
     int B, nd, nD, max_iter;
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
@@ -114,6 +118,12 @@ MPCQP_HD inline int stride_S(const DM& d) {
 }
 
 template <class DM>
+MPCQP_HD inline int zpad_S(const DM&) {
+    if constexpr (DM::is_static) return DM::zpad;
+    else return 0;
+}
+
+template <class DM>
 MPCQP_HD inline int rowstride_S(const DM& d) {
     if constexpr (DM::is_static) return DM::rs;
     else return d.nu;
@@ -124,7 +134,7 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     Carve c{};
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
-    c.S = take(d.Hp * stride_S(d));
+    c.S = take((d.Hp + zpad_S(d)) * stride_S(d));   // zero blocks first (StaticDims::zpad)
     c.Phi = take(d.npk);
     c.zero = take(4);                             // four zeros: where masked lanes of a chunk read point
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
@@ -175,8 +185,19 @@ struct Qp {
         : w(w_), d(d_), m(m_), b(b_), sm(sm_), c(make_carve(d_)), sp(stride_S(d_)), rs(rowstride_S(d_)) {
         jlt = reinterpret_cast<int*>(sm + c.jl);
         blkt = reinterpret_cast<int*>(sm + c.blk);
-        S = sm + c.S;
+        S = sm + c.S + zpad_S(d_) * sp;       // block 0; zero blocks at negative indices
         Phi = sm + c.Phi;
+    }
+
+    // four consecutive doubles from a 16-byte aligned LDS address (two ds_read_b128)
+    MPCQP_HD static void load4q(const double* p, double* x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef double v2q_ __attribute__((ext_vector_type(2)));
+        const v2q_ a = reinterpret_cast<const v2q_*>(p)[0], b2 = reinterpret_cast<const v2q_*>(p)[1];
+        x[0] = a.x; x[1] = a.y; x[2] = b2.x; x[3] = b2.y;
+#else
+        x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; x[3] = p[3];
+#endif
     }
 
     MPCQP_HD bool pair_on(int p) const { return (d.gmask >> (2 * p)) & 3u; }
@@ -192,6 +213,7 @@ struct Qp {
             const int blk_ = i / nb_, e = i - blk_ * nb_, a = e / d.nu;
             S[blk_ * sp + a * rs + (e - a * d.nu)] = g[i];
         }
+        for (int i = w.lane; i < zpad_S(d) * sp; i += WAVE) sm[c.S + i] = 0.0;
         if (!d.default_nb) {
             for (int i = w.lane; i <= d.Hc; i += WAVE) jlt[i] = m.jl[i];
             for (int i = w.lane; i < d.Hp; i += WAVE) blkt[i] = m.blk[i];
@@ -257,23 +279,25 @@ struct Qp {
         if constexpr (DM::is_static) {
             if (DM::nu == 4 && DM::nY <= 2 * WAVE && d.default_nb) {
                 // every lane owns rows r0 = lane and r1 = lane + 64: the (wave-uniform) v[j,:]
-                // loads are shared by both rows; a block column j > t reads the zero slot
+                // loads are shared by both rows; a block column j > t reads a zero block (zpad)
                 const int r0 = w.lane, r1 = w.lane + WAVE;
                 const bool ok0 = r0 < DM::nY, ok1 = r1 < DM::nY;
                 const int t0 = (ok0 ? r0 : 0) / DM::ny, a0 = (ok0 ? r0 : 0) % DM::ny;
                 const int t1 = (ok1 ? r1 : 0) / DM::ny, a1 = (ok1 ? r1 : 0) % DM::ny;
-                const int zoff = c.zero - c.S;
+                const double* Sa = S + t0 * sp + a0 * rs;        // block (t - j) at S_[-j * sp]
+                const double* Sb = S + t1 * sp + a1 * rs;
                 double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
-                MPCQP_UNROLL4
+                _Pragma("unroll 2")
                 for (int j = 0; j < DM::Hc; ++j) {
-                    const double* vj = v + j * 4;
-                    const double v0 = vj[0], v1 = vj[1], v2 = vj[2], v3 = vj[3];
-                    const double* Sa = S + ((ok0 && j <= t0) ? (t0 - j) * sp + a0 * rs : zoff);
-                    const double* Sb = S + ((ok1 && j <= t1) ? (t1 - j) * sp + a1 * rs : zoff);
-                    x0 = fma(Sa[0], v0, x0); x1 = fma(Sa[1], v1, x1);
-                    y0 = fma(Sb[0], v0, y0); y1 = fma(Sb[1], v1, y1);
-                    x0 = fma(Sa[2], v2, x0); x1 = fma(Sa[3], v3, x1);
-                    y0 = fma(Sb[2], v2, y0); y1 = fma(Sb[3], v3, y1);
+                    double vv[4], sa[4], sb[4];
+                    load4q(v + j * 4, vv);
+                    load4q(Sa - j * DM::sp, sa);
+                    load4q(Sb - j * DM::sp, sb);
+                    x0 = fma(sa[0], vv[0], x0); x1 = fma(sa[1], vv[1], x1);
+                    y0 = fma(sb[0], vv[0], y0); y1 = fma(sb[1], vv[1], y1);
+                    x0 = fma(sa[2], vv[2], x0); x1 = fma(sa[3], vv[3], x1);
+                    y0 = fma(sb[2], vv[2], y0); y1 = fma(sb[3], vv[3], y1);
+                    if (j % 2 == 1) MPCQP_SCHED_FENCE();     // bounds the loads in flight (registers)
                 }
                 if (ok0) out[r0] = x0 + x1;
                 if (ok1) out[r1] = y0 + y1;
@@ -305,14 +329,17 @@ struct Qp {
                 // of a block column are then added with two quad permutes and lane a keeps c = a.
                 const int k = w.lane < DM::nDU ? w.lane : 0;
                 const int j = k >> 2, a = k & 3;
-                const int zoff = c.zero - c.S;
+                const double* Sb = S - j * sp + a * rs;     // block (t - j): a zero block before the column starts (zpad)
+                const double* wa = wv + a;
                 double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-                MPCQP_UNROLL4
-                for (int t = 0; t < t_hi; ++t) {
-                    const bool ok = t >= j && w.lane < DM::nDU;
-                    const double* Sb = S + (ok ? (t - j) * sp + a * rs : zoff);    // zero slot before the block column starts
-                    const double wt = wv[t * 4 + a];
-                    p0 = fma(Sb[0], wt, p0); p1 = fma(Sb[1], wt, p1); p2 = fma(Sb[2], wt, p2); p3 = fma(Sb[3], wt, p3);
+                MPCQP_UNROLL
+                for (int t = 0; t < DM::Hp; ++t) {
+                    if (t >= t_hi) break;
+                    double sr[4];
+                    load4q(Sb + t * DM::sp, sr);
+                    const double wt = wa[t * 4];
+                    p0 = fma(sr[0], wt, p0); p1 = fma(sr[1], wt, p1); p2 = fma(sr[2], wt, p2); p3 = fma(sr[3], wt, p3);
+                    if (t % 5 == 4) MPCQP_SCHED_FENCE();     // bounds the loads in flight (registers)
                 }
                 p0 = w.quad_sum(p0); p1 = w.quad_sum(p1); p2 = w.quad_sum(p2); p3 = w.quad_sum(p3);
                 const double mine = a == 0 ? p0 : a == 1 ? p1 : a == 2 ? p2 : p3;
@@ -417,7 +444,7 @@ struct Qp {
                     dv = dd[4 * kk + lkp];
                     if (erow) tbv = tb[4 * kk + lkp];
                     MPCQP_UNROLL
-                    for (int J = 0; J <= I1; ++J) e[J] = S[t >= jI[J] ? base + offL[J] : zoff];
+                    for (int J = 0; J <= I1; ++J) e[J] = S[(DM::zpad || t >= jI[J]) ? base + offL[J] : zoff];
                 } else {
                     const int r = 4 * kk + lk;
                     const bool rok = r < NYR;
@@ -427,7 +454,7 @@ struct Qp {
                     if (erow) tbv = rok ? tb[rr] : 0.0;
                     const int base = t * SP + a * RS;
                     MPCQP_UNROLL
-                    for (int J = 0; J <= I1; ++J) e[J] = S[(rok && t >= jI[J]) ? base + offI[J] : zoff];
+                    for (int J = 0; J <= I1; ++J) e[J] = S[(rok && (DM::zpad || t >= jI[J])) ? base + offI[J] : zoff];
                 }
                 MPCQP_UNROLL
                 for (int I = I0; I <= I1; ++I) {
