@@ -136,7 +136,8 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
     c.S = take((d.Hp + zpad_S(d)) * stride_S(d));   // zero blocks first (StaticDims::zpad)
     c.Phi = take(d.npk);
-    c.zero = take(4);                             // four zeros: where masked lanes of a chunk read point
+    c.zero = take(6);                             // four zeros: where masked lanes of a chunk read point; [4]: trash slot
+                                                  // (target of the unconditional tile write-backs' invalid lanes)
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
     c.gt = take(d.nZ); c.rd = take(d.nZ);
     c.dinv = take(d.nZ > WAVE ? d.nZ : 0);        // 1/L[k][k] of the several-rows-per-lane factorisation
@@ -473,17 +474,26 @@ struct Qp {
                 _Pragma("unroll 2")
                 for (int kk = kB; kk < NK; ++kk) kstep(kk, true, true);
             }
+            // write-back: every lane does an unconditional read-modify-write; entries outside the
+            // stored triangle go to the trash slot (no exec-masked region per entry, so the reads of
+            // a tile are issued back to back)
+            double* const trash = sm + c.zero + 4;
             MPCQP_UNROLL
             for (int I = I0; I <= I1; ++I) {
                 const bool eI = erow && I == IE;
                 MPCQP_UNROLL
                 for (int J = 0; J <= I; ++J) {
+                    double* pp_[4];
+                    double old_[4];
                     MPCQP_UNROLL
                     for (int reg = 0; reg < 4; ++reg) {
                         const int i = 16 * I + lk + 4 * reg, ip = 16 * J + li;
-                        if (ip < NDU && ((i < NDU && ip <= i) || (eI && i == NDU)))
-                            P[pk(i, ip)] += scale * acc[I - I0][J][reg];
+                        const bool ok = ip < NDU && ((i < NDU && ip <= i) || (eI && i == NDU));
+                        pp_[reg] = ok ? P + pk(i, ip) : trash;
+                        old_[reg] = *pp_[reg];
                     }
+                    MPCQP_UNROLL
+                    for (int reg = 0; reg < 4; ++reg) *pp_[reg] = fma(scale, acc[I - I0][J][reg], old_[reg]);
                 }
             }
         }
@@ -1406,13 +1416,19 @@ struct Step {
                 for (int I = P + 1; I < NT; ++I)
                     acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[I][4 * kk], bb, acc[I], 0, 0, 0);
             }
+            double* const trash = sm + c.zero + 4;        // unconditional write-back, see EtDE_add_mfma
             MPCQP_UNROLL
             for (int I = P; I < NT; ++I) {
+                double* pp_[4];
+                double old_[4];
                 MPCQP_UNROLL
                 for (int reg = 0; reg < 4; ++reg) {
                     const int row = 16 * I + lk + 4 * reg, col = 16 * P + li;
-                    if (row < n && col <= row) Phi[pk(row, col)] -= acc[I][reg];
+                    pp_[reg] = (row < n && col <= row) ? Phi + pk(row, col) : trash;
+                    old_[reg] = *pp_[reg];
                 }
+                MPCQP_UNROLL
+                for (int reg = 0; reg < 4; ++reg) *pp_[reg] = old_[reg] - acc[I][reg];
             }
             w.sync();
         }
