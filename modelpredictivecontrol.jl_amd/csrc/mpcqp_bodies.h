@@ -1435,6 +1435,77 @@ struct Step {
     }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    // In-panel update on the matrix cores: after the four columns K0..K0+3 of panel P (block Bk of
+    // the panel) are final, their contribution to the later columns of the panel is removed,
+    //   Phi[i][c] -= sum_{k < 4} L[i][K0 + k] L[c][K0 + k]        (c = 16P + 4r + ., r > Bk; i >= c),
+    // one v_mfma_f64_16x16x4 per row tile with the TRANSPOSED product D' = X_P X_T' (X_T as in
+    // chol_panel_update with K step K0/4): lane (li, lk) then holds, in register r, the update of
+    // the entry (row 16T + li, column 16P + 4r + lk) -- four consecutive columns per quarter-wave, so
+    // one read-modify-write per (tile, later block) with all lanes busy.  Replaces the left-looking
+    // sweep over the panel's finished columns (up to 12 columns x 4 FMA chains per lane and block).
+    template <int P, int Bk>
+    __device__ __forceinline__ void chol_block_update() {
+        typedef double v4d_ __attribute__((ext_vector_type(4)));
+        constexpr int n = DM::nZ, NT = (n + 15) / 16, K0 = 16 * P + 4 * Bk;
+        const int li = w.lane & 15, lk = w.lane >> 4;
+        double x[NT];
+        MPCQP_UNROLL
+        for (int T = P; T < NT; ++T) {
+            const int row = 16 * T + li < n ? 16 * T + li : n - 1;
+            x[T] = Phi[pk(row, 0) + K0 + lk];
+        }
+        double* const trash = sm + c.zero + 4;
+        MPCQP_UNROLL
+        for (int T = P; T < NT; ++T) {
+            const v4d_ acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[P], x[T], v4d_{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            MPCQP_UNROLL
+            for (int r = Bk + 1; r < 4; ++r) {
+                if (16 * P + 4 * r >= n) continue;
+                const int row = 16 * T + li, col = 16 * P + 4 * r + lk;
+                double* const q_ = (row < n && col <= row) ? Phi + pk(row, col) : trash;
+                *q_ -= acc[r];
+            }
+        }
+        w.sync();
+    }
+
+    // One block of four columns of the compile-time-dims factorisation (see cholesky()); the recursion
+    // over K0 unrolls the whole factorisation: every row offset, lane index and panel step is a constant.
+    template <int K0>
+    __device__ __forceinline__ void chol_static(double thr) {
+        constexpr int n = DM::nZ, CB = 4, P = K0 / 16, Bk = (K0 % 16) / 4;
+        const int i = w.lane;
+        const bool act = i < n;
+        const int rowi = pk(act ? i : 0, 0);
+        if constexpr (Bk == 0 && P > 0) chol_panel_update<P>();      // contribution of the finished panels
+        const bool mine = act && i >= K0;
+        double v[CB], lk[CB];
+        load4(mine ? Phi + rowi + K0 : sm + c.zero, v);
+        MPCQP_UNROLL
+        for (int cc = 0; cc < CB; ++cc) {
+            constexpr int kdummy = 0; (void)kdummy;
+            const int k = K0 + cc;                       // k <= 63; a column k >= n only sees zeros
+            const double idl = (v[cc] > thr) ? rsqrt_(v[cc]) : 0.0;
+            const double idb = w.bcast(idl, k);
+            lk[cc] = v[cc] * idb;
+            if (i == k) myinvd = fmax(idl, 1e-32);
+            MPCQP_UNROLL
+            for (int c2 = cc + 1; c2 < CB; ++c2) v[c2] -= lk[cc] * w.bcast(lk[cc], K0 + c2);
+        }
+        if (mine) {
+            MPCQP_UNROLL
+            for (int cc = 0; cc < CB; ++cc) lk[cc] = (i > K0 + cc) ? lk[cc] : 0.0;
+            store4(Phi + rowi + K0, lk);
+        }
+        w.sync();
+        if constexpr (K0 + CB < n) {
+            if constexpr (Bk < 3) chol_block_update<P, Bk>();
+            chol_static<K0 + CB>(thr);
+        }
+    }
+#endif
+
     // ---- in-place Cholesky of packed Phi (row-major lower, see pk()), one row per lane, nZ <= 64
     // Left-looking, four columns at a time.  The part of the four dot products that only needs
     // finished columns (j < k0) is accumulated in one sweep over the lane's own row (four
@@ -1460,6 +1531,14 @@ struct Step {
         const double* zero4 = sm + c.zero;
         myinvd = 0.0;
         constexpr int CB = 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) {
+            chol_static<0>(thr);
+            chol_broke = w.any(act && myinvd <= 1e-32);
+            MPCQP_TOC(6);
+            return;
+        }
+#endif
         MPCQP_NOUNROLL
         for (int k0 = 0; k0 < n; k0 += CB) {
             const bool mine = act && i >= k0;
