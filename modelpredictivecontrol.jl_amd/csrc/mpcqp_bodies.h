@@ -32,6 +32,12 @@
 #define MPCQP_TOC(i) ((void)0)
 #endif
 
+#ifndef MPCQP_RELANE_MASK
+#define MPCQP_RELANE_MASK 0x010u     // measured on C3: solve_into_dz only
+#endif
+// relane site i is active iff bit i of MPCQP_RELANE_MASK is set (see DevWave::relane)
+#define MPCQP_RELANE(i) do { if ((MPCQP_RELANE_MASK >> (i)) & 1u) w.relane(); } while (0)
+
 namespace mpcqp {
 
 // 1/x for the per-row interior-point algebra.  Device: v_rcp_f64 + one Newton step.  Measured on
@@ -274,8 +280,29 @@ struct Qp {
         w.sync();
     }
 
+    // Held cumulative sums over the block columns (Pu v and Pu'w, construct.jl:797-806) without a loop
+    // of lane-dependent length: lane k = (j, c) holds x[k] (0 on lanes >= nDU), log2(Hc) steps of
+    // "fetch the value s blocks away and add".  One value per lane: nDU <= 64.  All lanes call.
+    MPCQP_HD double block_prefix(double x) {            // sum_{jj <= j} x[(jj, c)]
+        const int nu = d.nu, j = w.lane / nu;
+        for (int s_ = 1; s_ < d.Hc; s_ <<= 1) {
+            const double y = w.fetch(x, w.lane - s_ * nu);
+            x += (j >= s_ && w.lane < d.nDU) ? y : 0.0;
+        }
+        return x;
+    }
+    MPCQP_HD double block_suffix(double x) {            // sum_{jj >= j} x[(jj, c)]
+        const int nu = d.nu, j = w.lane / nu;
+        for (int s_ = 1; s_ < d.Hc; s_ <<= 1) {
+            const double y = w.fetch(x, w.lane + s_ * nu);
+            x += (j + s_ < d.Hc && w.lane < d.nDU) ? y : 0.0;
+        }
+        return x;
+    }
+
     // out[r] = sum_k E[r,k] v[k]   (r < nY; v has >= nDU entries)
     MPCQP_HD void E_apply(const double* v, double* out) {
+        MPCQP_RELANE(0);
         const int ny = d.ny, nu = d.nu;
         if constexpr (DM::is_static) {
             if (DM::nu == 4 && DM::nY <= 2 * WAVE && d.default_nb) {
@@ -321,6 +348,7 @@ struct Qp {
     // later block columns just start contributing later), so wv[t,a] is a broadcast LDS read and
     // there is no divergent branch in the loop.
     MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0, int t_hi = -1) {
+        MPCQP_RELANE(1);
         const int ny = d.ny, nu = d.nu;
         if (t_hi < 0) t_hi = d.Hp;          // only the steps t < t_hi contribute
         if constexpr (DM::is_static) {
@@ -385,6 +413,7 @@ struct Qp {
     typedef double v4d __attribute__((ext_vector_type(4)));
     // returns the first step t whose rows the ϵ row (tb) has been accumulated for (-1: no ϵ row)
     __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb) {
+        MPCQP_RELANE(2);
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp, RS = DM::rs;
         constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
         const int li = w.lane & 15, lk = w.lane >> 4;
@@ -873,6 +902,7 @@ struct Step {
     // fn(group, local index, Row&) for every row owned by this lane
     template <class Fn>
     MPCQP_HD void for_rows(Fn fn) {
+        MPCQP_RELANE(7);
         MPCQP_UNROLL
         for (int g = 0; g < NGROUP; ++g) {
             if (!qp.group_on(g)) continue;
@@ -1126,6 +1156,10 @@ struct Step {
         const long long tic11_ = clock64_();
         if (qp.pair_on(P_U) || qp.pair_on(P_W)) {
             double* ucum = sm + c.ucum;
+            if (d.nDU <= WAVE) {
+                const double acc = qp.block_prefix(w.lane < d.nDU ? v[w.lane] : 0.0);
+                if (w.lane < d.nDU) ucum[w.lane] = acc;
+            } else
             for (int k = w.lane; k < d.nDU; k += WAVE) {
                 const int j = k / nu, cc = k - j * nu;
                 double acc = 0.0;
@@ -1174,6 +1208,7 @@ struct Step {
     // ---- fn(Row&, (G v)[row]) for every finite row -------------------------------------------
     template <class Fn>
     MPCQP_HD void apply_G(const double* v, Fn fn) {
+        MPCQP_RELANE(5);
         MPCQP_TIC();
         primitives(v);
         const double e = d.neps ? v[d.nZ - 1] : 0.0;
@@ -1189,6 +1224,7 @@ struct Step {
     // ---- gt = G' wv, wv(Row&) evaluated on finite rows ---------------------------------------
     template <class Fn>
     MPCQP_HD void apply_Gt(Fn wv) {
+        MPCQP_RELANE(6);
         MPCQP_TIC();
         const long long tic_gt_ = clock64_();
         const int nu = d.nu;
@@ -1211,12 +1247,15 @@ struct Step {
         }
         prof_[8] += (double)(clock64_() - tic_gt_);
         const long long tic9_ = clock64_();
+        double sufU = 0.0;
+        if (useU && d.nDU <= WAVE) sufU = qp.block_suffix(w.lane < d.nDU ? sm[c.tA[P_U] + w.lane] : 0.0);
         for (int k = w.lane; k < d.nZ; k += WAVE) {
             double acc = 0.0;
             if (qp.pair_on(P_BOX)) acc += sm[c.tA[P_BOX] + k];
             if (k < d.nDU) {
                 if (qp.pair_on(P_DU)) acc += sm[c.tA[P_DU] + k];
-                if (useU) {
+                if (useU && d.nDU <= WAVE) acc += sufU;
+                else if (useU) {
                     const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tA[P_U];
                     for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];
@@ -1240,6 +1279,7 @@ struct Step {
 
     // ---- Phi <- H̃ (global -> LDS) ------------------------------------------------------------
     MPCQP_HD void load_H() {
+        MPCQP_RELANE(11);
         const double* H = m.Hpk + (size_t)b * d.npk;
         for (int i = w.lane; i < d.npk; i += WAVE) Phi[i] = H[i];
         w.sync();
@@ -1248,6 +1288,7 @@ struct Step {
     // ---- Phi += G' diag(dd) G, dd(Row&) evaluated on finite rows ------------------------------
     template <class Fn>
     MPCQP_HD void add_GtDG(Fn dd) {
+        MPCQP_RELANE(3);
         MPCQP_TIC();
         const int nu = d.nu, nDU = d.nDU, nZ = d.nZ;
         double ee = 0.0;
@@ -1282,7 +1323,28 @@ struct Step {
         const long long tic5_ = clock64_();
         // U rows: Pu' dU Pu has entry ((j,c),(j',c)) = sum_{jj >= max(j,j')} dU[jj,c]: lane (j,c)
         // forms its suffix sum once and adds it along its own row of the lower triangle
-        if (qp.pair_on(P_U)) {
+        if (qp.pair_on(P_U) && nDU <= WAVE) {
+            // one row per lane: suffix sum by log steps, then unconditional read-modify-writes along
+            // the lane's row (block columns right of the diagonal go to the trash slot)
+            const double* tU = sm + c.tA[P_U];
+            const int k = w.lane < nDU ? w.lane : 0;
+            const int j = k / nu, cc = k - j * nu;
+            const double suf = qp.block_suffix(w.lane < nDU ? tU[k] : 0.0);
+            double* const trash = sm + c.zero + 4;
+            double* const row = Phi + pk(k, cc);
+            if constexpr (DM::is_static) {
+                MPCQP_UNROLL
+                for (int j2 = 0; j2 < d.Hc; ++j2) {
+                    double* const q_ = (j2 <= j && w.lane < nDU) ? row + j2 * nu : trash;
+                    *q_ += suf;
+                }
+            } else {
+                for (int j2 = 0; j2 < d.Hc; ++j2) {
+                    double* const q_ = (j2 <= j && w.lane < nDU) ? row + j2 * nu : trash;
+                    *q_ += suf;
+                }
+            }
+        } else if (qp.pair_on(P_U)) {
             const double* tU = sm + c.tA[P_U];
             for (int k = w.lane; k < nDU; k += WAVE) {
                 const int j = k / nu, cc = k - j * nu;
@@ -1335,10 +1397,13 @@ struct Step {
         // ϵ row: Phi[eps, k] += sum_pairs L_P' tB     (staged in dz, which is free here)
         if (d.neps) {
             double* st = dz;
+            double sufB = 0.0;
+            if (epsU && nDU <= WAVE) sufB = qp.block_suffix(w.lane < nDU ? sm[c.tB[P_U] + w.lane] : 0.0);
             for (int k = w.lane; k < nDU; k += WAVE) {
                 double acc = 0.0;
                 if (qp.pair_on(P_DU)) acc += sm[c.tB[P_DU] + k];
-                if (epsU) {
+                if (epsU && nDU <= WAVE) acc += sufB;
+                else if (epsU) {
                     const int j = k / nu, cc = k - j * nu;
                     const double* tU = sm + c.tB[P_U];
                     MPCQP_UNROLL4
@@ -1521,6 +1586,7 @@ struct Step {
         if constexpr (!DM::is_static) {
             if (d.nZ > WAVE) { cholesky_big(); return; }
         }
+        MPCQP_RELANE(8);
         MPCQP_TIC();
         const int n = d.nZ;
         const int i = w.lane;
@@ -1606,6 +1672,7 @@ struct Step {
     // block the zero diagonal slot / pad entries do the masking.  The chunk of the next group is fetched ahead of the dependent chain, which is then
     // v_mul -> v_readlane -> v_fma per column.
     MPCQP_HD void solve_into_dz() {
+        MPCQP_RELANE(4);
         if constexpr (!DM::is_static) {
             if (d.nZ > WAVE) { solve_big(); return; }
         }
@@ -1628,14 +1695,21 @@ struct Step {
             for (int u = 0; u < 4; ++u) x[u] *= myinvd;
         };
         ldf(0, c0);
-        _Pragma("unroll 2")
-        for (int g = 0; g < nfull; ++g) {
+        auto fstep = [&](int g) {
             const int k0 = 4 * g;
             if (k0 + 4 < n) ldf(k0 + 4, c1);
             MPCQP_UNROLL
             for (int u = 0; u < 4; ++u) r -= c0[u] * w.bcast(r, k0 + u);
             MPCQP_UNROLL
             for (int u = 0; u < 4; ++u) c0[u] = c1[u];
+            MPCQP_SCHED_FENCE();             // one chunk fetched ahead, not all of them
+        };
+        if constexpr (DM::is_static) {       // straight-line code: constant row offsets and lane indices
+            MPCQP_UNROLL
+            for (int g = 0; g < nfull; ++g) fstep(g);
+        } else {
+            _Pragma("unroll 2")
+            for (int g = 0; g < nfull; ++g) fstep(g);
         }
         MPCQP_UNROLL
         for (int u = 0; u < 3; ++u)
@@ -1644,11 +1718,12 @@ struct Step {
         // rows k0+u <= i of the group; finished lanes i >= k0+4 read zeros); rows of a group are k0+4 apart
         r *= myinvd;
         auto ldb = [&](int k0, int cnt, double* x) {
+            // finished lanes (i >= k0 + 4) read a valid entry (column 0) and scale it by zero
             const bool on = act && i < k0 + 4;
-            const double* p = on ? Phi + pk(k0, 0) + i : zero4;
-            const int rs = on ? k0 + 4 : 0;
+            const double sc = on ? myinvd : 0.0;
+            const double* p = Phi + pk(k0, 0) + (i < k0 + 4 ? i : 0);
             MPCQP_UNROLL
-            for (int u = 0; u < 4; ++u) x[u] = (u < cnt) ? p[u * rs] * myinvd : 0.0;
+            for (int u = 0; u < 4; ++u) x[u] = (u < cnt) ? p[u * (k0 + 4)] * sc : 0.0;
         };
         if (rem) {
             ldb(4 * nfull, rem, c0);
@@ -1657,14 +1732,21 @@ struct Step {
                 if (u < rem) r -= c0[u] * w.bcast(r, 4 * nfull + u);
         }
         if (nfull > 0) ldb(4 * (nfull - 1), 4, c0);
-        _Pragma("unroll 2")
-        for (int g = nfull - 1; g >= 0; --g) {
+        auto bstep = [&](int g) {
             const int k0 = 4 * g;
             if (g > 0) ldb(k0 - 4, 4, c1);
             MPCQP_UNROLL
             for (int u = 3; u >= 0; --u) r -= c0[u] * w.bcast(r, k0 + u);
             MPCQP_UNROLL
             for (int u = 0; u < 4; ++u) c0[u] = c1[u];
+            MPCQP_SCHED_FENCE();
+        };
+        if constexpr (DM::is_static) {
+            MPCQP_UNROLL
+            for (int g = nfull - 1; g >= 0; --g) bstep(g);
+        } else {
+            _Pragma("unroll 2")
+            for (int g = nfull - 1; g >= 0; --g) bstep(g);
         }
         if (act) dz[i] = r;
         w.sync();
@@ -1942,39 +2024,39 @@ struct Step {
                 return r.lam * row_wi(r);                   // D~ = D / (1 + δ D)
             });
             cholesky();
-            // predictor: rc = s lam
-            newton([&](Row& r) { return r.s * r.lam; });
-            double amin = 1.0, ppsum = 0.0;
-            for_rows([&](int, int, Row& r) {
-                if (!fin(r)) return;
-                double ds, dl;
-                row_step(r, r.s * r.lam, ds, dl);
-                if (ds < 0.0) amin = fmin(amin, -r.s * rcp(ds));
-                if (dl < 0.0) amin = fmin(amin, -r.lam * rcp(dl));
-                r.pp = ds * dl;
-                ppsum += r.pp;
-            });
-            const double aaff = w.minv(amin);
-            // mu after the affine step: sum (s + a ds)(lam + a dl) = sum s lam (1 - a) + a^2 sum ds dl,
-            // because s dl + lam ds = -s lam on every row of the predictor
-            const double muaff = (1.0 - aaff) * mu + aaff * aaff * w.sum(ppsum) / wsum;
-            double sig = muaff / mu;
-            sig = sig * sig * sig;
-            const double smu = sig * mu;
-            // corrector: rc = s lam + ds_aff dl_aff - sigma mu.  The step is kept in the row
-            // (pp <- ds, gd <- dl): the update below needs nothing else, since the primal residual
-            // follows r_p <- (1 - alpha) r_p + alpha δ dl.
-            newton([&](Row& r) { return r.s * r.lam + r.pp - r.wt * smu; });
-            amin = 1e300;
-            for_rows([&](int, int, Row& r) {
-                if (!fin(r)) return;
-                double ds, dl;
-                row_step(r, r.s * r.lam + r.pp - r.wt * smu, ds, dl);
-                if (ds < 0.0) amin = fmin(amin, -r.s * rcp(ds));
-                if (dl < 0.0) amin = fmin(amin, -r.lam * rcp(dl));
-                r.pp = ds;
-                r.gd = dl;
-            });
+            // Two Newton solves with the same factor, one pass of the loop each (one copy of the
+            // code): pass 0 the predictor, rc = s lam; pass 1 the corrector,
+            // rc = s lam + ds_aff dl_aff - sigma mu (sigma = (mu_aff/mu)^3 from the predictor).
+            double amin = 1.0, smu = 0.0;
+            MPCQP_NOUNROLL
+            for (int pass = 0; pass < 2; ++pass) {
+                const double cpp = pass ? 1.0 : 0.0;
+                newton([&](Row& r) { return fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)); });
+                double ppsum = 0.0;
+                amin = pass ? 1e300 : 1.0;
+                for_rows([&](int, int, Row& r) {
+                    if (!fin(r)) return;
+                    double ds, dl;
+                    row_step(r, fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)), ds, dl);
+                    if (ds < 0.0) amin = fmin(amin, -r.s * rcp(ds));
+                    if (dl < 0.0) amin = fmin(amin, -r.lam * rcp(dl));
+                    // predictor: pp <- ds dl.  corrector: the step is kept in the row (pp <- ds,
+                    // gd <- dl): the update below needs nothing else, since the primal residual
+                    // follows r_p <- (1 - alpha) r_p + alpha δ dl.
+                    r.pp = pass ? ds : ds * dl;
+                    r.gd = pass ? dl : r.gd;
+                    ppsum += ds * dl;
+                });
+                if (pass == 0) {
+                    const double aaff = w.minv(amin);
+                    // mu after the affine step: sum (s + a ds)(lam + a dl) = sum s lam (1 - a) + a^2 sum ds dl,
+                    // because s dl + lam ds = -s lam on every row of the predictor
+                    const double muaff = (1.0 - aaff) * mu + aaff * aaff * w.sum(ppsum) / wsum;
+                    double sig = muaff / mu;
+                    sig = sig * sig * sig;
+                    smu = sig * mu;
+                }
+            }
             // Fraction to the boundary: 0.9999 when the iterate it leads to stays in the wide
             // neighbourhood min_i s_i lam_i >= 0.01 mu, otherwise 0.99.  (An unguarded 0.999 jams
             // about one instance in 20000; with the guard no instance of 65536 needs more

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mpcqp_types.h"
 
 #ifndef MPCQP_STEP_WAVES
@@ -63,6 +65,17 @@ struct DevWave {
         return v;
     }
     __device__ __forceinline__ double bcast(double v, int src) { return lane_value(v, src); }
+    // The lane id as a value the optimiser cannot trace back to threadIdx: address arithmetic built
+    // on it is redone where it is used instead of being hoisted out of the interior-point loop and
+    // kept in (spilled) registers for the whole kernel.
+    __device__ __forceinline__ void relane() { asm volatile("" : "+v"(lane)); }
+    // value of v in lane `src` (lane-varying source; any lane 0..63): two ds_bpermute_b32 through the
+    // LDS crossbar, no LDS storage
+    __device__ __forceinline__ double fetch(double v, int src) const {
+        const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+        const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+        return __hiloint2double(hi, lo);
+    }
     __device__ __forceinline__ bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 };
 
@@ -93,7 +106,8 @@ inline hipError_t ensure_lds(const void* fn, size_t bytes) {
 
 template <class SD>
 inline hipError_t launch_step_static(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
-    const size_t lds = (size_t)make_carve(SD(d)).total * sizeof(double);
+    size_t lds = (size_t)make_carve(SD(d)).total * sizeof(double);
+    if (const char* pad = getenv("MPCQP_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
     hipError_t e = ensure_lds((const void*)k_step_s<SD>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_step_s<SD>, dim3(d.B), dim3(WAVE), lds, st, d, m, io);

@@ -66,6 +66,13 @@ struct EmuWave {
         return s;
     }
     bool any(bool p) { return isum(p ? 1 : 0) != 0; }
+    void relane() {}
+    double fetch(double v, int src) {
+        sh->xd[lane] = v; sync();
+        double s = sh->xd[src & (WAVE - 1)];
+        sync();
+        return s;
+    }
     double bcast(double v, int src) {
         sh->xd[lane] = v; sync();
         double s = sh->xd[src];
