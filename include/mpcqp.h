@@ -71,6 +71,8 @@ typedef struct mpcqp_handle_s* mpcqp_handle;
 #define MPCQP_FLAG_KEEP_QP       (1u << 2)  /* keep q̃ and F of the last step for mpcqp_get         */
 #define MPCQP_FLAG_WARM_DUAL     (1u << 3)  /* closed loop: keep the multipliers between steps and  */
                                             /* start the next solve around them (and the shifted Z̃) */
+#define MPCQP_FLAG_NO_POLISH     (1u << 4)  /* skip the active-set polish of the interior-point iterate */
+                                            /* (measurements only: the polish is what bounds the error) */
 
 typedef struct {
     int32_t  batch;     /* B: number of independent controllers                              */

@@ -314,7 +314,7 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
 
 int mpcqp_set_flags(mpcqp_handle h, uint32_t flags) {
     if (!h) return MPCQP_ERR_NULL;
-    const uint32_t known = MPCQP_FLAG_RY_CONSTANT | MPCQP_FLAG_COLD_START | MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL;
+    const uint32_t known = MPCQP_FLAG_RY_CONSTANT | MPCQP_FLAG_COLD_START | MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL | MPCQP_FLAG_NO_POLISH;
     if (flags & ~known) return MPCQP_ERR_ARG;
     if ((flags ^ h->d.flags) & MPCQP_FLAG_WARM_DUAL) h->lam_valid = false;
     h->d.flags = flags;

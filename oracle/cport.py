@@ -26,6 +26,7 @@ def lib():
         L.linmpc_ref_step.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_double, C.c_double,
                                                         C.c_double, C.c_int]
         L.linmpc_ref_threads.restype = C.c_int
+        L.linmpc_ref_polish_params.argtypes = [C.c_double, C.c_double, C.c_int]
         _LIB = L
     return _LIB
 

@@ -139,6 +139,17 @@ void linmpc_ref_destroy(void* p) {
     free(r);
 }
 
+/* Active-set polish of the interior-point iterate (same rule as Step::polish of the kernels):
+ * once mu <= POL_MU the rows with lam_i > s_i are taken as the active set A and the
+ * equality-constrained QP on A is solved by Newton steps on its augmented Lagrangian,
+ *     (H + rho G_A'G_A) dz = -(H z + q + G_A'lam) - rho G_A'(G_A z - h_A),   lam += rho (G_A (z + dz) - h_A),
+ * with exactly evaluated residuals each round; the point is accepted when it satisfies the KKT
+ * conditions of the inequality-constrained QP (multipliers >= 0 on A, inactive rows feasible). */
+static double POL_MU = 1e-6, POL_RHO = 1e10, POL_RD = 1e-14, POL_RP = 1e-13, POL_LAM = 1e-12, POL_SL = 1e-11;
+static int POL_ROUNDS = 8;
+void linmpc_ref_polish_params(double mu, double rho, int rounds) { POL_MU = mu; POL_RHO = rho; POL_ROUNDS = rounds; }
+void linmpc_ref_polish_tols(double rd, double rp, double lam, double sl) { POL_RD = rd; POL_RP = rp; POL_LAM = lam; POL_SL = sl; }
+
 static int chol(double* A, int n) {     /* in place, lower, row-major full */
     for (int k = 0; k < n; ++k) {
         double v = A[k * n + k];
@@ -200,6 +211,9 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
         double *q = (double*)malloc(nZ * sizeof(double)), *z = (double*)malloc(nZ * sizeof(double));
         double *zs = (double*)malloc(nZ * sizeof(double)), *dz = (double*)malloc(nZ * sizeof(double));
         double *rd = (double*)malloc(nZ * sizeof(double)), *gt = (double*)malloc(nZ * sizeof(double));
+        double *zp = (double*)malloc(nZ * sizeof(double)), *lp = (double*)malloc(mmax * sizeof(double));
+        double *rpa = (double*)malloc(mmax * sizeof(double));
+        int* act = (int*)malloc(mmax * sizeof(int));
 #pragma omp for schedule(dynamic, 8)
         for (int b = 0; b < B; ++b) {
             double delta = delta0;       /* may be raised for this controller, see the factorisation */
@@ -269,7 +283,8 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                 if (!cold) { if (k < nDU - nu) v = Zb[k + nu]; else if (k >= nDU) v = Zb[k]; }
                 zs[k] = z[k] = v;
             }
-            int st = 1, it = 0;
+            int st = 1, it = 0, npol = 0;
+            double polmu_next = POL_MU;
             double laststep = 1e300;     /* alpha |dU|_inf / max(1, |dU|_inf) of the previous iteration */
             double rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0;   /* previous dual residual, 1 - alpha of the previous step */
             double nh = 1.0, rpn = 0;
@@ -320,6 +335,77 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                     int pstalled = rpn >= 0.5 * rpn_prev && lastscale <= 0.1 && rpn <= 1e-7 * nh;
                     rpn_prev = rpn;
                     if (mu <= gap_tol && (rdn <= res_tol * ndd || stalled) && (rpn <= 100.0 * res_tol * nh || pstalled) && laststep <= 1e-6) { st = 0; break; }
+                }
+                if (POL_MU > 0 && mu <= polmu_next && rpn <= 1e-6 * nh && npol < 4) {
+                    polmu_next = 1e-2 * mu;
+                    ++npol;
+                    for (int i = 0; i < m; ++i) { act[i] = lam[i] > s[i]; lp[i] = act[i] ? lam[i] : 0.0; }
+                    memcpy(Phi, Hb, (size_t)nZ * nZ * sizeof(double));
+                    for (int i = 0; i < m; ++i) {
+                        if (!act[i]) continue;
+                        const double* g = G + (size_t)i * nZ;
+                        for (int k = 0; k < nZ; ++k) {
+                            double gk = POL_RHO * g[k];
+                            if (gk == 0) continue;
+                            for (int j = 0; j <= k; ++j) Phi[k * nZ + j] += gk * g[j];
+                        }
+                    }
+                    if (chol(Phi, nZ) == 0) {
+                        memcpy(zp, z, nZ * sizeof(double));
+                        int ok = 0;
+                        for (int round = 0; round <= POL_ROUNDS; ++round) {
+                            double rpan = 0, rdn2 = 0, ndd2 = 0;
+                            for (int i = 0; i < m; ++i) {
+                                if (!act[i]) continue;
+                                double a = 0;
+                                const double* g = G + (size_t)i * nZ;
+                                for (int k = 0; k < nZ; ++k) a += g[k] * zp[k];
+                                rpa[i] = a - h[i];
+                                if (fabs(rpa[i]) > rpan) rpan = fabs(rpa[i]);
+                            }
+                            for (int k = 0; k < nZ; ++k) {
+                                double hz = 0, gl = 0;
+                                for (int j = 0; j < nZ; ++j) hz += Hb[k * nZ + j] * zp[j];
+                                for (int i = 0; i < m; ++i) if (act[i]) gl += G[(size_t)i * nZ + k] * lp[i];
+                                gt[k] = hz + q[k] + gl;
+                                if (fabs(gt[k]) > rdn2) rdn2 = fabs(gt[k]);
+                                double sc = fmax(fabs(q[k]), fmax(fabs(hz), fabs(gl)));
+                                if (sc > ndd2) ndd2 = sc;
+                            }
+                            if (rpan <= POL_RP * nh && rdn2 <= POL_RD * (1.0 + ndd2)) { ok = 1; break; }
+                            if (round == POL_ROUNDS) break;
+                            for (int k = 0; k < nZ; ++k) dz[k] = -gt[k];
+                            for (int i = 0; i < m; ++i) {
+                                if (!act[i]) continue;
+                                const double* g = G + (size_t)i * nZ;
+                                double c = POL_RHO * rpa[i];
+                                for (int k = 0; k < nZ; ++k) dz[k] -= g[k] * c;
+                            }
+                            chol_solve(Phi, dz, nZ);
+                            for (int k = 0; k < nZ; ++k) zp[k] += dz[k];
+                            for (int i = 0; i < m; ++i) {
+                                if (!act[i]) continue;
+                                double a = 0;
+                                const double* g = G + (size_t)i * nZ;
+                                for (int k = 0; k < nZ; ++k) a += g[k] * dz[k];
+                                lp[i] += POL_RHO * (rpa[i] + a);
+                            }
+                        }
+                        if (ok) {       /* KKT conditions of the inequality-constrained QP */
+                            double lmax = 0;
+                            for (int i = 0; i < m; ++i) if (act[i] && fabs(lp[i]) > lmax) lmax = fabs(lp[i]);
+                            for (int i = 0; i < m && ok; ++i) {
+                                if (act[i]) { if (lp[i] < -POL_LAM * (1.0 + lmax)) ok = 0; }
+                                else {
+                                    double a = 0;
+                                    const double* g = G + (size_t)i * nZ;
+                                    for (int k = 0; k < nZ; ++k) a += g[k] * zp[k];
+                                    if (h[i] - a < -POL_SL * nh) ok = 0;
+                                }
+                            }
+                        }
+                        if (ok) { memcpy(z, zp, nZ * sizeof(double)); st = 0; it = pass + npol; break; }
+                    }
                 }
                 /* a pivot below its threshold: Phi left float64's range; redo the factorisation with a
                    100x larger dual regularisation (same rule as Step::run of the kernels) */
@@ -411,7 +497,7 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
             if (st) ++nbad;
         }
         free(G); free(h); free(s); free(lam); free(rp); free(gd); free(pp); free(Dt); free(wv); free(dsv); free(dlv);
-        free(F); free(Phi); free(q); free(z); free(zs); free(dz); free(rd); free(gt);
+        free(F); free(Phi); free(q); free(z); free(zs); free(dz); free(rd); free(gt); free(zp); free(lp); free(rpa); free(act);
     }
     return nbad;
 }

@@ -153,13 +153,13 @@ def _maxstep(s, ds, lam, dl):
     return a
 
 
-def polish(H, q, G, h, z, lam, s, rounds=6):
-    """Active-set refinement: rows with lam_i > s_i are taken active and the equality-constrained
-    KKT system is solved exactly (least-squares: duplicated active rows are legal, e.g. a
-    saturated input held over a move-blocking interval); rows with a negative multiplier are
-    dropped and violated rows added, a few times."""
+def polish(H, q, G, h, z, lam, s, rounds=6, act=None):
+    """Active-set refinement: rows with lam_i > s_i (or the given set `act`) are taken active and the
+    equality-constrained KKT system is solved exactly (least-squares: duplicated active rows are
+    legal, e.g. a saturated input held over a move-blocking interval); rows with a negative
+    multiplier are dropped and violated rows added, a few times."""
     n = len(q)
-    act = lam > s
+    act = (lam > s) if act is None else act.copy()
     tolh = 1e-11 * (1.0 + np.abs(h).max())
     zp, lp = z, lam
     for _ in range(rounds):
@@ -219,13 +219,20 @@ def active_set_certificate(H, q, G, h, z, lam):
     i.e. it is the unique optimum to ~1e-10 (strong convexity: |dz| <= |dq| / lambda_min(H))."""
     nh = 1.0 + np.abs(h).max(initial=0.0)
     nl = 1.0 + np.abs(lam).max(initial=0.0)
-    slack = h - G @ z
-    Hz, Gl = H @ z, G.T @ lam
-    nd = 1.0 + max(np.abs(q).max(), np.abs(Hz).max(), np.abs(Gl).max())
+    # evaluated in extended precision: the terms of the stationarity sum reach 1e6 (multipliers of
+    # violated soft rows, 2 Cwt eps), and a residual of 1e-11 of that scale -- float64 evaluation
+    # noise -- would still allow an error of 1e-5 / lambda_min(H) in z.  The targets below are
+    # 1e-13 of the scale for stationarity and 1e-12 for the row conditions.
+    L = np.longdouble
+    zl, ll = z.astype(L), lam.astype(L)
+    slack = (h.astype(L) - G.astype(L) @ zl).astype(float)
+    Hz, Gl = (H.astype(L) @ zl), (G.T.astype(L) @ ll)
+    nd = 1.0 + max(np.abs(q).max(), float(np.abs(Hz).max()), float(np.abs(Gl).max()))
+    stat = float(np.abs(Hz + q.astype(L) + Gl).max())
     w = lam != 0
-    return bool(lam.min(initial=0.0) >= -1e-10 * nl and slack.min(initial=0.0) >= -1e-10 * nh
-                and np.abs(slack[w]).max(initial=0.0) <= 1e-10 * nh
-                and np.abs(Hz + q + Gl).max() <= 1e-11 * nd)
+    return bool(lam.min(initial=0.0) >= -1e-12 * nl and slack.min(initial=0.0) >= -1e-12 * nh
+                and np.abs(slack[w]).max(initial=0.0) <= 1e-12 * nh
+                and stat <= 1e-13 * nd)
 
 
 def solve_qp(H, q, A, b, zmin, zmax, z0=None, return_info=False):
@@ -240,10 +247,18 @@ def solve_qp(H, q, A, b, zmin, zmax, z0=None, return_info=False):
         info["certificate"] = "ipm-bound"
         info["err_bound"] = error_bound(H, q, G, h, z, lam)
         if len(h):
-            zp, lp = polish(H, q, G, h, z, lam, s)
-            if np.all(np.isfinite(zp)) and active_set_certificate(H, q, G, h, zp, lp):
-                info["ipm_vs_polish"] = float(np.abs(z - zp).max())
-                z, lam, info["polished"], info["certificate"] = zp, lp, True, "active-set"
+            # working sets tried in turn: the interior-point partition lam_i > s_i, then (degenerate
+            # vertices, where weakly active rows have s_i ~ lam_i) the rows that are tight at the
+            # interior-point optimum to 1e-7, 1e-6, 1e-8 of the bound scale; each with add/drop rounds
+            nh = 1.0 + np.abs(h).max()
+            slack = h - G @ z
+            starts = [None] + [slack < t * nh for t in (1e-7, 1e-6, 1e-8)]
+            for act0 in starts:
+                zp, lp = polish(H, q, G, h, z, lam, s, rounds=12 if act0 is not None else 6, act=act0)
+                if np.all(np.isfinite(zp)) and active_set_certificate(H, q, G, h, zp, lp):
+                    info["ipm_vs_polish"] = float(np.abs(z - zp).max())
+                    z, lam, info["polished"], info["certificate"] = zp, lp, True, "active-set"
+                    break
         else:
             info["certificate"] = "active-set"
         info["kkt"] = kkt_residuals(H, q, G, h, z, lam)

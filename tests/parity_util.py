@@ -204,9 +204,13 @@ def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
 
 def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False):
     """One randomly drawn controller family (dimensions, move blocking, which bounds exist, hard /
-    soft mix, terminal bounds, measured disturbance, weights, Cwt finite or Inf) stepped twice
-    through the C-ABI and through the oracle; returns the worst relative ΔU error over the steps
-    whose oracle optimum carries an exact certificate (None if none did)."""
+    soft mix, terminal bounds, measured disturbance, Cwt finite or Inf) as a batch of B DIFFERENT
+    controllers of that family -- every member has its own model, weights, operating points, bound
+    values, pattern of +-Inf holes, state, set point and disturbance -- stepped twice through the
+    C-ABI and, member by member, through the oracle.  Returns the worst relative ΔU error over all
+    members and steps whose oracle optimum carries an exact certificate (None if none did).
+    Member 0 is drawn from the family's own generator (the instances the earlier single-controller
+    form of this test compared), the others from generators of their own."""
     from oracle import estim as es
     rng = np.random.default_rng(1000 + seed)
     nx = int(rng.integers(2, 4 if small else 7)); nu = int(rng.integers(1, 3 if small else 5))
@@ -227,65 +231,93 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False):
             if sum(parts) > Hp:
                 parts[-1] -= sum(parts) - Hp
         Hc = [p for p in parts if p > 0] or 1
-    lam = rng.uniform(0.3, 0.97, nx)
-    Q, _ = np.linalg.qr(rng.standard_normal((nx, nx)))
-    A = Q @ np.diag(lam) @ Q.T
-    Bu = rng.standard_normal((nx, nu)) / np.sqrt(nx); C = rng.standard_normal((ny, nx)) / np.sqrt(nx)
-    Bd = rng.standard_normal((nx, nd)); Dd = 0.3 * rng.standard_normal((ny, nd))
-    model = es.LinModelOracle(A, Bu, C, Bd, Dd).setop(uop=0.2 * rng.standard_normal(nu),
-                                                      yop=rng.standard_normal(ny), dop=0.3 * rng.standard_normal(nd))
-    kf = es.SteadyKalmanFilterOracle(model)
-    soft = rng.random() < 0.75
-    kw = dict(Hp=Hp, Hc=Hc, Mwt=rng.uniform(0.5, 2.0, ny), Nwt=rng.uniform(0.02, 0.3, nu),
-              Lwt=rng.uniform(0.0, 0.1, nu) * (rng.random() < 0.5), Cwt=10 ** rng.uniform(3, 5.5) if soft else np.inf,
-              uop=model.uop, yop=model.yop, dop=model.dop, xhop=kf.xhop, fhop=kf.fhop)
-    orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
-    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
-    gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd) if nd else None,
-                            rep(kf.Dhd) if nd else None, lib=lib, **kw)
-    inf_some = lambda v: np.where(rng.random(v.shape) < 0.25, np.inf * np.sign(v), v)
-    con, cong = {}, {}
-    def put(name, gname, val):
-        con[name] = val; cong[gname] = val
-    if rng.random() < 0.8:
-        put("umin", "umin", inf_some(model.uop - rng.uniform(0.3, 1.2, nu)))
-        put("umax", "umax", inf_some(model.uop + rng.uniform(0.3, 1.2, nu)))
-    if rng.random() < 0.6:
-        put("dumin", "Δumin", inf_some(-rng.uniform(0.1, 0.6, nu)))
-        put("dumax", "Δumax", inf_some(rng.uniform(0.1, 0.6, nu)))
-    if soft and rng.random() < 0.8:
-        put("ymin", "ymin", inf_some(model.yop - rng.uniform(0.2, 1.5, ny)))
-        put("ymax", "ymax", inf_some(model.yop + rng.uniform(0.2, 1.5, ny)))
-    if soft and rng.random() < 0.4:
-        xm = np.full(kf.nxh, np.inf); xm[int(rng.integers(0, kf.nxh))] = 0.6
-        put("xhatmax", "x̂max", kf.xhop + xm)
-    if soft:                                # softness: some rows hard (0), some soft
-        for base, gbase, n in (("c_umin", "c_umin", nu), ("c_umax", "c_umax", nu), ("c_dumin", "c_Δumin", nu),
-                               ("c_dumax", "c_Δumax", nu), ("c_ymin", "c_ymin", ny), ("c_ymax", "c_ymax", ny)):
-            if base[2:] in con and rng.random() < 0.5:
-                put(base, gbase, rng.uniform(0.2, 1.5, n) * (rng.random(n) < 0.6 if base[2] != "y" else 1.0))
-    orc.setconstraint(**con); gpu.setconstraint(**cong)
-    x0 = 0.5 * rng.standard_normal(kf.nxh)
-    u_prev = model.uop + 0.2 * rng.standard_normal(nu)
-    gpu.initstate(u_prev); orc.lastu0 = u_prev - model.uop
+    fam = {}                                # structural decisions of the family, set by member 0
+
+    def decide(key, value):                 # member 0 decides, the others follow
+        return fam.setdefault(key, value)
+
+    def member(rg):
+        lam = rg.uniform(0.3, 0.97, nx)
+        Q, _ = np.linalg.qr(rg.standard_normal((nx, nx)))
+        A = Q @ np.diag(lam) @ Q.T
+        Bu = rg.standard_normal((nx, nu)) / np.sqrt(nx); C = rg.standard_normal((ny, nx)) / np.sqrt(nx)
+        Bd = rg.standard_normal((nx, nd)); Dd = 0.3 * rg.standard_normal((ny, nd))
+        model = es.LinModelOracle(A, Bu, C, Bd, Dd).setop(uop=0.2 * rg.standard_normal(nu),
+                                                          yop=rg.standard_normal(ny), dop=0.3 * rg.standard_normal(nd))
+        kf = es.SteadyKalmanFilterOracle(model)
+        soft = decide("soft", bool(rg.random() < 0.75))
+        Mw, Nw = rg.uniform(0.5, 2.0, ny), rg.uniform(0.02, 0.3, nu)
+        Lw = rg.uniform(0.0, 0.1, nu) * (rg.random() < 0.5)
+        cw = 10 ** rg.uniform(3, 5.5)
+        kw = dict(Hp=Hp, Hc=Hc, Mwt=Mw, Nwt=Nw, Lwt=Lw, Cwt=cw if soft else np.inf,
+                  uop=model.uop, yop=model.yop, dop=model.dop, xhop=kf.xhop, fhop=kf.fhop)
+        orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
+        inf_some = lambda v: np.where(rg.random(v.shape) < 0.25, np.inf * np.sign(v), v)
+        con = {}
+        if decide("u", bool(rg.random() < 0.8)):
+            con["umin"] = inf_some(model.uop - rg.uniform(0.3, 1.2, nu))
+            con["umax"] = inf_some(model.uop + rg.uniform(0.3, 1.2, nu))
+        if decide("du", bool(rg.random() < 0.6)):
+            con["dumin"] = inf_some(-rg.uniform(0.1, 0.6, nu))
+            con["dumax"] = inf_some(rg.uniform(0.1, 0.6, nu))
+        if decide("y", bool(soft and rg.random() < 0.8)):
+            con["ymin"] = inf_some(model.yop - rg.uniform(0.2, 1.5, ny))
+            con["ymax"] = inf_some(model.yop + rg.uniform(0.2, 1.5, ny))
+        if decide("x", bool(soft and rg.random() < 0.4)):
+            xm = np.full(kf.nxh, np.inf); xm[int(rg.integers(0, kf.nxh))] = 0.6
+            con["xhatmax"] = kf.xhop + xm
+        if soft:                                # softness: some rows hard (0), some soft
+            for base, n in (("c_umin", nu), ("c_umax", nu), ("c_dumin", nu), ("c_dumax", nu),
+                            ("c_ymin", ny), ("c_ymax", ny)):
+                if base[2:] in con and decide(base, bool(rg.random() < 0.5)):
+                    con[base] = rg.uniform(0.2, 1.5, n) * (rg.random(n) < 0.6 if base[2] != "y" else 1.0)
+        orc.setconstraint(**con)
+        x0 = 0.5 * rg.standard_normal(kf.nxh)
+        u_prev = model.uop + 0.2 * rg.standard_normal(nu)
+        orc.lastu0 = u_prev - model.uop
+        return dict(model=model, kf=kf, orc=orc, kw=kw, con=con, x0=x0, u_prev=u_prev, rg=rg)
+
+    mem = [member(rng)] + [member(np.random.default_rng([1000 + seed, i])) for i in range(1, B)]
+    st = lambda f: np.stack([f(m) for m in mem])
+    nxh = mem[0]["kf"].nxh
+    gpu = mpcqp.BatchLinMPC(st(lambda m: m["kf"].Ah), st(lambda m: m["kf"].Bhu), st(lambda m: m["kf"].Ch),
+                            st(lambda m: m["kf"].Bhd) if nd else None, st(lambda m: m["kf"].Dhd) if nd else None,
+                            lib=lib, Hp=Hp, Hc=Hc, Mwt=st(lambda m: m["kw"]["Mwt"]), Nwt=st(lambda m: m["kw"]["Nwt"]),
+                            Lwt=st(lambda m: m["kw"]["Lwt"]), Cwt=st(lambda m: m["kw"]["Cwt"]),
+                            uop=st(lambda m: m["model"].uop), yop=st(lambda m: m["model"].yop),
+                            dop=st(lambda m: m["model"].dop), xhop=st(lambda m: m["kf"].xhop),
+                            fhop=st(lambda m: m["kf"].fhop))
+    gname = dict(dumin="Δumin", dumax="Δumax", c_dumin="c_Δumin", c_dumax="c_Δumax", xhatmax="x̂max")
+    gpu.setconstraint(**{gname.get(k, k): st(lambda m: m["con"][k]) for k in mem[0]["con"]})
+    gpu.initstate(st(lambda m: m["u_prev"]))
     worst = None
     for k in range(2):
-        ry = model.yop + rng.standard_normal(ny) * (1.5 if k == 0 else 0.5)
-        d = model.dop + 0.3 * rng.standard_normal(nd) if nd else None
-        Dhat = (np.tile(d, Hp) + 0.05 * rng.standard_normal(nd * Hp)) if nd else None
-        gpu.moveinput(np.tile(x0, (B, 1)), ry, d, Dhat=Dhat)
-        orc.initpred(x0, orc.lastu0 + model.uop, ry, d, Dhat); orc.linconstraint()
-        z, st, info = qp.solve_qp(*orc.qp_data(), orc.warmstart(), return_info=True)
-        if st != 0:                       # the oracle gave up on this one (it would take its error
-            break                         # branch and the two loops would no longer see the same inputs)
-        assert np.all(gpu.status == 0), (seed, gpu.status)
-        e = rel_err(gpu.Z[B - 1:B], z[None, :], orc.nDU).max()
-        if info["certificate"] == "active-set":
-            worst = e if worst is None else max(worst, e)
-        elif e > 1e-4:                    # uncertified oracle point that differs: nobody to compare
-            break                         # with, and the two loops would part ways from here on
-        uo = orc.moveinput(x0, ry, d, Dhat=Dhat)
-        x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop)
+        for m in mem:
+            rg, model = m["rg"], m["model"]
+            m["ry"] = model.yop + rg.standard_normal(ny) * (1.5 if k == 0 else 0.5)
+            m["d"] = model.dop + 0.3 * rg.standard_normal(nd) if nd else None
+            m["Dhat"] = (np.tile(m["d"], Hp) + 0.05 * rg.standard_normal(nd * Hp)) if nd else None
+        gpu.moveinput(st(lambda m: m["x0"]), st(lambda m: m["ry"]), st(lambda m: m["d"]) if nd else None,
+                      Dhat=st(lambda m: m["Dhat"]) if nd else None)
+        stop = False
+        for i, m in enumerate(mem):
+            orc, model = m["orc"], m["model"]
+            orc.initpred(m["x0"], orc.lastu0 + model.uop, m["ry"], m["d"], m["Dhat"]); orc.linconstraint()
+            z, sto, info = qp.solve_qp(*orc.qp_data(), orc.warmstart(), return_info=True)
+            if sto != 0:                  # the oracle gave up on this one (it would take its error
+                stop = True               # branch and the two loops would no longer see the same inputs)
+                break
+            assert gpu.status[i] == 0, (seed, i, gpu.status)
+            e = rel_err(gpu.Z[i:i + 1], z[None, :], orc.nDU).max()
+            if info["certificate"] == "active-set":
+                worst = e if worst is None else max(worst, e)
+            elif e > 1e-4:                # uncertified oracle point that differs: nobody to compare
+                stop = True               # with, and the two loops would part ways from here on
+                break
+            uo = orc.moveinput(m["x0"], m["ry"], m["d"], Dhat=m["Dhat"])
+            m["x0"] = m["kf"].Ah @ m["x0"] + m["kf"].Bhu @ (uo - model.uop)
+        if stop:
+            break
     return worst
 
 

@@ -52,8 +52,9 @@ def test_step_matches_oracle(name, B, seed, hiplib):
     cert = ref["certified"]
     assert cert.mean() > 0.95
     assert err[cert].max() <= TOL, f"max rel ΔU err {err[cert].max():.3e}"
-    # oracle rows without the exact-KKT certificate are only known to ~1e-5 themselves
-    assert err.max() <= 5 * TOL
+    # the few oracle points without the exact-KKT certificate carry the oracle's rigorous error bound
+    # (oracle/qp.py: error_bound) instead: the kernel's polished optimum must lie inside it
+    assert err.max() <= TOL, f"max rel ΔU err over all instances {err.max():.3e}"
     assert np.abs(got["u"] - ref["u"]).max() <= TOL * max(1.0, np.abs(ref["u"]).max())
 
 
@@ -101,6 +102,37 @@ def test_full_size_properties_C3(hiplib):
     refh = oracle_batch(cfg, {k: (v[hard] if isinstance(v, np.ndarray) else v) for k, v in bt.items()})
     errh = rel_err(Z[hard], refh["Z"], nDU)
     assert errh[refh["certified"]].max() <= TOL
+
+
+def test_config4_batch_on_one_gpu(hiplib):
+    """BASELINE configs[3]'s batch (B = 262144, C3 shapes) on ONE GPU: every instance OPTIMAL, the
+    size-independent properties, sampled parity against the certified oracle, and shard = slice: the
+    first and the last 32768 instances solved on their own (the 8-GPU sharding of config 4) give the
+    same bits as inside the big batch."""
+    cfg = synth.C3
+    B = 262144
+    bt = synth.make_batch(cfg, B, seed=3)
+    got = run_batch(cfg, bt)
+    Z, st = got["Z"], got["status"]
+    assert np.all(st == mpcqp.STATUS_OPTIMAL)
+    nu, Hc, nDU = cfg.nu, cfg.Hc, cfg.nu * cfg.Hc
+    U0 = np.cumsum(Z[:, :nDU].reshape(B, Hc, nu), axis=1) + bt["lastu0"][:, None, :]
+    assert U0.max() <= cfg.umax + 1e-9 and U0.min() >= cfg.umin - 1e-9
+    eps = Z[:, -1]
+    assert eps.min() >= -1e-12
+    # soft output bound up to the slack.  Polished instances hold it to 1e-11; an instance the polish
+    # could not take over (degenerate vertex) ends on the interior-point rule, primal residual
+    # <= 1e-9 nh or stalled below 1e-7 nh: a handful in 262144
+    viol = (got["Yhat"] - cfg.ymax - eps[:, None]).max(axis=1)
+    assert viol.max() <= 1e-6 and (viol > 1e-8).sum() <= 4, (viol.max(), (viol > 1e-8).sum())
+    idx = np.arange(0, B, 4096)
+    ref = oracle_batch(cfg, {k: (v[idx] if isinstance(v, np.ndarray) else v) for k, v in bt.items()})
+    err = rel_err(Z[idx], ref["Z"], nDU)
+    assert ref["certified"].mean() > 0.9 and err[ref["certified"]].max() <= TOL
+    for lo in (0, B - 32768):
+        sub = synth.make_batch(cfg, 32768, seed=3, lo=lo)
+        assert np.array_equal(sub["xhat0"], bt["xhat0"][lo:lo + 32768])
+        assert np.array_equal(run_batch(cfg, sub)["Z"], Z[lo:lo + 32768])
 
 
 def _pair(model_kw, mpc_kw, B=3, con=None):
@@ -407,7 +439,7 @@ def test_random_controller_families_on_gpu(seed, hiplib):
     step from the shifted warm start) against the certified oracle optimum."""
     from tests.parity_util import run_random_case
     e = run_random_case(seed, B=5)
-    assert e is None or e <= TOL
+    assert e is not None and e <= TOL, e
 
 
 @pytest.mark.parametrize("seed", [2000, 2004, 2014, 2021, 2028, 2083])
@@ -418,7 +450,7 @@ def test_families_near_wave_limit(seed, hiplib):
     (csrc/mpcqp_types.h, MPCQP_HD)."""
     from tests.parity_util import run_random_case
     e = run_random_case(seed, B=3, large=True)
-    assert e is None or e <= TOL
+    assert e is not None and e <= TOL, e
 
 
 @pytest.mark.parametrize("seed", [3000, 3004, 3008, 3010])
@@ -428,7 +460,7 @@ def test_families_beyond_one_row_per_lane(seed, hiplib):
     tolerance as the one-row-per-lane kernels."""
     from tests.parity_util import run_random_case
     e = run_random_case(seed, B=3, huge=True)
-    assert e is None or e <= TOL
+    assert e is not None and e <= TOL, e
 
 
 @pytest.mark.parametrize("seed", list(range(6)))
@@ -437,4 +469,4 @@ def test_random_horizon_wide_forms_on_gpu(seed, hiplib):
     block-diagonal M_Hp with a dense terminal block and (odd seeds) custom linear constraints."""
     from tests.parity_util import run_random_case2
     e = run_random_case2(seed, B=4)
-    assert e is None or e <= TOL
+    assert e is not None and e <= TOL, e
