@@ -147,6 +147,8 @@ void linmpc_ref_destroy(void* p) {
  * conditions of the inequality-constrained QP (multipliers >= 0 on A, inactive rows feasible). */
 static double POL_MU = 1e-6, POL_RHO = 1e10, POL_RD = 1e-14, POL_RP = 1e-13, POL_LAM = 1e-12, POL_SL = 1e-11;
 static int POL_ROUNDS = 8;
+static double TERM_PFAC = 10.0, TERM_PSTALL = 1e-9;   /* primal residual target (x res_tol) and stall ceiling (x nh) */
+void linmpc_ref_term_params(double pfac, double pstall) { TERM_PFAC = pfac; TERM_PSTALL = pstall; }
 void linmpc_ref_polish_params(double mu, double rho, int rounds) { POL_MU = mu; POL_RHO = rho; POL_ROUNDS = rounds; }
 void linmpc_ref_polish_tols(double rd, double rp, double lam, double sl) { POL_RD = rd; POL_RP = rp; POL_LAM = lam; POL_SL = sl; }
 
@@ -332,9 +334,9 @@ int linmpc_ref_step(void* p, const double* xhat0, const double* lastu0, const do
                        step was nearly full counts as converged; the step criterion vouches for z) */
                     int stalled = rdn >= 0.5 * rdn_prev && lastscale <= 0.1;
                     rdn_prev = rdn;
-                    int pstalled = rpn >= 0.5 * rpn_prev && lastscale <= 0.1 && rpn <= 1e-7 * nh;
+                    int pstalled = rpn >= 0.5 * rpn_prev && lastscale <= 0.1 && rpn <= TERM_PSTALL * nh;
                     rpn_prev = rpn;
-                    if (mu <= gap_tol && (rdn <= res_tol * ndd || stalled) && (rpn <= 100.0 * res_tol * nh || pstalled) && laststep <= 1e-6) { st = 0; break; }
+                    if (mu <= gap_tol && (rdn <= res_tol * ndd || stalled) && (rpn <= TERM_PFAC * res_tol * nh || pstalled) && laststep <= 1e-6) { st = 0; break; }
                 }
                 if (POL_MU > 0 && mu <= polmu_next && rpn <= 1e-6 * nh && npol < 4) {
                     polmu_next = 1e-2 * mu;
