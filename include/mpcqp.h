@@ -219,6 +219,68 @@ int mpcqp_kf_predict(mpcqp_handle h, double* xhat0, const double* u0, const doub
 int mpcqp_kf_correct_device(mpcqp_handle h, double* xhat0, const double* y0m, const double* d0, void* stream);
 int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, const double* d0, void* stream);
 
+
+/* ---- which kernel runs a step; building specialised kernels ahead of the control loop -----------
+ * A step runs on (MPCQP_KERNEL_AOT) a kernel specialised on the handle's dimensions that is compiled
+ * into the library (the BASELINE shapes, csrc/mpcqp_dispatch.h), (MPCQP_KERNEL_ONDEMAND) a kernel
+ * specialised on demand for these dimensions and this pattern of constraint groups, compiled with
+ * the installation's hipcc and cached (csrc/mpcqp_kernels.hip), or (MPCQP_KERNEL_GENERIC) the
+ * runtime-dimension kernel (same source and numerics, about 4x slower; also the kernel of problems
+ * with custom linear constraints or nZ > 64).  mpcqp_step NEVER compiles: without a call of
+ * mpcqp_prepare (or a cached object from an earlier run / from mpcqp_prebuild) it uses the generic
+ * kernel.  The JuMP analogue is the one-time model build of init_optimization!
+ * (src/controller/linmpc.jl:303-339), which also happens before the control loop.
+ *   mpcqp_prepare      after mpcqp_set_bounds (the pattern of constraint groups is part of the key):
+ *                      compiles if needed (seconds, once per shape and machine), loads, returns the
+ *                      MPCQP_KERNEL_* kind the steps will run on (>= 0) or a negative error code.
+ *   mpcqp_kernel_kind  the kind a step would run on right now; never compiles.
+ *   mpcqp_row_groups   the handle's pattern of constraint groups (bit g: group g may hold finite rows;
+ *                      0 box lower [eps >= 0, hard dUmin], 1 box upper, 2 Umin, 3 Umax, 4 soft dUmin,
+ *                      5 soft dUmax, 6 Ymin, 7 Ymax, 8 xhat-min, 9 xhat-max, 10 Wmin, 11 Wmax).
+ *   mpcqp_prebuild     compile-only (no GPU, no handle): for build pipelines; dims->batch is ignored.
+ *   mpcqp_last_build_error  text of the last failed build of this thread.
+ * Environment: MPCQP_CACHE_DIR (default: <library dir>/spec_cache if writable, else
+ * $XDG_CACHE_HOME/mpcqp or ~/.cache/mpcqp), HIPCC (compiler binary), MPCQP_JIT=0 (never specialise). */
+#define MPCQP_KERNEL_GENERIC   0
+#define MPCQP_KERNEL_AOT       1
+#define MPCQP_KERNEL_ONDEMAND  2
+int mpcqp_prepare(mpcqp_handle h);
+int mpcqp_kernel_kind(mpcqp_handle h);
+int mpcqp_row_groups(mpcqp_handle h, uint32_t* row_groups);
+int mpcqp_prebuild(const mpcqp_dims* dims, uint32_t row_groups);
+const char* mpcqp_last_build_error(void);
+
+/* ---- several GPUs of one node behind one handle (contiguous shards, no coupling) -------
+ * mpcqp_multi_create makes one handle per entry of device_ids (an ordinal may repeat) and gives
+ * device g the problems [off_g, off_g + B_g) of the batch, B_g = floor(B/ndev) (+1 for the first
+ * B mod ndev devices).  Every array is problem-major, so a shard is ONE contiguous slice of each
+ * caller array: the set_* / step entry points below take the whole-batch HOST arrays of their
+ * single-device twins, slice them, and drive all devices concurrently (one stream per device; the
+ * step is enqueued everywhere before anything is awaited; results are copied back into the caller's
+ * arrays slice by slice -- the gather).  mpcqp_multi_handle gives the single-device handle of a shard
+ * for everything else (mpcqp_get, kf_*, prepare ...); mpcqp_multi_shard its offset and size.
+ * Device-resident data: call mpcqp_step_device on the shard handles with per-device pointers, and
+ * mpcqp_multi_gather_device to collect Z (nZ,B), u0 (nu,B), status (B) of all shards into buffers on
+ * one root device (hipMemcpyPeerAsync over xGMI; stream = a stream of the root device, or NULL). */
+typedef struct mpcqp_multi_s* mpcqp_multi;
+int mpcqp_multi_create(const mpcqp_dims* dims, const int32_t* device_ids, int32_t ndev, mpcqp_multi* out);
+int mpcqp_multi_destroy(mpcqp_multi mh);
+int mpcqp_multi_ndev(mpcqp_multi mh);
+mpcqp_handle mpcqp_multi_handle(mpcqp_multi mh, int32_t g);
+int mpcqp_multi_shard(mpcqp_multi mh, int32_t g, int32_t* offset, int32_t* count);
+int mpcqp_multi_set_model(mpcqp_multi mh, const double* Ahat, const double* Bu, const double* C,
+                          const double* Bd, const double* Dd, const double* fop_minus_xop);
+int mpcqp_multi_set_weights(mpcqp_multi mh, const double* Mdiag, const double* Ndiag,
+                            const double* Ldiag, const double* Cwt);
+int mpcqp_multi_set_bounds(mpcqp_multi mh, const mpcqp_bounds* bounds);
+int mpcqp_multi_prepare(mpcqp_multi mh);
+int mpcqp_multi_step(mpcqp_multi mh, const double* xhat0, const double* lastu0, const double* Ry,
+                     const double* Ru, const double* d0, const double* Dhat0, double* Ztilde,
+                     double* u0, int32_t* status, int32_t* iters, double* Yhat0);
+int mpcqp_multi_gather_device(mpcqp_multi mh, int32_t root, const double* const* Z_shards,
+                              const double* const* u0_shards, const int32_t* const* status_shards,
+                              double* Z_root, double* u0_root, int32_t* status_root, void* stream);
+
 /* Device time of the kernels of the last step / recondense on this handle, measured with HIP
  * events on the stream they ran on (milliseconds; < 0 if not available).                     */
 double mpcqp_last_step_ms(mpcqp_handle h);

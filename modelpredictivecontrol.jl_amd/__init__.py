@@ -4,9 +4,9 @@ JuliaControl/ModelPredictiveControl.jl behind a C-ABI (include/mpcqp.h).
 The directory name carries a dot, so it is imported through the `mpcqp` alias package at the
 repository root (`import mpcqp`), which points its `__path__` here.
 """
-from .api import (BatchLinMPC, Handle, MpcqpError, load_library, move_blocking, colmajor,  # noqa: F401
+from .api import (BatchLinMPC, Handle, MultiHandle, MpcqpError, load_library, move_blocking, colmajor,  # noqa: F401
                   steady_kalman_gain,
                   STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR, EXPORTS,
                   FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL,
                   GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC)
-from . import synth  # noqa: F401
+from . import synth, sharding  # noqa: F401

@@ -26,7 +26,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libmpcqp.so")
 
 # flags / codes of include/mpcqp.h
-FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL = 1, 2, 4, 8
+FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL, FLAG_NO_POLISH = 1, 2, 4, 8, 16
+KERNEL_GENERIC, KERNEL_AOT, KERNEL_ONDEMAND = 0, 1, 2
 STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
 GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC = 1, 2, 3, 4, 5, 6
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
@@ -35,7 +36,10 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
            "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
-           "mpcqp_set_flags")
+           "mpcqp_set_flags", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_row_groups", "mpcqp_prebuild",
+           "mpcqp_last_build_error", "mpcqp_multi_create", "mpcqp_multi_destroy", "mpcqp_multi_ndev",
+           "mpcqp_multi_handle", "mpcqp_multi_shard", "mpcqp_multi_set_model", "mpcqp_multi_set_weights",
+           "mpcqp_multi_set_bounds", "mpcqp_multi_prepare", "mpcqp_multi_step", "mpcqp_multi_gather_device")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -107,6 +111,23 @@ def load_library(path: str | None = None):
     lib.mpcqp_kf_predict.argtypes = [C.c_void_p] * 4
     lib.mpcqp_kf_correct_device.argtypes = [C.c_void_p] * 5
     lib.mpcqp_kf_predict_device.argtypes = [C.c_void_p] * 5
+    lib.mpcqp_prepare.argtypes = [C.c_void_p]
+    lib.mpcqp_kernel_kind.argtypes = [C.c_void_p]
+    lib.mpcqp_row_groups.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.mpcqp_prebuild.argtypes = [C.POINTER(Dims), C.c_uint32]
+    lib.mpcqp_last_build_error.restype = C.c_char_p
+    lib.mpcqp_multi_create.argtypes = [C.POINTER(Dims), _ip, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.mpcqp_multi_destroy.argtypes = [C.c_void_p]
+    lib.mpcqp_multi_ndev.argtypes = [C.c_void_p]
+    lib.mpcqp_multi_handle.restype = C.c_void_p
+    lib.mpcqp_multi_handle.argtypes = [C.c_void_p, C.c_int32]
+    lib.mpcqp_multi_shard.argtypes = [C.c_void_p, C.c_int32, _ip, _ip]
+    lib.mpcqp_multi_set_model.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.mpcqp_multi_set_weights.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    lib.mpcqp_multi_set_bounds.argtypes = [C.c_void_p, C.POINTER(Bounds)]
+    lib.mpcqp_multi_prepare.argtypes = [C.c_void_p]
+    lib.mpcqp_multi_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
+    lib.mpcqp_multi_gather_device.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     _lib = lib
     return lib
 
@@ -180,6 +201,27 @@ class Handle:
     def set_flags(self, flags):
         _chk(self.lib, self.lib.mpcqp_set_flags(self.h, int(flags)))
         self.flags = int(flags)
+
+    def prepare(self):
+        """Build/load the specialised step kernel of the current shape and constraint pattern
+        (mpcqp_prepare); returns KERNEL_GENERIC / KERNEL_AOT / KERNEL_ONDEMAND.  Steps never compile."""
+        k = self.lib.mpcqp_prepare(self.h)
+        if k < 0:
+            _chk(self.lib, k)
+        if k == KERNEL_GENERIC:
+            msg = self.lib.mpcqp_last_build_error().decode()
+            if msg:
+                warnings.warn(f"mpcqp: specialised kernel not available, using the runtime-dimension "
+                              f"kernel ({msg})", RuntimeWarning)
+        return k
+
+    def kernel_kind(self):
+        return self.lib.mpcqp_kernel_kind(self.h)
+
+    def row_groups(self):
+        g = C.c_uint32()
+        _chk(self.lib, self.lib.mpcqp_row_groups(self.h, C.byref(g)))
+        return int(g.value)
 
     def set_custom_constraints(self, nw, Wy=None, Wu=None, Wd=None, Wr=None, w_op=None):
         args = [None if a is None else _f64(a) for a in (Wy, Wu, Wd, Wr, w_op)]
@@ -271,6 +313,82 @@ class Handle:
 
     def last_condense_ms(self):
         return self.lib.mpcqp_last_condense_ms(self.h)
+
+
+class MultiHandle:
+    """Binding of the mpcqp_multi_* entry points: one batch over several GPUs of a node (an ordinal
+    may repeat), whole-batch HOST arrays in, whole-batch HOST arrays out."""
+
+    def __init__(self, B, nxhat, nu, ny, nd, Hp, Hc, devices, nb=None, neps=1, flags=0, max_iter=0,
+                 gap_tol=0.0, res_tol=0.0, dual_reg=0.0, lib=None):
+        self.lib = lib or load_library()
+        d = Dims(batch=B, nxhat=nxhat, nu=nu, ny=ny, nd=nd, Hp=Hp, Hc=Hc, neps=neps, device=0, flags=flags,
+                 max_iter=max_iter, gap_tol=gap_tol, res_tol=res_tol, dual_reg=dual_reg)
+        self._nb = None
+        if nb is not None:
+            self._nb = (C.c_int32 * len(nb))(*[int(v) for v in nb])
+            d.nb = C.cast(self._nb, _ip)
+        dev = (C.c_int32 * len(devices))(*[int(v) for v in devices])
+        self.h = C.c_void_p()
+        _chk(self.lib, self.lib.mpcqp_multi_create(C.byref(d), dev, len(devices), C.byref(self.h)))
+        self.B, self.nxhat, self.nu, self.ny, self.nd, self.Hp, self.Hc = B, nxhat, nu, ny, nd, Hp, Hc
+        self.nDU, self.nZ, self.nU, self.nY, self.nD = nu * Hc, nu * Hc + neps, nu * Hp, ny * Hp, nd * Hp
+        self.flags = flags
+        self.ndev = self.lib.mpcqp_multi_ndev(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.mpcqp_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, g):
+        o, n = C.c_int32(), C.c_int32()
+        _chk(self.lib, self.lib.mpcqp_multi_shard(self.h, g, C.byref(o), C.byref(n)))
+        return int(o.value), int(n.value)
+
+    def set_model(self, Ahat, Bu, Cm, Bd=None, Dd=None, dop=None):
+        args = [None if a is None else _f64(a) for a in (Ahat, Bu, Cm, Bd, Dd, dop)]
+        _chk(self.lib, self.lib.mpcqp_multi_set_model(self.h, *[_ptr(a) for a in args]))
+
+    def set_weights(self, Mdiag, Ndiag, Ldiag, Cwt=None):
+        args = [None if a is None else _f64(a) for a in (Mdiag, Ndiag, Ldiag, Cwt)]
+        _chk(self.lib, self.lib.mpcqp_multi_set_weights(self.h, *[_ptr(a) for a in args]))
+
+    def set_bounds(self, **kw):
+        b = Bounds()
+        keep = []
+        for k in BOUND_FIELDS:
+            v = kw.get(k)
+            if v is not None:
+                a = _f64(v)
+                keep.append(a)
+                setattr(b, k, a.ctypes.data_as(_dp))
+        _chk(self.lib, self.lib.mpcqp_multi_set_bounds(self.h, C.byref(b)))
+
+    def prepare(self):
+        k = self.lib.mpcqp_multi_prepare(self.h)
+        if k < 0:
+            _chk(self.lib, k)
+        return k
+
+    def step(self, xhat0, lastu0, Ry, Z, Ru=None, d0=None, Dhat0=None, want_Yhat=False):
+        B = self.B
+        x, lu, ry = _f64(xhat0), _f64(lastu0), _f64(Ry)
+        ru = None if Ru is None else _f64(Ru)
+        dd0 = None if d0 is None else _f64(d0)
+        dh = None if Dhat0 is None else _f64(Dhat0)
+        assert Z.dtype == np.float64 and Z.flags.c_contiguous and Z.size == B * self.nZ
+        u0 = np.empty((B, self.nu)); status = np.empty(B, np.int32); iters = np.empty(B, np.int32)
+        yh = np.empty((B, self.nY)) if want_Yhat else None
+        _chk(self.lib, self.lib.mpcqp_multi_step(self.h, _ptr(x), _ptr(lu), _ptr(ry), _ptr(ru), _ptr(dd0), _ptr(dh),
+                                                 _ptr(Z), _ptr(u0), _ptr(status), _ptr(iters), _ptr(yh)))
+        return (u0, status, iters, yh) if want_Yhat else (u0, status, iters)
 
 
 def steady_kalman_gain(Ahat, Chat, Qhat, Rhat, i_ym=None):
@@ -391,6 +509,7 @@ class BatchLinMPC:
                                            colmajor(self.Wd) if nd > 0 else None, colmajor(self.Wr), w_op)
         # default constraints: none (src/controller/construct.jl:887-913)
         self._b = {k: None for k in BOUND_FIELDS}
+        self._prepared = False                     # specialised kernel built/loaded for the current pattern
         self.Z = np.zeros((B, self.nZ))            # mpc.Z̃ (previous optimum)
         self.lastu0 = np.zeros((B, nu))            # mpc.lastu0
         self.solved_once = False
@@ -557,6 +676,7 @@ class BatchLinMPC:
                     raise RuntimeError("Cannot modify ±Inf constraints after calling moveinput!")
         self._b = new
         self.hd.set_bounds(**{k: v for k, v in new.items() if v is not None})
+        self._prepared = False
         if self.nw > 0 and any(neww[k] is not self._wb[k] for k in neww):
             fin = lambda a: None if a is None or np.all(np.isinf(a)) else a
             self.hd.set_custom_bounds(fin(neww["Wmin"]), fin(neww["Wmax"]), neww["C_wmin"], neww["C_wmax"])
@@ -627,6 +747,9 @@ class BatchLinMPC:
             d0, Dh0 = d - self.dop, Dhat - self.Dop
         elif d is not None and np.size(d) != 0:
             raise ValueError("d size must be (0,)")
+        if not self._prepared:                     # like JuMP's model build: before the loop, not in mpcqp_step
+            self.kernel = self.hd.prepare()
+            self._prepared = True
         out = self.hd.step(xhat0, lastu0, (ry - self.yop) if held else (Rhaty - self.Yop), self.Z,
                            Ru=None if Rhatu is None else Rhatu - self.Uop, d0=d0, Dhat0=Dh0,
                            want_Yhat=want_info)

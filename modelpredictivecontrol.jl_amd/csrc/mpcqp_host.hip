@@ -24,6 +24,23 @@ static thread_local std::string g_hip_err;
         }                                                                            \
     } while (0)
 
+// Every entry point selects the handle's device; the caller's current device is restored when the
+// entry point returns (a torch process, or a Julia host driving several handles, keeps its own).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define ON_DEVICE(h)                                                                   \
+    DeviceGuard guard_((h)->device);                                                   \
+    if (!guard_.ok) { g_hip_err = "hipSetDevice failed"; return MPCQP_ERR_DEVICE; }
+
 struct DBuf {                      // owned device array of doubles (or ints)
     void* p = nullptr;
     size_t bytes = 0;
@@ -68,12 +85,25 @@ static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
     return MPCQP_OK;
 }
 
+// A step enqueued on a caller's stream (mpcqp_step_device) may still read the handle's device
+// arrays: every upload into them is ordered behind the end of that step (event ev_s1).
 static int upload(mpcqp_handle h, DBuf& b, const void* src, size_t bytes) {
     int rc = dev_alloc(h, b, bytes);
     if (rc) return rc;
+    if (h->step_timed) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_s1, 0));
     HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
     return MPCQP_OK;
 }
+
+// slice of a problem-major array with `per` values per problem (NULL stays NULL)
+template <class T>
+static T* shard_of(T* a, int off, size_t per) { return a ? a + (size_t)off * per : nullptr; }
+
+struct mpcqp_multi_s {
+    std::vector<mpcqp_handle> h;
+    std::vector<int> off, cnt;
+    Dims d{};                       // whole-batch dimensions (B = total)
+};
 
 extern "C" {
 
@@ -134,7 +164,8 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (in->device < 0 || in->device >= ndev) return MPCQP_ERR_ARG;
-    HIPCHK(hipSetDevice(in->device));
+    DeviceGuard guard_(in->device);
+    if (!guard_.ok) { g_hip_err = "hipSetDevice failed"; return MPCQP_ERR_DEVICE; }
     mpcqp_handle h = new (std::nothrow) mpcqp_handle_s();
     if (!h) return MPCQP_ERR_NOMEM;
     Dims& d = h->d;
@@ -202,7 +233,7 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
 
 int mpcqp_destroy(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard_(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->ev_s0) (void)hipEventDestroy(h->ev_s0);
@@ -236,6 +267,7 @@ static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
         h->m.exT = (double*)a.p; h->m.kxT = (double*)b.p; h->m.bxv = (double*)c.p;
         h->m.Xdtab = d.nd > 0 ? (double*)x.p : nullptr;
     }
+    if (h->step_timed && st == h->stream) HIPCHK(hipStreamWaitEvent(st, h->ev_s1, 0));
     if (timed) HIPCHK(hipEventRecord(h->ev_c0, st));
     HIPCHK(launch_predmat(d, h->m, term, st));
     h->terminal_built = term;
@@ -249,7 +281,7 @@ int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const 
     if (!h || !Ahat || !Bu || !C) return MPCQP_ERR_NULL;
     const Dims& d = h->d;
     if (d.nd > 0 && (!Bd || !Dd)) return MPCQP_ERR_NULL;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t B = d.B, sz = sizeof(double);
     int rc = upload(h, h->Ahat, Ahat, B * d.nxh * d.nxh * sz);
     if (!rc) rc = upload(h, h->Bu, Bu, B * d.nxh * d.nu * sz);
@@ -275,7 +307,7 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
     if (!h || !Mdiag || !Ndiag || !Ldiag) return MPCQP_ERR_NULL;
     const Dims& d = h->d;
     if (d.neps && !Cwt) return MPCQP_ERR_NULL;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t B = d.B, sz = sizeof(double);
     int rc = upload(h, h->Mdiag, Mdiag, B * d.nY * sz);
     if (!rc) rc = upload(h, h->Ndiag, Ndiag, B * d.nDU * sz);
@@ -297,7 +329,7 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
     if (!h) return MPCQP_ERR_NULL;
     const Dims& d = h->d;
     if (!h->have_weights) return MPCQP_ERR_ORDER;       // N, L, C come from mpcqp_set_weights
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     if (Mblk) {
         int rc = upload(h, h->Mblk, Mblk, (size_t)d.B * d.Hp * d.ny * d.ny * sizeof(double));
         if (rc) return rc;
@@ -327,7 +359,7 @@ int mpcqp_set_custom_constraints(mpcqp_handle h, int nw, const double* Wy, const
     Dims& d = h->d;
     if (nw < 0) return MPCQP_ERR_ARG;
     if (nw > 0 && (!Wy || !Wu)) return MPCQP_ERR_NULL;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     Model& m = h->m;
     d.nw = nw; d.nW = nw * (d.Hp + 1);
     d.gmask &= ~(3u << (2 * P_W));          // bounds of a previous definition are dropped
@@ -357,7 +389,7 @@ int mpcqp_set_custom_bounds(mpcqp_handle h, const double* Wmin, const double* Wm
     Dims& d = h->d;
     if (d.nw < 1) return MPCQP_ERR_ORDER;               // mpcqp_set_custom_constraints first
     if (!d.neps && (C_wmin || C_wmax)) return MPCQP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     Model& m = h->m;
     const size_t n = (size_t)d.B * d.nW * sizeof(double);
     const double* src[4] = {Wmin, Wmax, C_wmin, C_wmax};
@@ -398,7 +430,7 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
                         if (cu[b * d.nU + t * d.nu + c] != cu[b * d.nU + h->jl[j] * d.nu + c])
                             return MPCQP_ERR_UNSUPPORTED;
     }
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const double* src[16] = {bin->U0min, bin->U0max, bin->DUmin, bin->DUmax, bin->Y0min, bin->Y0max,
                              bin->x0min, bin->x0max, bin->C_umin, bin->C_umax, bin->C_dumin,
                              bin->C_dumax, bin->C_ymin, bin->C_ymax, bin->c_x0min, bin->c_x0max};
@@ -448,7 +480,7 @@ int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
     if (step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     StepIO io{};
     io.xhat0 = xhat0; io.lastu0 = lastu0; io.Ry = Ry; io.Ru = Ru; io.d0 = d0; io.Dhat0 = Dhat0;
@@ -488,7 +520,7 @@ int mpcqp_step(mpcqp_handle h, const double* xhat0, const double* lastu0, const 
     if (!h || !xhat0 || !lastu0 || !Ry || !Ztilde || !u0 || !status) return MPCQP_ERR_NULL;
     const Dims& d = h->d;
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t B = d.B, sz = sizeof(double);
     const size_t nry = (d.flags & MPCQP_FLAG_RY_CONSTANT) ? d.ny : d.nY;
     int rc = upload(h, h->s_x, xhat0, B * d.nxh * sz);
@@ -522,14 +554,14 @@ int mpcqp_step(mpcqp_handle h, const double* xhat0, const double* lastu0, const 
 int mpcqp_recondense_device(mpcqp_handle h, void* stream) {
     if (!h) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     return condense(h, (hipStream_t)stream, true);
 }
 
 int mpcqp_get(mpcqp_handle h, int which, double* out) {
     if (!h || !out) return MPCQP_ERR_NULL;
     const Dims& d = h->d;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipDeviceSynchronize());
     const size_t B = d.B;
@@ -581,10 +613,12 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
             if (!h->keep_F.p) return MPCQP_ERR_ORDER;
             HIPCHK(hipMemcpy(out, h->keep_F.p, B * d.nY * sizeof(double), hipMemcpyDeviceToHost));
             return MPCQP_OK;
-        case 99:     /* per-phase cycle counters of profiling builds: (16,B) */
+#ifdef MPCQP_PROFILE
+        case 99:     /* per-phase cycle counters of profiling builds (-DMPCQP_PROFILE): (16,B) */
             if (!h->prof.p) return MPCQP_ERR_ORDER;
             HIPCHK(hipMemcpy(out, h->prof.p, B * 16 * sizeof(double), hipMemcpyDeviceToHost));
             return MPCQP_OK;
+#endif
         default:
             return MPCQP_ERR_ARG;
     }
@@ -600,7 +634,7 @@ int mpcqp_kf_set(mpcqp_handle h, const double* Khat, const int32_t* i_ym, int32_
         for (int j = 0; j < i; ++j)
             if (i_ym[j] == i_ym[i]) return MPCQP_ERR_ARG;
     }
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     int rc = upload(h, h->kf_K, Khat, (size_t)d.B * d.nxh * nym * sizeof(double));
     if (!rc) rc = upload(h, h->kf_iym, i_ym, (size_t)nym * sizeof(int32_t));
     if (rc) return rc;
@@ -616,7 +650,7 @@ int mpcqp_kf_correct_device(mpcqp_handle h, double* xhat0, const double* y0m, co
     if (!h || !xhat0 || !y0m) return MPCQP_ERR_NULL;
     if (h->d.nd > 0 && !d0) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_kf) return MPCQP_ERR_ORDER;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(launch_kf_correct(h->d, h->m, h->kf, xhat0, y0m, d0, (hipStream_t)stream));
     return MPCQP_OK;
 }
@@ -626,7 +660,7 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
     if (h->d.nd > 0 && !d0) return MPCQP_ERR_NULL;
     if (!h->have_model) return MPCQP_ERR_ORDER;
     if (h->d.nxh > 64) return MPCQP_ERR_UNSUPPORTED;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(launch_kf_predict(h->d, h->m, xhat0, u0, d0, (hipStream_t)stream));
     return MPCQP_OK;
 }
@@ -635,7 +669,7 @@ static int kf_host(mpcqp_handle h, double* xhat0, const double* a, size_t na, co
     if (!h || !xhat0 || !a) return MPCQP_ERR_NULL;
     const Dims& d = h->d;
     if (d.nd > 0 && !d0) return MPCQP_ERR_NULL;
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t B = d.B, sz = sizeof(double);
     int rc = upload(h, h->kf_x, xhat0, B * d.nxh * sz);
     if (!rc) rc = upload(h, correct ? h->kf_y : h->kf_u, a, B * na * sz);
@@ -657,6 +691,220 @@ int mpcqp_kf_correct(mpcqp_handle h, double* xhat0, const double* y0m, const dou
 
 int mpcqp_kf_predict(mpcqp_handle h, double* xhat0, const double* u0, const double* d0) {
     return kf_host(h, xhat0, u0, h ? (size_t)h->d.nu : 0, d0, false);
+}
+
+static thread_local std::string g_build_err;
+
+const char* mpcqp_last_build_error(void) { return g_build_err.c_str(); }
+
+int mpcqp_prepare(mpcqp_handle h) {
+    if (!h) return MPCQP_ERR_NULL;
+    g_build_err.clear();
+    return prepare_step(h->d, &g_build_err);
+}
+
+int mpcqp_kernel_kind(mpcqp_handle h) {
+    if (!h) return MPCQP_ERR_NULL;
+    return step_kernel_kind(h->d);
+}
+
+int mpcqp_row_groups(mpcqp_handle h, uint32_t* row_groups) {
+    if (!h || !row_groups) return MPCQP_ERR_NULL;
+    *row_groups = h->d.gmask;
+    return MPCQP_OK;
+}
+
+int mpcqp_prebuild(const mpcqp_dims* in, uint32_t row_groups) {
+    if (!in) return MPCQP_ERR_NULL;
+    if (in->nxhat < 1 || in->nu < 1 || in->ny < 1 || in->Hp < 1 || in->Hc < 1 || in->Hc > in->Hp ||
+        (in->neps != 0 && in->neps != 1) || (row_groups >> NGROUP))
+        return MPCQP_ERR_ARG;
+    Dims d{};
+    d.nxh = in->nxhat; d.nu = in->nu; d.ny = in->ny; d.nd = in->nd; d.Hp = in->Hp; d.Hc = in->Hc; d.neps = in->neps;
+    d.nDU = d.nu * d.Hc; d.nZ = d.nDU + d.neps; d.nU = d.nu * d.Hp; d.nY = d.ny * d.Hp;
+    d.gmask = row_groups;
+    d.default_nb = 1;
+    if (in->nb)
+        for (int i = 0; i < d.Hc; ++i)
+            if (in->nb[i] != (i == d.Hc - 1 ? d.Hp - d.Hc + 1 : 1)) d.default_nb = 0;
+    g_build_err.clear();
+    const int k = prebuild_step(d, &g_build_err);
+    return k < 0 ? MPCQP_ERR_DEVICE : k;
+}
+
+// ---- several devices behind one handle ---------------------------------------------------------
+int mpcqp_multi_create(const mpcqp_dims* in, const int32_t* device_ids, int32_t ndev, mpcqp_multi* out) {
+    if (!in || !device_ids || !out) return MPCQP_ERR_NULL;
+    *out = nullptr;
+    if (ndev < 1 || in->batch < ndev) return MPCQP_ERR_ARG;
+    mpcqp_multi mh = new (std::nothrow) mpcqp_multi_s();
+    if (!mh) return MPCQP_ERR_NOMEM;
+    const int B = in->batch, base = B / ndev, rem = B % ndev;
+    int o = 0;
+    for (int g = 0; g < ndev; ++g) {
+        mpcqp_dims dg = *in;
+        dg.batch = base + (g < rem ? 1 : 0);
+        dg.device = device_ids[g];
+        mpcqp_handle hg = nullptr;
+        const int rc = mpcqp_create(&dg, &hg);
+        if (rc) { mpcqp_multi_destroy(mh); return rc; }
+        mh->h.push_back(hg);
+        mh->off.push_back(o);
+        mh->cnt.push_back(dg.batch);
+        o += dg.batch;
+    }
+    mh->d = mh->h[0]->d;
+    mh->d.B = B;
+    *out = mh;
+    return MPCQP_OK;
+}
+
+int mpcqp_multi_destroy(mpcqp_multi mh) {
+    if (!mh) return MPCQP_ERR_NULL;
+    for (mpcqp_handle hg : mh->h) (void)mpcqp_destroy(hg);
+    delete mh;
+    return MPCQP_OK;
+}
+
+int mpcqp_multi_ndev(mpcqp_multi mh) { return mh ? (int)mh->h.size() : MPCQP_ERR_NULL; }
+
+mpcqp_handle mpcqp_multi_handle(mpcqp_multi mh, int32_t g) {
+    return (mh && g >= 0 && g < (int)mh->h.size()) ? mh->h[g] : nullptr;
+}
+
+int mpcqp_multi_shard(mpcqp_multi mh, int32_t g, int32_t* offset, int32_t* count) {
+    if (!mh || !offset || !count) return MPCQP_ERR_NULL;
+    if (g < 0 || g >= (int)mh->h.size()) return MPCQP_ERR_ARG;
+    *offset = mh->off[g]; *count = mh->cnt[g];
+    return MPCQP_OK;
+}
+
+int mpcqp_multi_set_model(mpcqp_multi mh, const double* Ahat, const double* Bu, const double* C,
+                          const double* Bd, const double* Dd, const double* dop) {
+    if (!mh) return MPCQP_ERR_NULL;
+    const Dims& d = mh->d;
+    for (size_t g = 0; g < mh->h.size(); ++g) {
+        const int o = mh->off[g];
+        const int rc = mpcqp_set_model(mh->h[g], shard_of(Ahat, o, (size_t)d.nxh * d.nxh), shard_of(Bu, o, (size_t)d.nxh * d.nu),
+                                       shard_of(C, o, (size_t)d.ny * d.nxh), shard_of(Bd, o, (size_t)d.nxh * d.nd),
+                                       shard_of(Dd, o, (size_t)d.ny * d.nd), shard_of(dop, o, d.nxh));
+        if (rc) return rc;
+    }
+    return MPCQP_OK;
+}
+
+int mpcqp_multi_set_weights(mpcqp_multi mh, const double* Mdiag, const double* Ndiag, const double* Ldiag,
+                            const double* Cwt) {
+    if (!mh) return MPCQP_ERR_NULL;
+    const Dims& d = mh->d;
+    for (size_t g = 0; g < mh->h.size(); ++g) {
+        const int o = mh->off[g];
+        const int rc = mpcqp_set_weights(mh->h[g], shard_of(Mdiag, o, d.nY), shard_of(Ndiag, o, d.nDU),
+                                         shard_of(Ldiag, o, d.nU), shard_of(Cwt, o, 1));
+        if (rc) return rc;
+    }
+    return MPCQP_OK;
+}
+
+int mpcqp_multi_set_bounds(mpcqp_multi mh, const mpcqp_bounds* b) {
+    if (!mh || !b) return MPCQP_ERR_NULL;
+    const Dims& d = mh->d;
+    for (size_t g = 0; g < mh->h.size(); ++g) {
+        const int o = mh->off[g];
+        mpcqp_bounds s{};
+        s.U0min = shard_of(b->U0min, o, d.nU); s.U0max = shard_of(b->U0max, o, d.nU);
+        s.DUmin = shard_of(b->DUmin, o, d.nDU); s.DUmax = shard_of(b->DUmax, o, d.nDU);
+        s.Y0min = shard_of(b->Y0min, o, d.nY); s.Y0max = shard_of(b->Y0max, o, d.nY);
+        s.x0min = shard_of(b->x0min, o, d.nxh); s.x0max = shard_of(b->x0max, o, d.nxh);
+        s.C_umin = shard_of(b->C_umin, o, d.nU); s.C_umax = shard_of(b->C_umax, o, d.nU);
+        s.C_dumin = shard_of(b->C_dumin, o, d.nDU); s.C_dumax = shard_of(b->C_dumax, o, d.nDU);
+        s.C_ymin = shard_of(b->C_ymin, o, d.nY); s.C_ymax = shard_of(b->C_ymax, o, d.nY);
+        s.c_x0min = shard_of(b->c_x0min, o, d.nxh); s.c_x0max = shard_of(b->c_x0max, o, d.nxh);
+        const int rc = mpcqp_set_bounds(mh->h[g], &s);
+        if (rc) return rc;
+    }
+    return MPCQP_OK;
+}
+
+int mpcqp_multi_prepare(mpcqp_multi mh) {
+    if (!mh) return MPCQP_ERR_NULL;
+    int kind = MPCQP_KERNEL_ONDEMAND;
+    for (mpcqp_handle hg : mh->h) {
+        const int k = mpcqp_prepare(hg);
+        if (k < 0) return k;
+        if (k < kind || k == MPCQP_KERNEL_AOT) kind = k;
+    }
+    return kind;
+}
+
+int mpcqp_multi_step(mpcqp_multi mh, const double* xhat0, const double* lastu0, const double* Ry,
+                     const double* Ru, const double* d0, const double* Dhat0, double* Ztilde,
+                     double* u0, int32_t* status, int32_t* iters, double* Yhat0) {
+    if (!mh || !xhat0 || !lastu0 || !Ry || !Ztilde || !u0 || !status) return MPCQP_ERR_NULL;
+    const Dims& dd = mh->d;
+    if (dd.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
+    const size_t sz = sizeof(double);
+    // phase 1: uploads and the step kernel enqueued on every device's stream
+    for (size_t g = 0; g < mh->h.size(); ++g) {
+        mpcqp_handle h = mh->h[g];
+        const Dims& d = h->d;
+        const int o = mh->off[g];
+        const size_t B = d.B;
+        const size_t nry = (d.flags & MPCQP_FLAG_RY_CONSTANT) ? d.ny : d.nY;
+        ON_DEVICE(h);
+        int rc = upload(h, h->s_x, shard_of(xhat0, o, d.nxh), B * d.nxh * sz);
+        if (!rc) rc = upload(h, h->s_lu, shard_of(lastu0, o, d.nu), B * d.nu * sz);
+        if (!rc) rc = upload(h, h->s_ry, shard_of(Ry, o, nry), B * nry * sz);
+        if (!rc && Ru) rc = upload(h, h->s_ru, shard_of(Ru, o, d.nU), B * d.nU * sz);
+        if (!rc && d.nd > 0) rc = upload(h, h->s_d0, shard_of(d0, o, d.nd), B * d.nd * sz);
+        if (!rc && d.nd > 0) rc = upload(h, h->s_dh, shard_of(Dhat0, o, d.nD), B * d.nD * sz);
+        if (!rc) rc = upload(h, h->s_Z, shard_of(Ztilde, o, d.nZ), B * d.nZ * sz);
+        if (!rc) rc = dev_alloc(h, h->s_u0, B * d.nu * sz);
+        if (!rc) rc = dev_alloc(h, h->s_st, B * sizeof(int32_t));
+        if (!rc) rc = dev_alloc(h, h->s_it, B * sizeof(int32_t));
+        if (!rc && Yhat0) rc = dev_alloc(h, h->s_yh, B * d.nY * sz);
+        if (rc) return rc;
+        rc = mpcqp_step_device(h, (const double*)h->s_x.p, (const double*)h->s_lu.p, (const double*)h->s_ry.p,
+                               Ru ? (const double*)h->s_ru.p : nullptr,
+                               d.nd > 0 ? (const double*)h->s_d0.p : nullptr,
+                               d.nd > 0 ? (const double*)h->s_dh.p : nullptr, (double*)h->s_Z.p,
+                               (double*)h->s_u0.p, (int32_t*)h->s_st.p, (int32_t*)h->s_it.p,
+                               Yhat0 ? (double*)h->s_yh.p : nullptr, h->stream);
+        if (rc) return rc;
+        // the gather: each shard's results into its slice of the caller's arrays
+        HIPCHK(hipMemcpyAsync(shard_of(Ztilde, o, d.nZ), h->s_Z.p, B * d.nZ * sz, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(shard_of(u0, o, d.nu), h->s_u0.p, B * d.nu * sz, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(shard_of(status, o, 1), h->s_st.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        if (iters) HIPCHK(hipMemcpyAsync(shard_of(iters, o, 1), h->s_it.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        if (Yhat0) HIPCHK(hipMemcpyAsync(shard_of(Yhat0, o, d.nY), h->s_yh.p, B * d.nY * sz, hipMemcpyDeviceToHost, h->stream));
+    }
+    // phase 2: wait for every device
+    for (mpcqp_handle h : mh->h) {
+        ON_DEVICE(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return MPCQP_OK;
+}
+
+int mpcqp_multi_gather_device(mpcqp_multi mh, int32_t root, const double* const* Z_shards,
+                              const double* const* u0_shards, const int32_t* const* status_shards,
+                              double* Z_root, double* u0_root, int32_t* status_root, void* stream) {
+    if (!mh || !Z_shards || !u0_shards || !status_shards || !Z_root || !u0_root || !status_root) return MPCQP_ERR_NULL;
+    if (root < 0 || root >= (int)mh->h.size()) return MPCQP_ERR_ARG;
+    mpcqp_handle hr = mh->h[root];
+    ON_DEVICE(hr);
+    hipStream_t st = stream ? (hipStream_t)stream : hr->stream;
+    const Dims& d = mh->d;
+    for (size_t g = 0; g < mh->h.size(); ++g) {
+        const int o = mh->off[g], src = mh->h[g]->device;
+        const size_t B = mh->cnt[g];
+        if (!Z_shards[g] || !u0_shards[g] || !status_shards[g]) return MPCQP_ERR_NULL;
+        HIPCHK(hipMemcpyPeerAsync(shard_of(Z_root, o, d.nZ), hr->device, Z_shards[g], src, B * d.nZ * sizeof(double), st));
+        HIPCHK(hipMemcpyPeerAsync(shard_of(u0_root, o, d.nu), hr->device, u0_shards[g], src, B * d.nu * sizeof(double), st));
+        HIPCHK(hipMemcpyPeerAsync(shard_of(status_root, o, 1), hr->device, status_shards[g], src, B * sizeof(int32_t), st));
+    }
+    if (!stream) HIPCHK(hipStreamSynchronize(st));
+    return MPCQP_OK;
 }
 
 static double elapsed(hipEvent_t a, hipEvent_t b, bool timed) {

@@ -6,7 +6,11 @@
 #include <cstdlib>
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -14,6 +18,7 @@
 #include <mutex>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "mpcqp_bodies.h"
 #include "mpcqp_devwave.h"
@@ -66,11 +71,18 @@ static bool env_flag(const char* name, bool dflt) {
 static bool force_generic() { static const bool f = env_flag("MPCQP_FORCE_GENERIC", false); return f; }
 
 // ---- on-demand specialisation ----------------------------------------------------------------
-// Dimensions outside the ahead-of-time list get their own compile-time-dims kernel the first
-// time they are used: csrc/mpcqp_spec.hip is compiled with the installation's hipcc (the same
-// compiler as the ahead-of-time build), cached as lib/spec_cache/spec_<dims>.so and dlopen'ed.
-// MPCQP_JIT=0 disables it (generic runtime-dims kernel then); any failure falls back to the
-// generic kernel with one message on stderr.
+// Dimensions outside the ahead-of-time list get their own compile-time-dims kernel: csrc/mpcqp_spec.hip
+// is compiled with the installation's hipcc (the same compiler as the ahead-of-time build), cached as
+// spec_<rev>_<dims>.so and dlopen'ed.  The compilation NEVER happens inside a step: it is done by
+// prepare_step() (mpcqp_prepare / mpcqp_prebuild of the C-ABI), the step only looks the object up and
+// runs the runtime-dimension kernel when there is none.  The compiler is started with posix_spawn on an
+// argument vector (no shell: paths with spaces or metacharacters are data), its output goes to a log
+// file next to the object.
+//   MPCQP_JIT=0          no on-demand kernels at all
+//   HIPCC                the compiler binary (one path; default /opt/rocm/bin/hipcc)
+//   MPCQP_JIT_FLAGS      extra compiler arguments, space separated (experiments)
+//   MPCQP_CACHE_DIR      where the objects live; default <library dir>/spec_cache when that is writable,
+//                        else $XDG_CACHE_HOME/mpcqp or ~/.cache/mpcqp
 struct SpecLib {
     int (*matches)(const Dims*) = nullptr;
     int (*matches_dims)(const Dims*) = nullptr;
@@ -79,7 +91,7 @@ struct SpecLib {
 };
 using SpecKey = std::tuple<int, int, int, int, int, int, unsigned, int>;
 static std::mutex g_spec_mu;
-static std::map<SpecKey, SpecLib> g_spec;        // failed builds are cached as empty entries
+static std::map<SpecKey, SpecLib> g_spec;        // failed loads are cached as empty entries
 
 static std::string lib_dir() {
     Dl_info info;
@@ -89,54 +101,174 @@ static std::string lib_dir() {
     return s == std::string::npos ? "." : p.substr(0, s);
 }
 
-static const SpecLib* jit_specialise(const Dims& d) {
-    static const bool enabled = env_flag("MPCQP_JIT", true);
-    if (!enabled) return nullptr;
+static bool dir_writable(const std::string& d) {
+    struct stat sb;
+    if (stat(d.c_str(), &sb) != 0) {
+        if (mkdir(d.c_str(), 0755) != 0 && errno != EEXIST) return false;
+    }
+    return access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+static std::string cache_dir() {
+    if (const char* e = getenv("MPCQP_CACHE_DIR")) {
+        if (e[0]) { (void)dir_writable(e); return e; }
+    }
+    const std::string local = lib_dir() + "/spec_cache";
+    if (dir_writable(local)) return local;
+    std::string base;
+    if (const char* x = getenv("XDG_CACHE_HOME")) base = x;
+    if (base.empty()) {
+        const char* home = getenv("HOME");
+        base = std::string(home ? home : "/tmp") + "/.cache";
+        (void)dir_writable(base);
+    }
+    const std::string d = base + "/mpcqp";
+    (void)dir_writable(d);
+    return d;
+}
+
+static std::string spec_name(const Dims& d) {
+    char name[192];
+    snprintf(name, sizeof name, "spec_r%d_%d_%d_%d_%d_%d_%d_%x_%d.so", MPCQP_KERNEL_REV, d.nu, d.ny, d.nxh,
+             d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
+    return name;
+}
+
+static bool jit_enabled() {
+    static const bool on = env_flag("MPCQP_JIT", true);
+    return on;
+}
+
+static bool spec_eligible(const Dims& d) {     // (custom linear constraints and nZ~ > 64 run on the runtime-dims kernel)
+    return d.nw == 0 && d.nZ <= WAVE;
+}
+
+// run `argv` (argv[0] = binary), stdout+stderr appended to `log`; returns the exit status, -1 on failure to start
+static int run_process(const std::vector<std::string>& argv, const std::string& log) {
+    std::vector<char*> av;
+    for (const std::string& a : argv) av.push_back(const_cast<char*>(a.c_str()));
+    av.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    pid_t pid = 0;
+    extern char** environ;
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) return -1;
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0) {
+        if (errno != EINTR) return -1;
+    }
+    return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+
+// compile the specialisation of `d` into the cache unless it is there already; 0 = present afterwards
+static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
+    const std::string cache = cache_dir(), so = cache + "/" + spec_name(d);
+    if (path_out) *path_out = so;
+    struct stat sb;
+    if (stat(so.c_str(), &sb) == 0) return 0;
+    if (access(cache.c_str(), W_OK | X_OK) != 0) {
+        if (err) *err = "specialisation cache directory " + cache + " is not writable (set MPCQP_CACHE_DIR)";
+        return -1;
+    }
+    const std::string src = lib_dir() + "/../csrc";
+    const char* hipcc = getenv("HIPCC");
+    char dims[160];
+    snprintf(dims, sizeof dims, "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu,%d", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps,
+             d.gmask, d.default_nb);
+    const std::string tmp = so + ".tmp" + std::to_string((long)getpid());   // (ranks of one job may build the same object)
+    std::vector<std::string> argv = {hipcc && hipcc[0] ? hipcc : "/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3",
+                                     "-std=c++17", "-shared", "-fPIC", "-w", "-I" + src, dims};
+    if (const char* extra = getenv("MPCQP_JIT_FLAGS")) {
+        std::string tok;
+        for (const char* c = extra;; ++c) {
+            if (*c == ' ' || *c == 0) { if (!tok.empty()) argv.push_back(tok); tok.clear(); if (!*c) break; }
+            else tok += *c;
+        }
+    }
+    argv.push_back(src + "/mpcqp_spec.hip");
+    argv.push_back("-o");
+    argv.push_back(tmp);
+    fprintf(stderr, "[mpcqp] specialising the step kernel for nu=%d ny=%d nxhat=%d Hp=%d Hc=%d neps=%d rows=0x%x "
+                    "(one-time, cached in %s)\n", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, cache.c_str());
+    const std::string log = so + ".log";
+    const int rc = run_process(argv, log);
+    if (rc != 0 || rename(tmp.c_str(), so.c_str()) != 0) {
+        (void)unlink(tmp.c_str());
+        if (err) *err = "compiling the specialisation failed (exit " + std::to_string(rc) + ", see " + log + ")";
+        return -1;
+    }
+    (void)unlink(log.c_str());
+    return 0;
+}
+
+// the loaded specialisation of `d`, or nullptr; loads a cached object, never compiles
+static const SpecLib* find_spec(const Dims& d, bool load) {
+    if (!jit_enabled() || !spec_eligible(d)) return nullptr;
     const SpecKey key{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb};
     std::lock_guard<std::mutex> lock(g_spec_mu);
     auto it = g_spec.find(key);
     if (it != g_spec.end()) return it->second.step ? &it->second : nullptr;
-    SpecLib sl;
-    const std::string dir = lib_dir(), cache = dir + "/spec_cache", src = dir + "/../csrc";
-    char name[160];
-    snprintf(name, sizeof name, "spec_r%d_%d_%d_%d_%d_%d_%d_%x_%d.so", MPCQP_KERNEL_REV, d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
-    const std::string so = cache + "/" + name;
+    if (!load) return nullptr;
+    const std::string so = cache_dir() + "/" + spec_name(d);
     struct stat sb;
-    if (stat(so.c_str(), &sb) != 0) {
-        mkdir(cache.c_str(), 0755);
-        const char* hipcc = getenv("HIPCC") ? getenv("HIPCC") : "/opt/rocm/bin/hipcc";
-        char cmd[2048];
-        snprintf(cmd, sizeof cmd,
-                 "%s --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -w -I%s "
-                 "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu,%d %s/mpcqp_spec.hip -o %s.tmp%d 2>&1 && mv %s.tmp%d %s",
-                 hipcc, src.c_str(), d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb, src.c_str(),
-                 so.c_str(), (int)getpid(), so.c_str(), (int)getpid(), so.c_str());   // (ranks of one job may build the same object)
-        fprintf(stderr, "[mpcqp] specialising the step kernel for nu=%d ny=%d nxhat=%d Hp=%d Hc=%d "
-                        "neps=%d rows=0x%x (one-time, cached in %s)\n",
-                d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, cache.c_str());
-        FILE* p = popen(cmd, "r");
-        std::string out;
-        if (p) {
-            char buf[512];
-            while (fgets(buf, sizeof buf, p)) out += buf;
-            const int rc = pclose(p);
-            if (rc != 0) fprintf(stderr, "[mpcqp] specialisation failed (rc=%d), using the generic kernel:\n%s\n", rc, out.c_str());
-        }
-    }
-    if (stat(so.c_str(), &sb) == 0) {
-        void* hdl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (hdl) {
-            sl.matches = (int (*)(const Dims*))dlsym(hdl, "mpcqp_spec_matches");
-            sl.matches_dims = (int (*)(const Dims*))dlsym(hdl, "mpcqp_spec_matches_dims");
-            sl.step = (int (*)(const Dims*, const Model*, const StepIO*, void*))dlsym(hdl, "mpcqp_spec_launch_step");
-            sl.hessian = (int (*)(const Dims*, const Model*, void*))dlsym(hdl, "mpcqp_spec_launch_hessian");
-            if (!sl.matches || !sl.step || !sl.hessian || !sl.matches(&d)) sl = SpecLib{};
-        } else {
-            fprintf(stderr, "[mpcqp] dlopen(%s) failed: %s\n", so.c_str(), dlerror());
-        }
+    if (stat(so.c_str(), &sb) != 0) return nullptr;              // not built (yet): nothing is remembered
+    SpecLib sl;
+    void* hdl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (hdl) {
+        sl.matches = (int (*)(const Dims*))dlsym(hdl, "mpcqp_spec_matches");
+        sl.matches_dims = (int (*)(const Dims*))dlsym(hdl, "mpcqp_spec_matches_dims");
+        sl.step = (int (*)(const Dims*, const Model*, const StepIO*, void*))dlsym(hdl, "mpcqp_spec_launch_step");
+        sl.hessian = (int (*)(const Dims*, const Model*, void*))dlsym(hdl, "mpcqp_spec_launch_hessian");
+        if (!sl.matches || !sl.step || !sl.hessian || !sl.matches(&d)) sl = SpecLib{};
+    } else {
+        fprintf(stderr, "[mpcqp] dlopen(%s) failed: %s\n", so.c_str(), dlerror());
     }
     auto res = g_spec.emplace(key, sl);
     return res.first->second.step ? &res.first->second : nullptr;
+}
+
+static bool aot_matches(const Dims& d) {
+#define X(NU, NY, NXH, HP, HC, NEPS, GM) \
+    if (StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>::matches(d)) return true;
+    MPCQP_SPECIALIZATIONS(X)
+#undef X
+    return false;
+}
+
+// Which kernel a step of `d` runs on: 0 the runtime-dimension kernel, 1 an ahead-of-time
+// specialisation, 2 an on-demand one (already loaded or loadable from the cache).
+int step_kernel_kind(const Dims& d) {
+    if (force_generic()) return 0;
+    if (aot_matches(d)) return 1;
+    return find_spec(d, true) ? 2 : 0;
+}
+
+// Make the specialised kernel of `d` available (compile if needed, load).  Returns the kernel kind
+// as step_kernel_kind(); `err` receives the reason when an eligible specialisation could not be built.
+int prepare_step(const Dims& d, std::string* err) {
+    if (force_generic()) return 0;
+    if (aot_matches(d)) return 1;
+    if (!jit_enabled() || !spec_eligible(d)) return 0;
+    if (find_spec(d, true)) return 2;
+    if (build_spec(d, nullptr, err) != 0) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_spec_mu);            // forget a remembered failure of an earlier load
+        g_spec.erase(SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb});
+    }
+    if (find_spec(d, true)) return 2;
+    if (err) *err = "the specialisation was built but could not be loaded";
+    return 0;
+}
+
+// compile only (no device, no load): for build pipelines
+int prebuild_step(const Dims& d, std::string* err) {
+    if (aot_matches(d)) return 1;
+    if (!jit_enabled() || !spec_eligible(d)) return 0;
+    return build_spec(d, nullptr, err) == 0 ? 2 : -1;
 }
 
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
@@ -167,8 +299,7 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
         }
         MPCQP_SPECIALIZATIONS(X)
 #undef X
-        if (d.nw == 0 && d.nZ <= WAVE)   // (custom linear constraints and nZ~ > 64 run on the runtime-dims kernel)
-            if (const SpecLib* sl = jit_specialise(d)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
+        if (const SpecLib* sl = find_spec(d, true)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
     }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_step, lds);

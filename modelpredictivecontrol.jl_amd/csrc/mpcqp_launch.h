@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "mpcqp_types.h"
 
 namespace mpcqp {
@@ -9,6 +11,10 @@ hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStrea
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st);
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
 size_t step_lds_bytes(const Dims& d);
+// kernel a step runs on: 0 runtime-dimension kernel, 1 ahead-of-time specialisation, 2 on-demand specialisation
+int step_kernel_kind(const Dims& d);
+int prepare_step(const Dims& d, std::string* err);     // compile (if needed) + load; returns the kind
+int prebuild_step(const Dims& d, std::string* err);    // compile only; -1 on failure
 hipError_t launch_kf_correct(const Dims& d, const Model& m, const KfParams& kf, double* xhat0,
                              const double* y0m, const double* d0, hipStream_t st);
 hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const double* u0,

@@ -42,7 +42,7 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 4
+#define MPCQP_KERNEL_REV 5
 
 namespace mpcqp {
 

@@ -161,6 +161,10 @@ hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const
         for (int i = 0; i < d.nxh; ++i) kf_predict_lane(d, m, b, i, xin.data(), xhat0, u0, d0);
     return hipSuccess;
 }
+// (the emulator has no on-demand kernels: every shape it was not compiled for runs the runtime-dims body)
+int step_kernel_kind(const Dims&) { return 0; }
+int prepare_step(const Dims&, std::string*) { return 0; }
+int prebuild_step(const Dims&, std::string*) { return 0; }
 size_t step_lds_bytes(const Dims& d) { return (size_t)make_carve(d).total * sizeof(double); }
 
 }  // namespace mpcqp

@@ -19,6 +19,9 @@ enum { hipStreamNonBlocking = 1 };
 inline const char* hipGetErrorString(hipError_t) { return "fake-hip error"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, void*, unsigned) { return hipSuccess; }
+inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
