@@ -3,15 +3,22 @@
 GPU; `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` for N > 1).
 
 A "step" = one pass of the hot path (initpred! + linconstraint! + QP solve + getinput!, kernel K3)
-over one resident batch of synthetic controllers: BASELINE.json configs[2] (batch 65536 per GPU,
-nx=12 nu=4 ny=4, Hp=30 Hc=10, hard umin/umax, soft ymax).  Every step is a cold-started solve of
-the same seeded instances, so all K timed steps do identical work.  Inputs are in HBM before the
-timed region; the batch shards by contiguous index range over the ranks with no data-path
-collective (weak scaling: 65536 instances per GPU).
+over one resident batch of synthetic controllers, every step a cold-started solve of the same seeded
+instances (all K timed steps do identical work), inputs in HBM before the timed region.
+
+Workload (BASELINE.json):
+  N = 1   configs[2]: batch 65536, nx=12 nu=4 ny=4, Hp=30 Hc=10, hard umin/umax, soft ymax ("C3").
+  N > 1   configs[3]: the same shapes, GLOBAL batch 262144 split into contiguous index ranges over the
+          ranks (32768 per GPU at N = 8; `sharding.shard_range`, the rule of mpcqp_multi_create) with no
+          collective on the data path -- `"scaling": "strong"`; the weak-scaling figure (65536
+          controllers per GPU, global 65536 N) is measured in the same run and reported under
+          `config.weak_scaling`.  `--mode weak` makes the weak run the headline instead.
+After the timed region the ranks gather status and first moves of the whole batch with ONE all_gather
+each over RCCL (the scatter/gather of the north star; it is outside the step).
 
 Prints ONE JSON line (rank 0) with `roofline` (FP64 flops of the dominant kernel k_step against the
-chip's FP64 peak, kernel time from HIP events on the launch stream) and `cpu_baseline` (the
-oracle's C port on the host cores, bounded sample, rank 0 at N=1 only).
+chip's FP64 peak, kernel time from HIP events on the launch stream) and `cpu_baseline` (the oracle's C
+port on the host cores, bounded sample, rank 0 at N = 1 only).
 """
 from __future__ import annotations
 
@@ -50,13 +57,83 @@ def algorithmic_bytes(cfg):
     return 8 * (ins + outs)
 
 
+class Shard:
+    """This rank's contiguous shard [lo, lo + B) of a seeded global batch, resident on its GPU."""
+
+    def __init__(self, cfg, lo, B, seed, local):
+        import torch
+        import mpcqp
+        from mpcqp import synth
+        self.cfg, self.B, self.lo = cfg, B, lo
+        bt = synth.make_batch(cfg, B, seed=seed, lo=lo)
+        self.bt = bt
+        neps = 0 if np.isinf(cfg.Cwt) else 1
+        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=neps, device=local,
+                          flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START)
+        hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
+        hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt),
+                       np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt) if neps else None)
+        full = lambda v, n: None if not np.isfinite(v) else np.full((B, n), float(v))
+        hd.set_bounds(U0min=full(cfg.umin, hd.nU), U0max=full(cfg.umax, hd.nU),
+                      DUmin=full(cfg.dumin, hd.nDU), DUmax=full(cfg.dumax, hd.nDU),
+                      Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY))
+        self.kernel = hd.prepare()              # specialised kernel (compiled once per shape, never in a step)
+        self.hd = hd
+        dev = torch.device("cuda", local)
+        self.dev = dev
+        self.t_x = torch.from_numpy(bt["xhat0"]).to(dev)
+        self.t_lu = torch.from_numpy(bt["lastu0"]).to(dev)
+        self.t_ry = torch.from_numpy(bt["ry"]).to(dev)
+        self.t_Z = torch.zeros((B, hd.nZ), dtype=torch.float64, device=dev)
+        self.t_u0 = torch.empty((B, cfg.nu), dtype=torch.float64, device=dev)
+        self.t_st = torch.empty(B, dtype=torch.int32, device=dev)
+        self.t_it = torch.empty(B, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.current_stream()
+
+    def step(self):
+        self.hd.step_device(self.t_x.data_ptr(), self.t_lu.data_ptr(), self.t_ry.data_ptr(), self.t_Z.data_ptr(),
+                            self.t_u0.data_ptr(), self.t_st.data_ptr(), iters=self.t_it.data_ptr(),
+                            stream=self.stream.cuda_stream)
+
+
+def timed_run(sh, steps, warmup, dist):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns (wall seconds, max over the
+    ranks; per-step kernel ms from events on the launch stream)."""
+    import torch
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        sh.step()
+    barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        evs[k].record(sh.stream)
+        sh.step()
+    evs[steps].record(sh.stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=sh.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, kern_ms
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="controllers per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="controllers per GPU (0: the BASELINE workload)")
     ap.add_argument("--config", default="C3")
+    ap.add_argument("--mode", default="auto", choices=["auto", "config4", "weak"],
+                    help="N > 1: config4 = global batch 262144 split over the ranks (default), weak = 65536 per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -64,7 +141,7 @@ def main():
 
     import torch
     import mpcqp
-    from mpcqp import synth
+    from mpcqp import sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,78 +158,83 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     cfg = synth.get_config(args.config)
-    B = args.batch
-    bt = synth.make_batch(cfg, B, seed=args.seed, lo=rank * B)      # this rank's shard
-    neps = 0 if np.isinf(cfg.Cwt) else 1
-    nxh, nu, ny, Hp, Hc = cfg.nxh, cfg.nu, cfg.ny, cfg.Hp, cfg.Hc
-    hd = mpcqp.Handle(B, nxh, nu, ny, 0, Hp, Hc, neps=neps, device=local,
-                      flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START)
-    hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
-    hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt),
-                   np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt) if neps else None)
-    full = lambda v, n: None if not np.isfinite(v) else np.full((B, n), float(v))
-    hd.set_bounds(U0min=full(cfg.umin, hd.nU), U0max=full(cfg.umax, hd.nU),
-                  DUmin=full(cfg.dumin, hd.nDU), DUmax=full(cfg.dumax, hd.nDU),
-                  Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY))
-    dev = torch.device("cuda", local)
-    t_x = torch.from_numpy(bt["xhat0"]).to(dev)
-    t_lu = torch.from_numpy(bt["lastu0"]).to(dev)
-    t_ry = torch.from_numpy(bt["ry"]).to(dev)
-    t_Z = torch.zeros((B, hd.nZ), dtype=torch.float64, device=dev)
-    t_u0 = torch.empty((B, nu), dtype=torch.float64, device=dev)
-    t_st = torch.empty(B, dtype=torch.int32, device=dev)
-    t_it = torch.empty(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream()
+    PER_GPU = 65536
+    GLOBAL4 = 262144
+    strong = world > 1 and args.mode in ("auto", "config4") and not args.batch
+    if args.batch:
+        lo, B, Bglobal = rank * args.batch, args.batch, args.batch * world
+    elif strong:
+        lo, B = sharding.shard_range(GLOBAL4, rank, world)
+        Bglobal = GLOBAL4
+    else:
+        lo, B, Bglobal = rank * PER_GPU, PER_GPU, PER_GPU * world
+    sh = Shard(cfg, lo, B, args.seed, local)
+    hd = sh.hd
+    elapsed, kern_ms = timed_run(sh, args.steps, args.warmup, dist)
 
-    def step():
-        hd.step_device(t_x.data_ptr(), t_lu.data_ptr(), t_ry.data_ptr(), t_Z.data_ptr(),
-                       t_u0.data_ptr(), t_st.data_ptr(), iters=t_it.data_ptr(),
-                       stream=stream.cuda_stream)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        evs[k].record(stream)
-        step()
-    evs[args.steps].record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
+    status = sh.t_st.cpu().numpy()
+    iters = sh.t_it.cpu().numpy()
+    n_opt, it_sum = int((status == 0).sum()), float(iters.sum())
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    status = t_st.cpu().numpy()
-    iters = t_it.cpu().numpy()
-    n_opt, mean_it = int((status == 0).sum()), float(iters.mean())
-    if dist is not None:
-        agg = torch.tensor([n_opt, float(iters.sum())], dtype=torch.float64, device=dev)
+        agg = torch.tensor([n_opt, it_sum], dtype=torch.float64, device=sh.dev)
         dist.all_reduce(agg)
-        n_opt, mean_it = int(agg[0].item()), float(agg[1].item()) / (B * world)
+        n_opt, it_sum = int(agg[0].item()), float(agg[1].item())
+    mean_it = it_sum / Bglobal
+
+    # the gather of the north star (outside the step): status and first moves of the whole batch on every rank
+    gather = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st_all = sharding.gather(sh.t_st, Bglobal, dist)
+        u_all = sharding.gather(sh.t_u0, Bglobal, dist)
+        torch.cuda.synchronize()
+        gather = {"ms": (time.perf_counter() - t0) * 1e3, "bytes_per_rank": int(B * (4 + 8 * cfg.nu)),
+                  "optimal_fraction": float((st_all == 0).double().mean().item()),
+                  "u0_checksum": float(u_all.sum().item()), "collective": "all_gather (RCCL), one per array"}
+
+    # weak-scaling figure next to the config-4 run
+    weak = None
+    if strong:
+        shw = Shard(cfg, rank * PER_GPU, PER_GPU, args.seed, local)
+        ew, _ = timed_run(shw, args.steps, args.warmup, dist)
+        weak = {"batch_per_gpu": PER_GPU, "global_batch": PER_GPU * world, "value": PER_GPU * world * args.steps / ew,
+                "ms_per_step": ew / args.steps * 1e3}
+        del shw
 
     # setmodel! path (K1 + K2 re-condensation of all models), reported next to the step time
-    hd.recondense_device(stream=stream.cuda_stream)
+    hd.recondense_device(stream=sh.stream.cuda_stream)
     torch.cuda.synchronize()
-    recond_ms = hd.last_condense_ms()
+    recond_ms, k1_ms = hd.last_condense_ms(), hd.last_predmat_ms()
+
+    # end to end through host pointers (PCIe both ways, pageable NumPy arrays): never the reported value
+    e2e_ms = None
+    if world == 1:
+        Zh = np.zeros((B, hd.nZ))
+        hd.step(sh.bt["xhat0"], sh.bt["lastu0"], sh.bt["ry"], Zh)
+        t0 = time.perf_counter()
+        u0h, sth, ith = hd.step(sh.bt["xhat0"], sh.bt["lastu0"], sh.bt["ry"], Zh)
+        e2e_ms = (time.perf_counter() - t0) * 1e3
 
     if rank == 0:
-        total = B * world * args.steps
+        total = Bglobal * args.steps
         value = total / elapsed
         # row counts of the reference's A Z̃ <= b (i_b rule); the kernel merges the U rows of a
         # move-blocking interval, the flop model keeps the reference's count
         rows_u = (int(np.isfinite(cfg.umin)) + int(np.isfinite(cfg.umax))) * hd.nU
         rows_y = (int(np.isfinite(cfg.ymin)) + int(np.isfinite(cfg.ymax))) * hd.nY
+        neps = 0 if np.isinf(cfg.Cwt) else 1
         flops, w_grad, w_iter = algorithmic_flops(cfg, mean_it, rows_u, rows_y)
-        kms = float(np.mean(kern_ms))
+        kms, kmed = float(np.mean(kern_ms)), float(np.median(kern_ms))
         achieved = flops * B / (kms * 1e-3) / 1e12
+        # rows active at the optimum (rank 0's shard): inputs on a bound, outputs on the soft bound
+        Zr = sh.t_Z.cpu().numpy()
+        nDU = hd.nDU
+        U0 = np.cumsum(Zr[:, :nDU].reshape(B, cfg.Hc, cfg.nu), axis=1) + sh.bt["lastu0"][:, None, :]
+        act_u = (np.abs(U0 - cfg.umax) <= 1e-9) | (np.abs(U0 - cfg.umin) <= 1e-9) if np.isfinite(cfg.umax) else np.zeros_like(U0, bool)
+        soft_on = Zr[:, -1] > 1e-9 if neps else np.zeros(B, bool)
+        active = {"controllers_with_an_active_row": float((act_u.any(axis=(1, 2)) | soft_on).mean()),
+                  "input_rows_on_a_bound": float(act_u.mean()), "controllers_with_slack": float(soft_on.mean())}
         traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_k_step.json")))
@@ -164,32 +246,39 @@ def main():
             "metric": "QP solves/sec (moveinput!)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg.name, "batch_per_gpu": B, "global_batch": B * world,
-                       "nx": cfg.nx, "nxhat": nxh, "nu": nu, "ny": ny, "Hp": Hp, "Hc": Hc,
+            "config": {"workload": cfg.name + (" (BASELINE configs[3]: global batch 262144 over the ranks)" if strong else ""),
+                       "batch_per_gpu": B, "global_batch": Bglobal,
+                       "nx": cfg.nx, "nxhat": cfg.nxh, "nu": cfg.nu, "ny": cfg.ny, "Hp": cfg.Hp, "Hc": cfg.Hc,
                        "nZ": hd.nZ, "rows": int(rows_u + rows_y + neps), "cold_start": True,
-                       "ipm_mean_iters": mean_it, "optimal_fraction": n_opt / (B * world),
-                       "recondense_ms": recond_ms,
-                       "sharding": "contiguous index ranges, no collective on the data path"},
+                       "ipm_mean_iters": mean_it, "optimal_fraction": n_opt / Bglobal,
+                       "kernel": {0: "runtime-dimension", 1: "ahead-of-time specialisation", 2: "on-demand specialisation"}[sh.kernel],
+                       "value_from_median_step": Bglobal / (kmed * 1e-3) if world == 1 else None,
+                       "median_kernel_ms": kmed,
+                       "recondense_ms": recond_ms, "recondense_K1_ms": k1_ms, "recondense_K2_ms": recond_ms - k1_ms,
+                       "end_to_end_ms": e2e_ms, "active_rows": active,
+                       "weak_scaling": weak, "gather": gather,
+                       "sharding": "contiguous index ranges (sharding.shard_range), no collective on the data path"},
             "roofline": {"bound": "mfma", "kernel": "k_step", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel_ms": kms, "flops_per_solve": flops,
                          "hbm_algorithmic_GBps": algorithmic_bytes(cfg) * B / (kms * 1e-3) / 1e9,
-                         "note": "FP64 vector/matrix peak (no f64 entry in the MFMA table: "
-                                 "half the 157.3 TF FP32 rate); flops = W_grad + I W_iter, "
-                                 "SURVEY 8(d) structure-exploiting count"},
+                         "note": "FP64 peak shared by v_fma_f64 and v_mfma_f64 (one datapath: measured, "
+                                 "scripts/ubench/mfma_valu_overlap.hip): half the 157.3 TF FP32 rate; flops = "
+                                 "W_grad + I W_iter, SURVEY 8(d) structure-exploiting count, I = mean "
+                                 "factorisations per solve (interior-point iterations + polish)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args)
+            out["cpu_baseline"] = cpu_baseline(cfg, args, B)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, args):
+def cpu_baseline(cfg, args, B):
     """The oracle's C port (oracle/linmpc_ref.c, dense per-controller restatement of the same
     step, OpenMP over controllers) on this box's host cores, bounded sample of the same workload."""
     from mpcqp import synth
@@ -201,7 +290,7 @@ def cpu_baseline(cfg, args):
     t0 = time.perf_counter()
     rb.step(bt["xhat0"], bt["lastu0"], bt["ry"])
     rate = probe / (time.perf_counter() - t0)
-    n = int(min(args.batch, max(probe, rate * args.cpu_seconds)))
+    n = int(min(B, max(probe, rate * args.cpu_seconds)))
     n = max(256, (n // 256) * 256)
     reps = max(1, int(round(rate * args.cpu_seconds / n)))        # ~cpu_seconds of CPU work in all
     bt = synth.make_batch(cfg, n, seed=args.seed)
@@ -218,7 +307,7 @@ def cpu_baseline(cfg, args):
     return {"value": n * reps / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
             "sample": f"first {n} instances of the same workload x {reps} cold-start passes, "
                       f"{dt:.1f} s, dense per-controller C restatement (oracle/linmpc_ref.c), "
-                      f"mean {float(it.mean()):.1f} IPM iterations, all optimal: {bool((st == 0).all())}"}
+                      f"mean {float(it.mean()):.1f} factorisations, all optimal: {bool((st == 0).all())}"}
 
 
 if __name__ == "__main__":

@@ -285,6 +285,7 @@ int mpcqp_multi_gather_device(mpcqp_multi mh, int32_t root, const double* const*
  * events on the stream they ran on (milliseconds; < 0 if not available).                     */
 double mpcqp_last_step_ms(mpcqp_handle h);
 double mpcqp_last_condense_ms(mpcqp_handle h);
+double mpcqp_last_predmat_ms(mpcqp_handle h);    /* K1 part of the last condensation (K2 = the rest) */
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC = 1, 2, 3, 4
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
            "mpcqp_destroy", "mpcqp_get_sizes", "mpcqp_set_model", "mpcqp_set_weights",
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_recondense_device",
-           "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_kf_set",
+           "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_last_predmat_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
            "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
            "mpcqp_set_flags", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_row_groups", "mpcqp_prebuild",
@@ -106,6 +106,8 @@ def load_library(path: str | None = None):
     lib.mpcqp_last_step_ms.argtypes = [C.c_void_p]
     lib.mpcqp_last_condense_ms.restype = C.c_double
     lib.mpcqp_last_condense_ms.argtypes = [C.c_void_p]
+    lib.mpcqp_last_predmat_ms.restype = C.c_double
+    lib.mpcqp_last_predmat_ms.argtypes = [C.c_void_p]
     lib.mpcqp_kf_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.mpcqp_kf_correct.argtypes = [C.c_void_p] * 4
     lib.mpcqp_kf_predict.argtypes = [C.c_void_p] * 4
@@ -313,6 +315,9 @@ class Handle:
 
     def last_condense_ms(self):
         return self.lib.mpcqp_last_condense_ms(self.h)
+
+    def last_predmat_ms(self):
+        return self.lib.mpcqp_last_predmat_ms(self.h)
 
 
 class MultiHandle:

@@ -51,7 +51,7 @@ struct mpcqp_handle_s {
     Model m{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
+    hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_cm = nullptr;
     bool step_timed = false, cond_timed = false;
     bool have_model = false, have_weights = false, terminal_built = false;
     std::vector<int> nb, jl, blk;
@@ -198,6 +198,7 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev_s1);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_c0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_c1);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_cm);
     if (e != hipSuccess) {
         g_hip_err = std::string("stream/event create: ") + hipGetErrorString(e);
         rc = MPCQP_ERR_DEVICE;
@@ -240,6 +241,7 @@ int mpcqp_destroy(mpcqp_handle h) {
     if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
     if (h->ev_c0) (void)hipEventDestroy(h->ev_c0);
     if (h->ev_c1) (void)hipEventDestroy(h->ev_c1);
+    if (h->ev_cm) (void)hipEventDestroy(h->ev_cm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MPCQP_OK;
@@ -271,6 +273,7 @@ static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
     if (timed) HIPCHK(hipEventRecord(h->ev_c0, st));
     HIPCHK(launch_predmat(d, h->m, term, st));
     h->terminal_built = term;
+    if (timed) HIPCHK(hipEventRecord(h->ev_cm, st));       // between K1 (prediction tables) and K2 (Hessian)
     if (h->have_weights) HIPCHK(launch_hessian(d, h->m, st));
     if (timed) { HIPCHK(hipEventRecord(h->ev_c1, st)); h->cond_timed = true; }
     return MPCQP_OK;
@@ -921,6 +924,10 @@ double mpcqp_last_step_ms(mpcqp_handle h) {
 
 double mpcqp_last_condense_ms(mpcqp_handle h) {
     return h ? elapsed(h->ev_c0, h->ev_c1, h->cond_timed) : -1.0;
+}
+
+double mpcqp_last_predmat_ms(mpcqp_handle h) {
+    return h ? elapsed(h->ev_c0, h->ev_cm, h->cond_timed) : -1.0;
 }
 
 }  // extern "C"

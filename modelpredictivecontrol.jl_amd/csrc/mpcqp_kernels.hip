@@ -25,6 +25,8 @@
 #include "mpcqp_dispatch.h"
 #include "mpcqp_launch.h"
 
+extern char** environ;      // (the specialisation compiler inherits the environment)
+
 namespace mpcqp {
 
 __global__ __launch_bounds__(64) void k_predmat(Dims d, Model m, int terminal) {
@@ -153,8 +155,7 @@ static int run_process(const std::vector<std::string>& argv, const std::string& 
     posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     posix_spawn_file_actions_adddup2(&fa, 1, 2);
     pid_t pid = 0;
-    extern char** environ;
-    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), ::environ);
     posix_spawn_file_actions_destroy(&fa);
     if (rc != 0) return -1;
     int status = 0;

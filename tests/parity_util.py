@@ -63,6 +63,41 @@ def oracle_batch(cfg, bt):
             "q": np.array(Q), "H": np.array(H)}
 
 
+def write_c_fixture(path, name="C2", n=8):
+    """Raw fixture for tests/abi_c_client.c `run`: the first n instances of a golden file
+    (tests/golden/<name>_seed0-3.npz) in the C-ABI layout + their expected optimum."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{name}_seed0-3.npz"))
+    cfg = synth.CONFIGS[name]
+    bt = {k[3:]: g[k][:n] for k in g.files if k.startswith("in_")}
+    B, nu, ny, Hp, Hc = n, cfg.nu, cfg.ny, cfg.Hp, cfg.Hc
+    neps = 0 if np.isinf(cfg.Cwt) else 1
+    fin = np.isfinite
+    hdr = np.array([B, cfg.nxh, nu, ny, Hp, Hc, neps, int(fin(cfg.umin) or fin(cfg.umax)),
+                    int(fin(cfg.dumin) or fin(cfg.dumax)), int(fin(cfg.ymax)), 0, 0], np.int32)
+    full = lambda v, m: np.full((B, m), float(v))
+    arrs = [mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]),
+            full(cfg.Mwt, ny * Hp), full(cfg.Nwt, nu * Hc), full(cfg.Lwt, nu * Hp), np.full(B, cfg.Cwt if neps else 0.0)]
+    if hdr[7]:
+        arrs += [full(cfg.umin, nu * Hp), full(cfg.umax, nu * Hp)]
+    if hdr[8]:
+        arrs += [full(cfg.dumin, nu * Hc), full(cfg.dumax, nu * Hc)]
+    if hdr[9]:
+        arrs += [full(cfg.ymax, ny * Hp)]
+    arrs += [bt["xhat0"], bt["lastu0"], bt["ry"], g["out_Z"][:n]]
+    with open(path, "wb") as f:
+        f.write(hdr.tobytes())
+        for a in arrs:
+            f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+
+
+def build_c_client(exe, lib, root):
+    import os, subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "abi_c_client.c"), lib, "-o", exe, "-lm",
+                           "-Wl,-rpath," + os.path.dirname(os.path.abspath(lib)), "-Wl,-rpath,/opt/rocm/lib"])
+
+
 def rel_err(Zg, Zo, nDU):
     """max_b ‖ΔU_gpu − ΔU_oracle‖∞ / max(1, ‖ΔU_oracle‖∞)  (BASELINE.md §4 'Parity')."""
     return np.max(np.abs(Zg[:, :nDU] - Zo[:, :nDU]), axis=1) / np.maximum(

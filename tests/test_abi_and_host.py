@@ -32,13 +32,23 @@ def test_library_exports_every_declared_symbol():
 def test_header_is_plain_c(tmp_path):
     """include/mpcqp.h compiles as C and every declared entry point links (tests/abi_c_client.c)."""
     import subprocess
-    lib = mpcqp.DEFAULT_LIB
+    from tests.parity_util import build_c_client
     exe = str(tmp_path / "abi_c_client")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "abi_c_client.c"), lib, "-o", exe,
-                           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    build_c_client(exe, mpcqp.DEFAULT_LIB, ROOT)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "entry points" in out.stdout, out.stdout + out.stderr
+
+
+def test_c_client_runs_a_step_on_cpu_emulator(tmp_path, emulib):
+    """The plain-C client drives create -> set_* -> prepare -> step on raw float64 fixtures (golden C2
+    instances) -- here linked against the CPU wave emulator, in the -m gpu suite against libmpcqp.so."""
+    import subprocess
+    from tests.parity_util import build_c_client, write_c_fixture
+    exe, fx = str(tmp_path / "abi_c_client_emu"), str(tmp_path / "c2.bin")
+    build_c_client(exe, os.path.join(ROOT, "tests", "emu", "libmpcqp_emu.so"), ROOT)
+    write_c_fixture(fx, "C2", 4)
+    out = subprocess.run([exe, "run", fx], capture_output=True, text=True)
+    assert out.returncode == 0 and "run ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_library_is_a_gfx950_code_object():

@@ -6,6 +6,8 @@ the CPU oracle on the same seeded inputs.  Tolerance (north star, BASELINE.md se
 measured against the oracle's *certified optimum* -- the reference's default OSQP run is itself
 only ~1e-3 accurate (SURVEY.md section 7 "hard parts").
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -102,6 +104,41 @@ def test_full_size_properties_C3(hiplib):
     refh = oracle_batch(cfg, {k: (v[hard] if isinstance(v, np.ndarray) else v) for k, v in bt.items()})
     errh = rel_err(Z[hard], refh["Z"], nDU)
     assert errh[refh["certified"]].max() <= TOL
+
+
+def test_c_client_runs_steps_on_gpu(tmp_path, hiplib):
+    """tests/abi_c_client.c, plain C99, drives the full call sequence of the C-ABI on the GPU (raw
+    float64 fixtures of both BASELINE shapes) and checks the optimum against the golden one."""
+    import subprocess
+    from tests.parity_util import build_c_client, write_c_fixture
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_c_client")
+    build_c_client(exe, mpcqp.DEFAULT_LIB, root)
+    for name in ("C2", "C3"):
+        fx = str(tmp_path / f"{name}.bin")
+        write_c_fixture(fx, name, 16)
+        out = subprocess.run([exe, "run", fx], capture_output=True, text=True)
+        assert out.returncode == 0 and "run ok" in out.stdout and "kernel kind 1" in out.stdout, out.stdout + out.stderr
+
+
+def test_multi_device_entry_points_on_gpu(hiplib):
+    """mpcqp_multi_*: one batch over two shards (this box's single GPU twice) equals the single-handle
+    run bit for bit; the device-side gather collects the shards' results on the root."""
+    import torch
+    cfg = synth.C3
+    B = 1000
+    bt = synth.make_batch(cfg, B, seed=6)
+    ref = run_batch(cfg, bt, cold_start=True)
+    mh = mpcqp.MultiHandle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, [0, 0, 0], neps=1,
+                           flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START)
+    mh.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
+    mh.set_weights(np.full((B, mh.nY), cfg.Mwt), np.full((B, mh.nDU), cfg.Nwt), np.full((B, mh.nU), cfg.Lwt), np.full(B, cfg.Cwt))
+    mh.set_bounds(U0min=np.full((B, mh.nU), cfg.umin), U0max=np.full((B, mh.nU), cfg.umax), Y0max=np.full((B, mh.nY), cfg.ymax))
+    assert mh.prepare() == mpcqp.KERNEL_AOT
+    Z = np.zeros((B, mh.nZ))
+    u0, st, it = mh.step(bt["xhat0"], bt["lastu0"], bt["ry"], Z)
+    assert np.array_equal(Z, ref["Z"]) and np.all(st == 0)
+    assert [mh.shard(g) for g in range(3)] == [(0, 334), (334, 333), (667, 333)]
 
 
 def test_config4_batch_on_one_gpu(hiplib):
