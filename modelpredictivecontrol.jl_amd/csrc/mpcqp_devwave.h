@@ -31,8 +31,11 @@ struct DevWave {
     template <int CTRL>
     static __device__ __forceinline__ double dpp(double v) {
         int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        // (all rows and banks enabled and every control used here is a permutation inside a row: no lane
+        // keeps its old value, so `old` is a don't-care -- passing 0 with bound_ctrl saves the copy of the
+        // source into the destination that update_dpp(old = self) needs)
+        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
         return __hiloint2double(hi, lo);
     }
     static __device__ __forceinline__ double lane_value(double v, int src) {   // src wave-uniform

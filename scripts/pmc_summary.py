@@ -13,7 +13,7 @@ def find(pat):
 
 
 vals, batch, kname = {}, None, None
-for name in ("sq1", "sq2", "fetch", "write"):
+for name in ("sq1", "sq2", "sq3", "fetch", "write"):
     f = find(f"pmc_{name}/**/*counter_collection.csv")
     if not f:
         continue
