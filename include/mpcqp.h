@@ -140,14 +140,19 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk);
  *     wmin <= Wy ŷe + Wu ue + Wd d̂e + Wr r̂e <= wmax,     nw rows per step, Hp+1 steps
  * Wy (nw,ny,B), Wu (nw,nu,B), Wd (nw,nd,B) or NULL, Wr (nw,ny,B) or NULL.  The constraints are
  * written on engineering values while this ABI works in deviation variables: w_op (nw,B) =
- * Wy yop + Wu uop + Wd dop + Wr yop (NULL = 0) carries the operating points.  r̂e(k) is taken as
- * the first block of R̂y (the reference's default R̂y = repeat(ry)).  nw = 0 removes them.
+ * Wy yop + Wu uop + Wd dop + Wr yop (NULL = 0) carries the operating points.  r̂e(k): see
+ * mpcqp_set_current_setpoint.  nw = 0 removes them.
  * Bounds and softness (default 1, like c_wmin/c_wmax): Wmin, Wmax, C_wmin, C_wmax (nw (Hp+1), B),
  * NULL = absent (±Inf).  Problems with custom constraints run on the runtime-dimension kernel.   */
 int mpcqp_set_custom_constraints(mpcqp_handle h, int nw, const double* Wy, const double* Wu,
                                  const double* Wd, const double* Wr, const double* w_op);
 int mpcqp_set_custom_bounds(mpcqp_handle h, const double* Wmin, const double* Wmax,
                             const double* C_wmin, const double* C_wmax);
+/* r̂e(k), the first ny entries of the extended set point vector the Wr term multiplies, is the CURRENT
+ * set point ry(k) (src/controller/execute.jl:351).  With a held set point (MPCQP_FLAG_RY_CONSTANT) the
+ * library has it already; with a full R̂y trajectory pass ry(k) - yop here, (ny,B), before the step
+ * (NULL: back to the first block of R̂y).                                                          */
+int mpcqp_set_current_setpoint(mpcqp_handle h, const double* ry_now);
 
 /* Bounds (deviation values) and softness (ECR) vectors; shapes (nU,B), (nDU,B), (nY,B), (nx̂,B).
  * Field order follows ControllerConstraint (src/controller/construct.jl:126-199).            */

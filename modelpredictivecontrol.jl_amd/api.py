@@ -36,7 +36,7 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_last_predmat_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
            "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
-           "mpcqp_set_flags", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_row_groups", "mpcqp_prebuild",
+           "mpcqp_set_flags", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_row_groups", "mpcqp_prebuild",
            "mpcqp_last_build_error", "mpcqp_multi_create", "mpcqp_multi_destroy", "mpcqp_multi_ndev",
            "mpcqp_multi_handle", "mpcqp_multi_shard", "mpcqp_multi_set_model", "mpcqp_multi_set_weights",
            "mpcqp_multi_set_bounds", "mpcqp_multi_prepare", "mpcqp_multi_step", "mpcqp_multi_gather_device")
@@ -113,6 +113,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_kf_predict.argtypes = [C.c_void_p] * 4
     lib.mpcqp_kf_correct_device.argtypes = [C.c_void_p] * 5
     lib.mpcqp_kf_predict_device.argtypes = [C.c_void_p] * 5
+    lib.mpcqp_set_current_setpoint.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpcqp_prepare.argtypes = [C.c_void_p]
     lib.mpcqp_kernel_kind.argtypes = [C.c_void_p]
     lib.mpcqp_row_groups.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -203,6 +204,10 @@ class Handle:
     def set_flags(self, flags):
         _chk(self.lib, self.lib.mpcqp_set_flags(self.h, int(flags)))
         self.flags = int(flags)
+
+    def set_current_setpoint(self, ry_now):
+        a = None if ry_now is None else _f64(ry_now)
+        _chk(self.lib, self.lib.mpcqp_set_current_setpoint(self.h, _ptr(a)))
 
     def prepare(self):
         """Build/load the specialised step kernel of the current shape and constraint pattern
@@ -525,7 +530,9 @@ class BatchLinMPC:
     def setmodel(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None):
         """`setmodel!` re-condensation path (src/controller/execute.jl:684-790): K1 (+K2)."""
         dopv = self.fhop - self.xhop
+        self._Ahat, self._Bhu = np.asarray(Ahat, float).copy(), np.asarray(Bhu, float).copy()
         self._Chat = np.asarray(Chat, float).copy()
+        self._Bhd = None if self.nd == 0 else np.asarray(Bhd, float).copy()
         self._Dhd = None if self.nd == 0 else np.asarray(Dhd, float).copy()
         self.hd.set_model(colmajor(Ahat), colmajor(Bhu), colmajor(Chat),
                           None if self.nd == 0 else colmajor(Bhd),
@@ -752,6 +759,8 @@ class BatchLinMPC:
             d0, Dh0 = d - self.dop, Dhat - self.Dop
         elif d is not None and np.size(d) != 0:
             raise ValueError("d size must be (0,)")
+        if self.nw > 0 and not held:               # r̂e(k) = ry(k) for the Wr term (execute.jl:351)
+            self.hd.set_current_setpoint(ry - self.yop)
         if not self._prepared:                     # like JuMP's model build: before the loop, not in mpcqp_step
             self.kernel = self.hd.prepare()
             self._prepared = True
@@ -762,6 +771,8 @@ class BatchLinMPC:
         self._Yhat0 = out[3] if want_info else None
         self._lastu0_prev = lastu0
         self._winfo = (xhat0, np.tile(ry, Hp) if (held and self.nw > 0) else Rhaty, d0, Dh0)
+        self._ry_now = ry.copy()
+        self._ginfo = (xhat0.copy(), np.tile(ry, Hp) if held else Rhaty, self.Uop.copy() if Rhatu is None else Rhatu)
         self.solved_once = True
         nerr = int(np.sum(self.status == STATUS_ERROR))
         nwarn = int(np.sum(self.status == STATUS_ITERATION_LIMIT))
@@ -785,17 +796,49 @@ class BatchLinMPC:
         return a
 
     def getinfo(self):
-        """Subset of `getinfo` (src/controller/execute.jl:145-198): ΔU, ϵ, u, U, Ŷ (needs
-        `moveinput(..., want_info=True)` for Ŷ)."""
-        nu, Hc = self.nu, self.Hc
+        """`getinfo` (src/controller/execute.jl:145-198) for every controller of the batch: ΔU, ϵ, J,
+        U, u, lastu, d, D̂, x̂, ŷ, Ŷ, x̂end, Ŷs, R̂y, R̂u, W (+ the reference's ASCII aliases).  Ŷ comes
+        from the kernel (`moveinput(..., want_info=True)`, predict! transcription.jl:1136-1145); the
+        quantities derived from it (J, ŷ-independent ones aside) need that flag too."""
+        nu, Hc, Hp, ny, nd = self.nu, self.Hc, self.Hp, self.ny, self.nd
         DU = self.Z[:, :self.nDU]
         blk = np.repeat(np.arange(Hc), self.nb)
         cum = np.cumsum(DU.reshape(self.B, Hc, nu), axis=1)
         U0 = cum[:, blk, :].reshape(self.B, -1) + np.tile(self._lastu0_prev, self.Hp)
-        info = {"ΔU": DU.copy(), "ϵ": self.Z[:, -1].copy() if self.neps else np.zeros(self.B),
-                "u": self.lastu0 + self.uop, "U": U0 + self.Uop}
+        xhat0, Rhaty, Rhatu = self._ginfo
+        _, _, d0, Dh0 = self._winfo
+        eps = self.Z[:, -1].copy() if self.neps else np.zeros(self.B)
+        info = {"ΔU": DU.copy(), "ϵ": eps, "u": self.lastu0 + self.uop, "U": U0 + self.Uop,
+                "lastu": self._lastu0_prev + self.uop, "x̂": xhat0 + self.xhop, "R̂y": Rhaty.copy(), "R̂u": Rhatu.copy(),
+                "d": (d0 + self.dop) if nd > 0 else np.zeros((self.B, 0)),
+                "D̂": (Dh0 + self.Dop) if nd > 0 else np.zeros((self.B, 0)),
+                "Ŷs": np.zeros((self.B, self.nY))}          # stochastic predictions: InternalModel only (predictstoch!)
+        # ŷ(k) = Ĉ x̂0 + D̂d d0 + yop (evaloutput, execute.jl:297-314)
+        yk = np.einsum("bij,bj->bi", self._Chat, xhat0) + self.yop
+        if nd > 0:
+            yk = yk + np.einsum("bij,bj->bi", self._Dhd, d0)
+        info["ŷ"] = yk
+        # x̂end = x̂0(k+Hp): the augmented model driven by the optimal inputs (predict!, transcription.jl:1136-1145)
+        x = xhat0.copy()
+        dop_x = self.fhop - self.xhop
+        U0s = U0.reshape(self.B, Hp, nu)
+        for t in range(Hp):
+            x = np.einsum("bij,bj->bi", self._Ahat, x) + np.einsum("bij,bj->bi", self._Bhu, U0s[:, t]) + dop_x
+            if nd > 0:
+                dt = d0 if t == 0 else Dh0[:, (t - 1) * nd:t * nd]
+                x = x + np.einsum("bij,bj->bi", self._Bhd, dt)
+        info["x̂end"] = x + self.xhop
         if self._Yhat0 is not None:
             info["Ŷ"] = self._Yhat0 + self.Yop
+            # J = (Ŷ-R̂y)'M(Ŷ-R̂y) + ΔU'N ΔU + (U-R̂u)'L(U-R̂u) + C ϵ²   (obj_nonlinprog!, general.jl:107 with r)
+            ey, eu = info["Ŷ"] - Rhaty, info["U"] - Rhatu
+            if self.Mblk is not None:
+                eyb = ey.reshape(self.B, Hp, ny)
+                Jy = np.einsum("bti,btij,btj->b", eyb, self.Mblk, eyb)
+            else:
+                Jy = np.sum(np.tile(self.Mwt, Hp) * ey * ey, axis=1)
+            info["J"] = (Jy + np.sum(np.tile(self.Nwt, Hc) * DU * DU, axis=1) + np.sum(np.tile(self.Lwt, Hp) * eu * eu, axis=1)
+                         + (self.Cwt * eps * eps if self.neps else 0.0))
             if self.nw > 0:       # W = Wy ŷe + Wu ue + Wd d̂e + Wr r̂e   (execute.jl:221, relaxW)
                 xhat0, Rhaty, d0, Dh0 = self._winfo
                 Hp, ny, nd = self.Hp, self.ny, self.nd
@@ -805,11 +848,15 @@ class BatchLinMPC:
                 ye = np.concatenate([yk, info["Ŷ"]], axis=1).reshape(self.B, Hp + 1, ny)
                 U = info["U"].reshape(self.B, Hp, nu)
                 ue = np.concatenate([U, U[:, -1:, :]], axis=1)
-                re = np.concatenate([Rhaty[:, :ny], Rhaty], axis=1).reshape(self.B, Hp + 1, ny)
+                re = np.concatenate([self._ry_now, Rhaty], axis=1).reshape(self.B, Hp + 1, ny)
                 Wv = (np.einsum("bij,btj->bti", self.Wy, ye) + np.einsum("bij,btj->bti", self.Wu, ue)
                       + np.einsum("bij,btj->bti", self.Wr, re))
                 if nd > 0:
                     de = np.concatenate([d0 + self.dop, Dh0 + self.Dop], axis=1).reshape(self.B, Hp + 1, nd)
                     Wv = Wv + np.einsum("bij,btj->bti", self.Wd, de)
                 info["W"] = Wv.reshape(self.B, -1)
+        for a, k in (("DeltaU", "ΔU"), ("epsilon", "ϵ"), ("Dhat", "D̂"), ("xhat", "x̂"), ("yhat", "ŷ"), ("Yhat", "Ŷ"),
+                     ("xhatend", "x̂end"), ("Yhats", "Ŷs"), ("Rhaty", "R̂y"), ("Rhatu", "R̂u")):
+            if k in info:
+                info[a] = info[k]
         return info

@@ -969,8 +969,8 @@ struct Step {
     // F_w of linconstraint_custom! (execute.jl:337-364), row k = (t, i), t = 0..Hp:
     //   Wy [ŷ(k); F + Yop] + Wu [Tu u(k-1) + Uop; u(k-1)] + Wd [d(k); D̂] + Wr [ry(k); R̂y]
     // in deviation variables plus the operating-point part w_op = Wy yop + Wu uop + Wd dop + Wr yop.
-    // ŷ0(k) = Ĉ x̂0 + D̂d d0 (evaloutput); r̂e(k) is the first block of R̂y (the reference's default
-    // R̂y = repeat(ry)).
+    // ŷ0(k) = Ĉ x̂0 + D̂d d0 (evaloutput); r̂e(k) = ry(k) (Model::ry_now, mpcqp_set_current_setpoint; without it
+    // the first block of R̂y, which is the same thing for the reference's default R̂y = repeat(ry)).
     MPCQP_HD double Fw_at(int k, const StepIO& io, const double* x0, const double* lu) const {
         const int nw = d.nw, ny = d.ny, nu = d.nu, nd = d.nd, nx = d.nxh;
         const int t = k / nw, i = k - t * nw;
@@ -991,8 +991,11 @@ struct Step {
             }
             acc += qp.Wy_(i, a) * ye;
             if (m.Wr) {
+                // r̂e(k) is the CURRENT set point ry(k) (execute.jl:351, R̂e_term[1:ny] .= mpc.ry), the rest R̂y
                 const int tr = t == 0 ? 0 : t - 1;
-                const double re = rconst ? io.Ry[(size_t)b * ny + a] : io.Ry[(size_t)b * d.nY + tr * ny + a];
+                const double re = rconst ? io.Ry[(size_t)b * ny + a]
+                                  : (t == 0 && m.ry_now) ? m.ry_now[(size_t)b * ny + a]
+                                                         : io.Ry[(size_t)b * d.nY + tr * ny + a];
                 acc += m.Wr[(size_t)b * nw * ny + i + nw * a] * re;
             }
         }

@@ -58,7 +58,7 @@ struct mpcqp_handle_s {
     std::vector<void*> owned;
     // model / weights / bounds storage
     DBuf Ahat, Bu, C, Bd, Dd, dop, Mdiag, Ndiag, Ldiag, Cwt, Mblk;
-    DBuf Wy, Wu, Wd, Wr, w_op, Wmin, Wmax, C_wmin, C_wmax;
+    DBuf Wy, Wu, Wd, Wr, w_op, Wmin, Wmax, C_wmin, C_wmax, ry_now;
     DBuf bnd[16];
     // staging for the host-pointer step
     DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
@@ -383,6 +383,20 @@ int mpcqp_set_custom_constraints(mpcqp_handle h, int nw, const double* Wy, const
     }
     layout_rows(h);
     HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_set_current_setpoint(mpcqp_handle h, const double* ry_now) {
+    if (!h) return MPCQP_ERR_NULL;
+    ON_DEVICE(h);
+    if (ry_now) {
+        int rc = upload(h, h->ry_now, ry_now, (size_t)h->d.B * h->d.ny * sizeof(double));
+        if (rc) return rc;
+        h->m.ry_now = (const double*)h->ry_now.p;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } else {
+        h->m.ry_now = nullptr;
+    }
     return MPCQP_OK;
 }
 

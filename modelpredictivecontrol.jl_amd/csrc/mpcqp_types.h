@@ -96,6 +96,7 @@ struct Model {
     // custom linear constraints (relaxW, construct.jl:1086-1160): W = Wy ŷe + Wu ue + Wd d̂e + Wr r̂e
     const double *Wy, *Wu, *Wd, *Wr;   // [B][ny|nu|nd|ny][nw] (ABI (nw,·,B)); Wd, Wr may be null
     const double* w_op;                // [B][nw] operating-point part of W, may be null
+    const double* ry_now;              // [B][ny] current set point ry(k) - yop for the Wr term of step k (null: first block of R̂y)
     const double *Wmin, *Wmax, *C_wmin, *C_wmax;   // [B][nW]
     // horizon tables
     const int* jl;   // [Hc+1] block starts j_l (move_blocking, construct.jl:597-660)

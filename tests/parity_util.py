@@ -408,7 +408,8 @@ def run_random_case2(seed, lib=None, B=2, small=False):
     worst = None
     for k in range(2):
         ry = model.yop + rng.standard_normal(ny)
-        Rhaty = np.tile(ry, Hp) + 0.2 * rng.standard_normal(ny * Hp) if seed % 2 == 0 else None
+        # (odd seeds: custom constraints with a Wr term AND a set point trajectory whose first block is not ry(k))
+        Rhaty = np.tile(ry, Hp) + 0.2 * rng.standard_normal(ny * Hp) if seed % 4 != 2 else None
         Rhatu = np.tile(model.uop, Hp) + 0.1 * rng.standard_normal(nu * Hp)
         d = model.dop + 0.3 * rng.standard_normal(nd) if nd else None
         Dhat = (np.tile(d, Hp) + 0.05 * rng.standard_normal(nd * Hp)) if nd else None

@@ -164,6 +164,12 @@ def test_kernel_bodies_on_cpu_emulator(nd, terminal, emulib):
         assert np.abs(ug[0] - uo).max() <= 1e-6
         assert np.abs(gpu.getinfo()["Ŷ"][0] - orc.getinfo()["Ŷ"]).max() <= 1e-6
         assert np.abs(gpu.getinfo()["U"][0] - orc.getinfo()["U"]).max() <= 1e-6
+        ig, io = gpu.getinfo(), orc.getinfo()             # getinfo completeness (execute.jl:145-198)
+        assert np.abs(ig["x̂end"][0] - io["x̂end"]).max() <= 1e-6 * max(1.0, np.abs(io["x̂end"]).max())
+        assert abs(ig["J"][0] - io["J"]) <= 1e-6 * max(1.0, abs(io["J"]))
+        assert np.abs(ig["ŷ"][0] - (kf.Ch @ x0 + (kf.Dhd @ (np.array(d) - model.dop) if nd else 0.0) + model.yop)).max() <= 1e-12
+        assert set(("ΔU", "ϵ", "J", "U", "u", "lastu", "d", "D̂", "x̂", "ŷ", "Ŷ", "x̂end", "Ŷs", "R̂y", "R̂u",
+                    "DeltaU", "epsilon", "Dhat", "xhat", "yhat", "Yhat", "xhatend", "Yhats", "Rhaty", "Rhatu")) <= set(ig)
 
 
 @pytest.mark.slow
