@@ -207,6 +207,27 @@ def main():
     torch.cuda.synchronize()
     recond_ms, k1_ms = hd.last_condense_ms(), hd.last_predmat_ms()
 
+    # resident closed loop: Kalman correction + moveinput! + Kalman prediction of one period in ONE launch
+    # (mpcqp_loop_device); x̂0, u stay in HBM, the measurement is synthetic noise, the gain a synthetic
+    # (B, nx̂, ny) array -- the arithmetic of a period does not depend on their values
+    loop = None
+    if world == 1:
+        rg = np.random.default_rng(1)
+        hd.kf_set(np.ascontiguousarray(0.05 * rg.standard_normal((B, cfg.ny, cfg.nxh))), np.arange(cfg.ny))
+        t_y = torch.from_numpy(0.1 * rg.standard_normal((B, cfg.ny))).to(sh.dev)
+        t_xl = sh.t_x.clone()
+        bufs = [sh.t_lu.clone(), sh.t_u0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            hd.loop_device(t_xl.data_ptr(), t_y.data_ptr(), bufs[k % 2].data_ptr(), sh.t_ry.data_ptr(), sh.t_Z.data_ptr(),
+                           bufs[(k + 1) % 2].data_ptr(), sh.t_st.data_ptr(), iters=sh.t_it.data_ptr(), stream=sh.stream.cuda_stream)
+        torch.cuda.synchronize()
+        dtl = time.perf_counter() - t0
+        loop = {"periods_per_s": B * args.steps / dtl, "ms_per_period": dtl / args.steps * 1e3, "launches_per_period": 1,
+                "optimal_fraction": float((sh.t_st == 0).double().mean().item()),
+                "what": "preparestate! (SteadyKalmanFilter) + moveinput! + updatestate! fused in the step kernel"}
+
     # end to end through host pointers (PCIe both ways, pageable NumPy arrays): never the reported value
     e2e_ms = None
     if world == 1:
@@ -257,7 +278,7 @@ def main():
                        "value_from_median_step": Bglobal / (kmed * 1e-3) if world == 1 else None,
                        "median_kernel_ms": kmed,
                        "recondense_ms": recond_ms, "recondense_K1_ms": k1_ms, "recondense_K2_ms": recond_ms - k1_ms,
-                       "end_to_end_ms": e2e_ms, "active_rows": active,
+                       "end_to_end_ms": e2e_ms, "active_rows": active, "closed_loop": loop,
                        "weak_scaling": weak, "gather": gather,
                        "sharding": "contiguous index ranges (sharding.shard_range), no collective on the data path"},
             "roofline": {"bound": "mfma", "kernel": "k_step", "achieved": achieved,

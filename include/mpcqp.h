@@ -189,6 +189,16 @@ int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
                       double* Ztilde, double* u0, int32_t* status, int32_t* iters,
                       double* Yhat0, void* stream);
 
+/* One control period of a resident closed loop in ONE launch: preparestate! (SteadyKalmanFilter
+ * correction with the measurement y0m (nym,B), kalman.jl:284-295), moveinput! and updatestate!
+ * (kalman.jl:298-309, with the input just computed) inside the step kernel.  xhat0 (nx̂,B) is updated
+ * in place: in = x̂0(k|k-1), out = x̂0(k+1|k); everything else as mpcqp_step_device (u0 of one period
+ * is lastu0 of the next: swap the two buffers).  Needs mpcqp_kf_set.  DEVICE pointers.          */
+int mpcqp_loop_device(mpcqp_handle h, double* xhat0, const double* y0m, const double* lastu0,
+                      const double* Ry, const double* Ru, const double* d0, const double* Dhat0,
+                      double* Ztilde, double* u0, int32_t* status, int32_t* iters, double* Yhat0,
+                      void* stream);
+
 /* Re-run K1+K2 on the resident model/weights (timing of the setmodel! path). */
 int mpcqp_recondense_device(mpcqp_handle h, void* stream);
 

@@ -32,7 +32,7 @@ STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
 GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC = 1, 2, 3, 4, 5, 6
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
            "mpcqp_destroy", "mpcqp_get_sizes", "mpcqp_set_model", "mpcqp_set_weights",
-           "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_recondense_device",
+           "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_loop_device", "mpcqp_recondense_device",
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_last_predmat_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
            "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
@@ -100,6 +100,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_custom_bounds.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
     lib.mpcqp_step_device.argtypes = [C.c_void_p] + [C.c_void_p] * 12
+    lib.mpcqp_loop_device.argtypes = [C.c_void_p] + [C.c_void_p] * 13
     lib.mpcqp_recondense_device.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpcqp_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.mpcqp_last_step_ms.restype = C.c_double
@@ -276,6 +277,13 @@ class Handle:
         _chk(self.lib, self.lib.mpcqp_step_device(self.h, v(xhat0), v(lastu0), v(Ry), v(Ru), v(d0),
                                                   v(Dhat0), v(Z), v(u0), v(status), v(iters),
                                                   v(Yhat0), v(stream)))
+
+    def loop_device(self, xhat0, y0m, lastu0, Ry, Z, u0, status, iters=0, Ru=0, d0=0, Dhat0=0, Yhat0=0, stream=0):
+        """preparestate! + moveinput! + updatestate! of one period in one launch (mpcqp_loop_device);
+        integer device addresses, xhat0 updated in place."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _chk(self.lib, self.lib.mpcqp_loop_device(self.h, v(xhat0), v(y0m), v(lastu0), v(Ry), v(Ru), v(d0), v(Dhat0),
+                                                  v(Z), v(u0), v(status), v(iters), v(Yhat0), v(stream)))
 
     def recondense_device(self, stream=0):
         _chk(self.lib, self.lib.mpcqp_recondense_device(self.h, C.c_void_p(int(stream)) if stream else None))

@@ -118,7 +118,7 @@ struct StaticDims {
 constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs (cs only stored with runtime dims)
 
 struct Carve {
-    int S, Phi, zero, z, dz, q, zlo, zhi, gt, rd, dinv, zb, F, tA[NPAIR], tB[NPAIR], ucum, exT, Wm;
+    int S, Phi, zero, z, dz, q, zlo, zhi, gt, rd, dinv, zb, xh, F, tA[NPAIR], tB[NPAIR], ucum, exT, Wm;
     int rows[NROWARR];
     int jl, blk;               // int tables (offset in doubles, storage as int)
     int total;                 // doubles
@@ -154,6 +154,7 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     c.z = take(d.nZ); c.dz = take(d.nZ); c.q = take(d.nZ);
     c.gt = take(d.nZ); c.rd = take(d.nZ);
     c.dinv = take(d.nZ > WAVE ? d.nZ : 0);        // 1/L[k][k] of the several-rows-per-lane factorisation
+    c.xh = take(d.nxh);                           // x̂0 of this period (corrected in place by the fused Kalman step)
     c.zb = take(DM::is_static ? 0 : d.nZ);        // iterate kept while the polish runs (a register with compile-time dims)
     c.zlo = c.dz; c.zhi = c.gt;                   // only live while the rows are being set up
     c.F = -1;                                     // placed below (aliases the Ŷ-row scratch when it exists)
@@ -1012,7 +1013,7 @@ struct Step {
     // ---- free response, gradient, right-hand sides (initpred!, linconstraint!) -------------
     MPCQP_HD void build(const StepIO& io) {
         const int nx = d.nxh, nu = d.nu, ny = d.ny, nd = d.nd, nY = d.nY;
-        const double* x0 = io.xhat0 + (size_t)b * nx;
+        const double* x0 = sm + c.xh;                        // staged by step_body (after the optional correction)
         const double* lu = io.lastu0 + (size_t)b * nu;
         const double* K = m.Ktab + (size_t)b * nx * nY;
         const double* Bv = m.Bvec + (size_t)b * nY;
@@ -2299,6 +2300,38 @@ template <class W, class DM>
 MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int b, double* sm) {
     Qp<W, DM> qp(w, d, m, b, sm);
     qp.load_tables();
+    // x̂0 of this period into LDS; with kf_y0m the SteadyKalmanFilter correction first
+    // (correct_estimate_obsv!, src/estimator/kalman.jl:284-295; same arithmetic order as kf_correct_lane)
+    {
+        const int nx = d.nxh, ny = d.ny, nd = d.nd;
+        double* xh = sm + qp.c.xh;
+        for (int i = w.lane; i < nx; i += WAVE) xh[i] = io.xhat0[(size_t)b * nx + i];
+        w.sync();
+        if (io.kf_y0m) {
+            const double* Cm = m.C + (size_t)b * ny * nx;
+            const double* K = io.kf_K + (size_t)b * io.kf_nym * nx;
+            double acc[4];                                     // rows i = lane + 64 q (nx̂ <= 256)
+            int nq = 0;
+            for (int i = w.lane; i < nx; i += WAVE, ++nq) {
+                double a_ = xh[i];
+                for (int mm = 0; mm < io.kf_nym; ++mm) {
+                    const int a = io.kf_iym[mm];
+                    double v = io.kf_y0m[(size_t)b * io.kf_nym + mm];
+                    for (int k = 0; k < nx; ++k) v -= Cm[a + ny * k] * xh[k];
+                    for (int e = 0; e < nd; ++e) v -= m.Dd[(size_t)b * ny * nd + a + ny * e] * io.d0[(size_t)b * nd + e];
+                    a_ += K[i + nx * mm] * v;
+                }
+                acc[nq] = a_;
+            }
+            w.sync();
+            nq = 0;
+            for (int i = w.lane; i < nx; i += WAVE, ++nq) {
+                xh[i] = acc[nq];
+                if (!io.kf_predict) io.xhat0_out[(size_t)b * nx + i] = acc[nq];
+            }
+            w.sync();
+        }
+    }
     Step<W, DM> st(qp);
     st.build(io);
     if ((d.flags & 4u) && io.q_keep) {
@@ -2323,6 +2356,21 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
         double* tY = sm + st.c.tA[P_Y];
         qp.E_apply(st.z, tY);
         for (int r = w.lane; r < d.nY; r += WAVE) io.Yhat0[(size_t)b * d.nY + r] += tY[r];      // same lane parked F[r]
+    }
+    if (io.kf_predict) {
+        // updatestate! (predict_estimate_obsv!, kalman.jl:298-309) with the input just computed:
+        // x̂0 <- Â x̂0 + B̂u u0 + B̂d d0 + (f̂op - x̂op)
+        const int nx = d.nxh, nu = d.nu, nd = d.nd;
+        const double* xh = sm + st.c.xh;
+        const double* A = m.Ahat + (size_t)b * nx * nx;
+        for (int i = w.lane; i < nx; i += WAVE) {
+            double acc = m.dop ? m.dop[(size_t)b * nx + i] : 0.0;
+            for (int k = 0; k < nx; ++k) acc += A[i + nx * k] * xh[k];
+            for (int cc = 0; cc < nu; ++cc)
+                acc += m.Bu[(size_t)b * nx * nu + i + nx * cc] * (st.z[cc] + io.lastu0[(size_t)b * nu + cc]);
+            for (int e = 0; e < nd; ++e) acc += m.Bd[(size_t)b * nx * nd + i + nx * e] * io.d0[(size_t)b * nd + e];
+            io.xhat0_out[(size_t)b * nx + i] = acc;
+        }
     }
     if (w.lane == 0) {
         io.status[b] = status;

@@ -488,10 +488,24 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
     return MPCQP_OK;
 }
 
+// shared by mpcqp_step_device (kf = false) and mpcqp_loop_device
+static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* lastu0, const double* Ry,
+                            const double* Ru, const double* d0, const double* Dhat0, double* Ztilde, double* u0,
+                            int32_t* status, int32_t* iters, double* Yhat0, void* stream,
+                            const double* y0m, double* xhat0_out, int predict);
+
 int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
                       const double* Ry, const double* Ru, const double* d0, const double* Dhat0,
                       double* Ztilde, double* u0, int32_t* status, int32_t* iters,
                       double* Yhat0, void* stream) {
+    return step_device_impl(h, xhat0, lastu0, Ry, Ru, d0, Dhat0, Ztilde, u0, status, iters, Yhat0, stream,
+                            nullptr, nullptr, 0);
+}
+
+static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* lastu0, const double* Ry,
+                            const double* Ru, const double* d0, const double* Dhat0, double* Ztilde, double* u0,
+                            int32_t* status, int32_t* iters, double* Yhat0, void* stream,
+                            const double* y0m, double* xhat0_out, int predict) {
     if (!h || !xhat0 || !lastu0 || !Ry || !Ztilde || !u0 || !status) return MPCQP_ERR_NULL;
     const Dims& d = h->d;
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
@@ -502,6 +516,10 @@ int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
     StepIO io{};
     io.xhat0 = xhat0; io.lastu0 = lastu0; io.Ry = Ry; io.Ru = Ru; io.d0 = d0; io.Dhat0 = Dhat0;
     io.Z = Ztilde; io.u0 = u0; io.Yhat0 = Yhat0; io.status = status; io.iters = iters;
+    if (y0m) {
+        io.kf_K = h->kf.Khat; io.kf_iym = h->kf.i_ym; io.kf_nym = h->kf.nym;
+        io.kf_y0m = y0m; io.xhat0_out = xhat0_out; io.kf_predict = predict;
+    }
     if (d.flags & MPCQP_FLAG_KEEP_QP) {
         int rc = dev_alloc(h, h->keep_q, (size_t)d.B * d.nZ * sizeof(double));
         if (!rc) rc = dev_alloc(h, h->keep_F, (size_t)d.B * d.nY * sizeof(double));
@@ -529,6 +547,17 @@ int mpcqp_step_device(mpcqp_handle h, const double* xhat0, const double* lastu0,
     HIPCHK(hipEventRecord(h->ev_s1, st));
     h->step_timed = true;
     return MPCQP_OK;
+}
+
+int mpcqp_loop_device(mpcqp_handle h, double* xhat0, const double* y0m, const double* lastu0,
+                      const double* Ry, const double* Ru, const double* d0, const double* Dhat0,
+                      double* Ztilde, double* u0, int32_t* status, int32_t* iters, double* Yhat0,
+                      void* stream) {
+    if (!h || !y0m || !xhat0) return MPCQP_ERR_NULL;
+    if (!h->have_kf) return MPCQP_ERR_ORDER;
+    if (h->d.nxh > 4 * WAVE) return MPCQP_ERR_UNSUPPORTED;
+    return step_device_impl(h, xhat0, lastu0, Ry, Ru, d0, Dhat0, Ztilde, u0, status, iters, Yhat0, stream,
+                            y0m, xhat0, 1);
 }
 
 int mpcqp_step(mpcqp_handle h, const double* xhat0, const double* lastu0, const double* Ry,

@@ -118,6 +118,14 @@ struct StepIO {
     const double* lam_prev;    // optional [B][nrows]: multipliers of the previous period (MPCQP_FLAG_WARM_DUAL)
     double* lam_out;           // optional [B][nrows]: multipliers of this period
     double *prof;              // optional [B][16] per-phase cycle counts (-DMPCQP_PROFILE builds only)
+    // optional: the SteadyKalmanFilter steps on both sides of moveinput! inside the same launch
+    // (mpcqp_loop_device): kf_y0m != null => preparestate! first, x̂0 += K̂ (y0m - Ĉm x̂0 - D̂dm d0);
+    // kf_predict != 0 => updatestate! last, x̂0 <- Â x̂0 + B̂u u0 + B̂d d0 + (f̂op - x̂op); both write xhat0_out
+    const double* kf_K;        // [B][nym][nxh]
+    const int* kf_iym;         // [nym]
+    const double* kf_y0m;      // [B][nym]
+    double* xhat0_out;         // [B][nxh]  (may alias xhat0)
+    int kf_nym, kf_predict;
 };
 
 // Packed lower triangle, row-major.  Rows are grouped in fours; every row of group g = i/4 is padded

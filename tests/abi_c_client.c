@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
         (const void*)mpcqp_set_model, (const void*)mpcqp_set_weights,
         (const void*)mpcqp_set_output_weight_blocks, (const void*)mpcqp_set_custom_constraints,
         (const void*)mpcqp_set_custom_bounds, (const void*)mpcqp_set_flags, (const void*)mpcqp_set_bounds, (const void*)mpcqp_step,
-        (const void*)mpcqp_step_device, (const void*)mpcqp_recondense_device, (const void*)mpcqp_get,
+        (const void*)mpcqp_step_device, (const void*)mpcqp_loop_device, (const void*)mpcqp_recondense_device, (const void*)mpcqp_get,
         (const void*)mpcqp_last_step_ms, (const void*)mpcqp_last_condense_ms, (const void*)mpcqp_last_predmat_ms,
         (const void*)mpcqp_kf_set, (const void*)mpcqp_kf_correct, (const void*)mpcqp_kf_predict,
         (const void*)mpcqp_kf_correct_device, (const void*)mpcqp_kf_predict_device,

@@ -63,6 +63,60 @@ def oracle_batch(cfg, bt):
             "q": np.array(Q), "H": np.array(H)}
 
 
+def fused_loop_vs_separate_steps(lib=None, B=3, periods=4, torch_device=None):
+    """mpcqp_loop_device (preparestate! + moveinput! + updatestate! in one launch) against the three
+    separate entry points on the same resident data: returns max |difference| of x̂0, u0, Z̃ over the
+    periods (the arithmetic is the same instruction for instruction: expected 0).  Arrays are torch
+    tensors on `torch_device`, or NumPy arrays when the library is the CPU emulator."""
+    cfg = synth.Config("loop", nx=3, nu=2, ny=2, Hp=8, Hc=3, umin=-0.6, umax=0.7, ymax=0.9)
+    bt = synth.make_batch(cfg, B, seed=12)
+    rng = np.random.default_rng(5)
+    K = mpcqp.steady_kalman_gain(bt["Ahat"], bt["Chat"], np.eye(cfg.nxh), np.eye(cfg.ny))
+
+    def make():
+        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=1, flags=mpcqp.FLAG_RY_CONSTANT, lib=lib)
+        hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
+        hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt))
+        hd.set_bounds(U0min=np.full((B, hd.nU), cfg.umin), U0max=np.full((B, hd.nU), cfg.umax), Y0max=np.full((B, hd.nY), cfg.ymax))
+        hd.kf_set(mpcqp.colmajor(K), np.arange(cfg.ny))
+        hd.prepare()
+        return hd
+
+    if torch_device is None:
+        new = lambda a: np.ascontiguousarray(a).copy()
+        ptr = lambda a: a.ctypes.data
+        host = lambda a: a
+        sync = lambda: None
+    else:
+        import torch
+        new = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch_device)
+        ptr = lambda a: a.data_ptr()
+        host = lambda a: a.cpu().numpy()
+        sync = torch.cuda.synchronize
+    runs = []
+    for fused in (False, True):
+        hd = make()
+        x = new(bt["xhat0"]); lu = new(bt["lastu0"]); ry = new(bt["ry"])
+        Z = new(np.zeros((B, hd.nZ))); u0 = new(np.zeros((B, cfg.nu)))
+        st = new(np.zeros(B, np.int32)); it = new(np.zeros(B, np.int32))
+        rg = np.random.default_rng(7)
+        out = []
+        for k in range(periods):
+            y = new(0.3 * rg.standard_normal((B, cfg.ny)))
+            if fused:
+                hd.loop_device(ptr(x), ptr(y), ptr(lu), ptr(ry), ptr(Z), ptr(u0), ptr(st), iters=ptr(it))
+            else:
+                hd.kf_correct_device(ptr(x), ptr(y))
+                hd.step_device(ptr(x), ptr(lu), ptr(ry), ptr(Z), ptr(u0), ptr(st), iters=ptr(it))
+                hd.kf_predict_device(ptr(x), ptr(u0))
+            sync()
+            assert np.all(host(st) == 0)
+            out.append((host(x).copy(), host(u0).copy(), host(Z).copy()))
+            lu, u0 = u0, lu                      # u0 of this period is lastu0 of the next
+        runs.append(out)
+    return max(float(np.abs(a - b).max()) for pa, pb in zip(*runs) for a, b in zip(pa, pb))
+
+
 def write_c_fixture(path, name="C2", n=8):
     """Raw fixture for tests/abi_c_client.c `run`: the first n instances of a golden file
     (tests/golden/<name>_seed0-3.npz) in the C-ABI layout + their expected optimum."""

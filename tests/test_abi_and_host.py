@@ -265,6 +265,12 @@ def test_random_controller_families_on_cpu_emulator(seed, emulib):
     assert e is not None and e <= 1e-5
 
 
+def test_fused_loop_equals_separate_steps_on_cpu_emulator(emulib):
+    """mpcqp_loop_device: Kalman correction, moveinput! and Kalman prediction in one launch."""
+    from tests.parity_util import fused_loop_vs_separate_steps
+    assert fused_loop_vs_separate_steps(lib=emulib, B=2, periods=3) == 0.0
+
+
 def _check_readme_example(worst, U, Y, Hp, nxh):
     assert (Hp, nxh) == (30, 24)                       # 10 + 20 delays; 22 states + 2 output integrators
     assert worst <= 1e-6                               # ABI vs oracle, every period

@@ -141,6 +141,13 @@ def test_multi_device_entry_points_on_gpu(hiplib):
     assert [mh.shard(g) for g in range(3)] == [(0, 334), (334, 333), (667, 333)]
 
 
+def test_fused_loop_equals_separate_steps_on_gpu(hiplib):
+    """mpcqp_loop_device (one launch per control period) against kf_correct + step + kf_predict."""
+    import torch
+    from tests.parity_util import fused_loop_vs_separate_steps
+    assert fused_loop_vs_separate_steps(B=64, periods=5, torch_device=torch.device("cuda", 0)) == 0.0
+
+
 def test_config4_batch_on_one_gpu(hiplib):
     """BASELINE configs[3]'s batch (B = 262144, C3 shapes) on ONE GPU: every instance OPTIMAL, the
     size-independent properties, sampled parity against the certified oracle, and shard = slice: the
