@@ -9,4 +9,5 @@ from .api import (BatchLinMPC, Handle, MultiHandle, MpcqpError, load_library, mo
                   STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR, EXPORTS,
                   FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL,
                   GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC)
-from . import synth, sharding  # noqa: F401
+from . import synth, sharding, mhe  # noqa: F401
+from .mhe import BatchMHE, MheHandle  # noqa: F401

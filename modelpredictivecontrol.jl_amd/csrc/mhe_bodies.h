@@ -1,0 +1,867 @@
+// mhe_bodies.h -- kernel bodies of the batched linear MovingHorizonEstimator, written
+// against a wave interface W (gfx950: mhe_devwave.h; CPU emulator: tests/emu) like mpcqp_bodies.h.
+//
+// What the reference does per period (LinModel, SingleShooting; one estimator):
+//   add_data_windows!        src/estimator/mhe/execute.jl:497-548   -> push_data()
+//   initpred! (F, fx̄, H̃, q̃)  src/estimator/mhe/execute.jl:419-457   -> build_q()        (stage form, see below)
+//   linconstraint! (b)       src/estimator/mhe/transcription.jl:732-782 -> the row residuals of the sweeps
+//   optim_objective!         src/estimator/mhe/execute.jl:576-618   -> interior-point iterations
+//   getstate!                src/estimator/mhe/execute.jl:629-643   -> write_outputs()
+//   correct_cov!/update_cov! src/estimator/mhe/execute.jl:727-781   -> cov_body()       (KalmanFilter recursion,
+//                            src/estimator/kalman.jl:1235-1264, 1275-1290)
+//
+// Stage form.  With states x(0..N) (x(0) = x̂0arr, N = Nk), g(j) = B̂u u0(j) + B̂d d0(j+p) + (f̂op - x̂op),
+// e(i) = y0m(i) - D̂dm d0(i+1):   ŵ(j) = x(j+1) - Â x(j) - g(j),   v̂(i) = e(i) - Ĉm x(i+1-p)   and
+//   J = (x(0)-x̄)' P̄⁻¹ (x(0)-x̄) + Σ ŵ' Q̂⁻¹ ŵ + Σ v̂' R̂⁻¹ v̂          (execute.jl:444-453 is its condensed form)
+// so the Hessian in X is block tridiagonal:  diag blocks  [s=0] 2P̄⁻¹ + T1 (+T3 if p=1) | T1+T2+T3 | [s=N] T2 (+T3 if p=0),
+// sub-diagonal blocks Oc = -2 Q̂⁻¹ Â,  T1 = 2 Â'Q̂⁻¹Â, T2 = 2 Q̂⁻¹, T3 = 2 Ĉm'R̂⁻¹Ĉm.
+// Bounds (setconstraint!, construct.jl:858-1049, per channel): x̂min <= x(s) <= x̂max, ŵmin <= ŵ(j) <= ŵmax,
+// v̂min <= v̂(i) <= v̂max; every row touches one stage (x̂, v̂) or two neighbours (ŵ), so
+// Φ = H + G'D̃G keeps the block-tridiagonal pattern.  Newton systems are solved by the block Thomas
+// recursion  S(s) = Φ(s,s) - O(s-1) S(s-1)⁻¹ O(s-1)',  Si(s) = S(s)⁻¹ (Gauss-Jordan in registers).
+//
+// Interior-point method: the same dual-regularised Mehrotra predictor-corrector as the LinMPC step
+// (mpcqp_bodies.h Step::run; oracle/linmpc_ref.c restates it), without the active-set polish.
+#pragma once
+#include <math.h>
+
+#include "mhe_types.h"
+
+namespace mpcqp {
+namespace mhe {
+
+template <int I>
+struct IC { static constexpr int v = I; };
+template <int N, int I = 0, class F>
+MPCQP_HD void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        sfor<N, I + 1>(f);
+    }
+}
+
+// Row-lane linear algebra of one 16-lane group: every lane holds ITS row of each operand.
+template <class W, int NX>
+struct Ops {
+    W& w;
+    using Row = double[NX];
+
+    MPCQP_HD double mv(const Row& M, double v) const {            // (M v)[r]
+        double acc = 0.0;
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; acc = fma(M[c], w.template rowbc<c>(v), acc); });
+        return acc;
+    }
+    MPCQP_HD void mm(const Row& X, const Row& Y, Row& C) const {  // C = X Y
+        sfor<NX>([&](auto ic) {
+            constexpr int c = decltype(ic)::v;
+            double acc = 0.0;
+            sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(X[k], w.template rowbc<k>(Y[c]), acc); });
+            C[c] = acc;
+        });
+    }
+    MPCQP_HD void mmt_acc(const Row& X, const Row& Y, Row& C, double sign) const {   // C += sign X Y'
+        sfor<NX>([&](auto ic) {
+            constexpr int c = decltype(ic)::v;
+            double acc = 0.0;
+            sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(X[k], w.template rowbc<c>(Y[k]), acc); });
+            C[c] = fma(sign, acc, C[c]);
+        });
+    }
+    // in-place inverse of a symmetric positive definite matrix (Gauss-Jordan, no pivoting: the pivots
+    // are those of the LDL' factorisation).  Returns false (for the whole group) on a bad pivot.
+    MPCQP_HD bool gj(Row& a, int r) const {
+        bool ok = true;
+        sfor<NX>([&](auto ik) {
+            constexpr int k = decltype(ik)::v;
+            const double dk = w.template rowbc<k>(a[k]);
+            ok = ok && (dk > 1e-280) && (dk < 1e280);
+            const double pinv = 1.0 / dk;
+            const bool piv = (r == k);
+            const double f = piv ? -1.0 : a[k];      // pivot row: a[c] <- a[c]/dk  ==  0*a[c] + 1*rk
+            const double m = piv ? 0.0 : 1.0;
+            sfor<NX>([&](auto ic) {
+                constexpr int c = decltype(ic)::v;
+                if constexpr (c != k) {
+                    const double rk = w.template rowbc<k>(a[c]) * pinv;
+                    a[c] = fma(-f, rk, a[c] * m);
+                }
+            });
+            a[k] = piv ? pinv : -f * pinv;
+        });
+        return ok;
+    }
+    MPCQP_HD static void ld(const double* p, int stride, Row& M) {
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] = p[(size_t)c * stride]; });
+    }
+    MPCQP_HD static void st(double* p, int stride, const Row& M) {
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; p[(size_t)c * stride] = M[c]; });
+    }
+    MPCQP_HD static void add_diag(Row& M, int r, double v) {
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] += (r == c) ? v : 0.0; });
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// set_model: the constant block of every estimator (once per model / covariance change)
+template <class W, int NX>
+MPCQP_HD void setup_body(W& w, const Dims& d, const Raw& in, double* cst_all, int wave_id) {
+    using O = Ops<W, NX>;
+    typename O::Row A, At, Qi, Cm, Ct, Ri, T, U;
+    O op{w};
+    const int lane = w.lane, r = lane & (RL - 1), g = lane >> 4;
+    const CstMap cm = cst_map(NX, d.nu, d.nd);
+    const int nx = d.nx, nym = d.nym, nu = d.nu, nd = d.nd;
+    for (int wg = wave_id; wg * GPW < d.B; wg += d.nwaves) {
+        const int bq = wg * GPW + g;
+        const bool live = bq < d.B;
+        const int b = live ? bq : d.B - 1;
+        double* cst = cst_all + (size_t)b * cm.stride + r;
+        const double* Ar = in.Ahat + (size_t)b * nx * nx;
+        const double* Qr = in.Q + (size_t)b * nx * nx;
+        const double* Cr = in.Cm + (size_t)b * nym * nx;
+        const double* Rr = in.R + (size_t)b * nym * nym;
+        sfor<NX>([&](auto ic) {
+            constexpr int c = decltype(ic)::v;
+            const bool in_x = r < nx && c < nx;
+            A[c] = in_x ? Ar[c * nx + r] : 0.0;
+            At[c] = in_x ? Ar[r * nx + c] : 0.0;
+            Qi[c] = in_x ? Qr[c * nx + r] : (r == c ? 1.0 : 0.0);
+            Cm[c] = (r < nym && c < nx) ? Cr[c * nym + r] : 0.0;          // row = measured output r
+            Ct[c] = (r < nx && c < nym) ? Cr[r * nym + c] : 0.0;          // row = state r, column = output c
+            Ri[c] = (r < nym && c < nym) ? Rr[c * nym + r] : (r == c ? 1.0 : 0.0);
+        });
+        if (live) {
+            O::st(cst + cm.A, RL, A); O::st(cst + cm.At, RL, At);
+            O::st(cst + cm.Cm, RL, Cm); O::st(cst + cm.Ct, RL, Ct);
+            O::st(cst + cm.Q, RL, Qi); O::st(cst + cm.R, RL, Ri);
+        }
+        op.gj(Qi, r);
+        op.gj(Ri, r);
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Qi[c] *= 2.0; Ri[c] *= 2.0; });    // 2 Q̂⁻¹, 2 R̂⁻¹
+        typename O::Row Bm;
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bm[c] = Qi[c]; });
+        if (live) O::st(cst + cm.T2, RL, Qi);
+        op.mm(Qi, A, T);                                   // 2 Q̂⁻¹ Â
+        op.mm(At, T, U);                                   // T1 = Â' 2Q̂⁻¹ Â
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bm[c] += U[c]; T[c] = -T[c]; });
+        if (live) { O::st(cst + cm.T1, RL, U); O::st(cst + cm.Oc, RL, T); }
+        op.mm(At, Qi, U);                                  // (Â' 2Q̂⁻¹) = -Oc'
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; U[c] = -U[c]; });
+        if (live) O::st(cst + cm.OcT, RL, U);
+        op.mm(Ri, Cm, T);                                  // 2R̂⁻¹ Ĉm
+        op.mm(Ct, T, U);                                   // T3
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bm[c] += U[c]; });
+        if (live) { O::st(cst + cm.T3, RL, U); O::st(cst + cm.Bmid, RL, Bm); }
+        op.mm(Ct, Ri, U);                                  // CR = Ĉm' 2R̂⁻¹
+        if (live) O::st(cst + cm.CR, RL, U);
+        if (live) {
+            for (int c = 0; c < nu; ++c) cst[cm.Bu + c * RL] = r < nx ? in.Bu[(size_t)b * nx * nu + c * nx + r] : 0.0;
+            for (int c = 0; c < nd; ++c) {
+                cst[cm.Bd + c * RL] = r < nx ? in.Bd[(size_t)b * nx * nd + c * nx + r] : 0.0;
+                cst[cm.Ddm + c * RL] = r < nym ? in.Ddm[(size_t)b * nym * nd + c * nym + r] : 0.0;
+            }
+            cst[cm.fx] = (r < nx && in.fx) ? in.fx[(size_t)b * nx + r] : 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// arrival covariance: mode bit 0 = KalmanFilter correction, bit 1 = prediction (data independent),
+// then Pi2 = 2 P̄⁻¹.  P row-lane [B][NX*RL]; mode 4: (re)load P from the ABI array P0 [B][nx*nx] first.
+template <class W, int NX>
+MPCQP_HD void cov_body(W& w, const Dims& d, const Args& a, int mode, const double* P0, double* Pout, int wave_id) {
+    using O = Ops<W, NX>;
+    typename O::Row P, A, Cm, X, Y, M;
+    O op{w};
+    const int lane = w.lane, r = lane & (RL - 1), g = lane >> 4;
+    const CstMap cm = cst_map(NX, d.nu, d.nd);
+    const int nx = d.nx;
+    for (int wg = wave_id; wg * GPW < d.B; wg += d.nwaves) {
+        const int bq = wg * GPW + g;
+        const bool live = bq < d.B;
+        const int b = live ? bq : d.B - 1;
+        const double* cst = a.cst + (size_t)b * cm.stride + r;
+        double* Pm = a.P + (size_t)b * NX * RL + r;
+        if (mode & 4) {
+            sfor<NX>([&](auto ic) {
+                constexpr int c = decltype(ic)::v;
+                P[c] = (r < nx && c < nx) ? P0[(size_t)b * nx * nx + c * nx + r] : (r == c ? 1.0 : 0.0);
+            });
+        } else {
+            O::ld(Pm, RL, P);
+        }
+        if (mode & 1) {        // P <- P - P Ĉm' (Ĉm P Ĉm' + R̂)⁻¹ Ĉm P
+            O::ld(cst + cm.Cm, RL, Cm);
+            O::ld(cst + cm.R, RL, M);
+            op.mm(Cm, P, X);                   // Ĉm P          (row = output)
+            op.mmt_acc(X, Cm, M, 1.0);         // M = R̂ + (Ĉm P) Ĉm'
+            op.gj(M, r);
+            op.mm(M, X, Y);                    // M⁻¹ Ĉm P
+            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] = 0.0; });
+            op.mmt_acc(P, Cm, M, 1.0);         // P Ĉm'         (row = state, column = output)
+            op.mm(M, Y, X);
+            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; P[c] -= X[c]; });
+        }
+        if (mode & 2) {        // P <- Â P Â' + Q̂
+            O::ld(cst + cm.A, RL, A);
+            op.mm(A, P, X);
+            O::ld(cst + cm.Q, RL, P);
+            // (padding rows/columns of Q̂ hold the identity: the padded block of P stays the identity)
+            op.mmt_acc(X, A, P, 1.0);
+        }
+        if (live) {
+            O::st(Pm, RL, P);
+            if (Pout && r < nx)
+                sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; if (c < nx) Pout[(size_t)b * nx * nx + c * nx + r] = P[c]; });
+        }
+        op.gj(P, r);
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; P[c] *= 2.0; });
+        if (live) O::st(a.Pi2 + (size_t)b * NX * RL + r, RL, P);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one inequality row: slack sv, multiplier lv, primal residual rp = g'z + s - h.
+struct RowK {
+    double Dt, wv, c;
+};
+MPCQP_HD inline RowK row_rhs(bool has, double sv, double lv, double rp, double extra, double delta) {
+    // D̃ = D/(1 + δD), c = w rc/s - D̃ rp with rc = s λ + extra (Step::run of mpcqp_bodies.h)
+    RowK k;
+    const double D = lv / sv;
+    k.wv = 1.0 / (1.0 + delta * D);
+    k.Dt = has ? D * k.wv : 0.0;
+    const double rc = sv * lv + extra;
+    k.c = has ? k.wv * rc / sv - k.Dt * rp : 0.0;
+    return k;
+}
+MPCQP_HD inline void row_dir(bool has, double sv, double lv, double rp, double gd, double extra, double delta,
+                             double& ds, double& dl) {
+    const double D = lv / sv, wv = 1.0 / (1.0 + delta * D), Dt = D * wv, rc = sv * lv + extra;
+    dl = has ? -wv * rc / sv + Dt * (rp + gd) : 0.0;
+    ds = has ? -wv * ((rp + gd) + delta * rc / sv) : 0.0;
+}
+MPCQP_HD inline double ratio(double v, double dv) { return dv < 0.0 ? -v / dv : 1e300; }
+
+// ---------------------------------------------------------------------------------------------
+template <class W, int NX>
+struct Solver {
+    using O = Ops<W, NX>;
+    using Row = typename O::Row;
+    W& w;
+    const Dims& d;
+    const Args& a;
+    O op;
+    const int lane, r, g;
+    const CstMap cm;
+    const SlotMap sm;
+    int b;
+    bool live;
+    const double* cst;
+    double* sc;      // this lane's column of the wave scratch
+    double* lds;     // this lane's column of the wave's LDS: Oc, OcT, Bmid rows
+    int N, p;
+    bool cX, cW, cV;
+    double xlo, xhi, wlo, whi, vlo, vhi;
+    bool hxlo, hxhi, hwlo, hwhi, hvlo, hvhi;
+
+    MPCQP_HD Solver(W& w_, const Dims& d_, const Args& a_, double* smem, int wave_id)
+        : w(w_), d(d_), a(a_), op{w_}, lane(w_.lane), r(w_.lane & (RL - 1)), g(w_.lane >> 4),
+          cm(cst_map(NX, d_.nu, d_.nd)), sm(slot_map(NX, d_.He, d_.cls)) {
+        sc = a.scratch + (size_t)wave_id * d.nslot * WAVE + lane;
+        lds = smem + lane;
+        N = d.N;
+        p = d.direct ? 0 : 1;
+        cX = d.cls & CLS_X; cW = d.cls & CLS_W; cV = d.cls & CLS_V;
+    }
+    MPCQP_HD double& S(int slot) { return sc[(size_t)slot * WAVE]; }
+    MPCQP_HD const double* L_Oc() const { return lds; }
+    MPCQP_HD const double* L_OcT() const { return lds + (size_t)NX * WAVE; }
+    MPCQP_HD const double* L_Bmid() const { return lds + (size_t)2 * NX * WAVE; }
+    MPCQP_HD int yslot(int i) const { return (d.hy + i) % d.He; }
+    MPCQP_HD int dslot(int i) const { return (d.hd + i) % (d.He + 1); }
+    // measurement attached to state s (p = 0: i = s-1, p = 1: i = s), -1: none
+    MPCQP_HD int meas_of(int s) const { const int i = s - 1 + p; return (i >= 0 && i < N) ? i : -1; }
+
+    // diagonal block of the Hessian at stage s
+    MPCQP_HD void base_block(int s, Row& Bs) {
+        if (s > 0 && s < N) {
+            O::ld(L_Bmid(), WAVE, Bs);
+            return;
+        }
+        Row T;
+        if (s == 0) {
+            O::ld(a.Pi2 + (size_t)b * NX * RL + r, RL, Bs);
+            O::ld(cst + cm.T1, RL, T);
+        } else {
+            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] = 0.0; });
+            O::ld(cst + cm.T2, RL, T);
+        }
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] += T[c]; });
+        if (meas_of(s) >= 0) {
+            O::ld(cst + cm.T3, RL, T);
+            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] += T[c]; });
+        }
+    }
+
+    // add_data_windows! (execute.jl:497-548): this period's data become window entry N-1 (ring slots)
+    MPCQP_HD void push_data() {
+        if (!a.y0m_new) return;
+        const int nx = d.nx, nu = d.nu, nd = d.nd, nym = d.nym, He = d.He;
+        if (live) {
+            const int e = yslot(N - 1);
+            if (r < nym) a.Y0m[((size_t)b * He + e) * nym + r] = a.y0m_new[(size_t)b * nym + r];
+            if (r < nx) a.X0old[((size_t)b * He + e) * nx + r] = a.xhat0[(size_t)b * nx + r];
+            for (int c = r; c < nu; c += RL) a.U0[((size_t)b * He + e) * nu + c] = a.u0_new[(size_t)b * nu + c];
+            const int ed = dslot(N);
+            for (int c = r; c < nd; c += RL) a.D0[((size_t)b * (He + 1) + ed) * nd + c] = a.d0_new[(size_t)b * nd + c];
+        }
+        w.sync();
+    }
+
+    MPCQP_HD double g_of(int j) {      // g(j)[r] = B̂u u0(j) + B̂d d0(j+p) + (f̂op - x̂op)
+        double acc = cst[cm.fx];
+        const double* u = a.U0 + ((size_t)b * d.He + yslot(j)) * d.nu;
+        for (int c = 0; c < d.nu; ++c) acc = fma(cst[cm.Bu + c * RL], u[c], acc);
+        const double* dd = a.D0 + ((size_t)b * (d.He + 1) + dslot(j + p)) * d.nd;
+        for (int c = 0; c < d.nd; ++c) acc = fma(cst[cm.Bd + c * RL], dd[c], acc);
+        return acc;
+    }
+    MPCQP_HD double e_of(int i) {      // e(i)[r] = y0m(i) - D̂dm d0(i+1)        (lanes r < nym)
+        double acc = r < d.nym ? a.Y0m[((size_t)b * d.He + yslot(i)) * d.nym + r] : 0.0;
+        const double* dd = a.D0 + ((size_t)b * (d.He + 1) + dslot(i + 1)) * d.nd;
+        for (int c = 0; c < d.nd; ++c) acc = fma(-cst[cm.Ddm + c * RL], dd[c], acc);
+        return acc;
+    }
+
+    MPCQP_HD void run() {
+        const int nx = d.nx, nym = d.nym;
+        push_data();
+        // ---- constants to LDS
+        {
+            Row T;
+            O::ld(cst + cm.Oc, RL, T); O::st(lds, WAVE, T);
+            O::ld(cst + cm.OcT, RL, T); O::st(lds + (size_t)NX * WAVE, WAVE, T);
+            O::ld(cst + cm.Bmid, RL, T); O::st(lds + (size_t)2 * NX * WAVE, WAVE, T);
+        }
+        auto bnd = [&](const double* p_, bool on, int n, double dflt) { return (on && p_ && r < n) ? p_[(size_t)b * RL + r] : dflt; };
+        xlo = bnd(a.xmin, cX, nx, -BIG); xhi = bnd(a.xmax, cX, nx, BIG);
+        wlo = bnd(a.wmin, cW, nx, -BIG); whi = bnd(a.wmax, cW, nx, BIG);
+        vlo = bnd(a.vmin, cV, nym, -BIG); vhi = bnd(a.vmax, cV, nym, BIG);
+        hxlo = xlo > -BIG; hxhi = xhi < BIG; hwlo = wlo > -BIG; hwhi = whi < BIG; hvlo = vlo > -BIG; hvhi = vhi < BIG;
+        const double lam0 = 10.0;
+        const double xbar = r < nx ? a.X0old[((size_t)b * d.He + yslot(0)) * nx + r] : 0.0;     // x̂0arr_old
+
+        // ---- stage data: g, e, q, starting point (x(0) = x̄, ŵ = 0), slacks and multipliers
+        double nh_l = 1.0;
+        int m_l = 0;
+        {
+            Row T;
+            double xc = xbar, gprev = 0.0;
+            for (int s = 0; s <= N; ++s) {
+                const double gs = s < N ? g_of(s) : 0.0;
+                if (s < N) S(sm.G + s) = gs;
+                double q = 0.0;
+                if (s == 0) {
+                    O::ld(a.Pi2 + (size_t)b * NX * RL + r, RL, T);
+                    q -= op.mv(T, xbar);
+                }
+                if (s > 0) {
+                    O::ld(cst + cm.T2, RL, T);
+                    q -= op.mv(T, gprev);
+                }
+                if (s < N) {
+                    O::ld(L_OcT(), WAVE, T);
+                    q -= op.mv(T, gs);                  // + Â' 2Q̂⁻¹ g(s)
+                }
+                const int i = meas_of(s);
+                double ei = 0.0;
+                if (i >= 0) {
+                    ei = e_of(i);
+                    S(sm.E + i) = ei;
+                    O::ld(cst + cm.CR, RL, T);
+                    q -= op.mv(T, ei);
+                }
+                S(sm.Q + s) = q;
+                S(sm.X + s) = xc;
+                // rows of this stage
+                if (cX) {
+                    const double s0 = fmax(xc - xlo, 1.0), s1 = fmax(xhi - xc, 1.0);
+                    S(sm.XR + 4 * s + 0) = s0; S(sm.XR + 4 * s + 1) = lam0 / s0;
+                    S(sm.XR + 4 * s + 2) = s1; S(sm.XR + 4 * s + 3) = lam0 / s1;
+                    m_l += (hxlo ? 1 : 0) + (hxhi ? 1 : 0);
+                    if (hxlo) nh_l = fmax(nh_l, fabs(xlo) + 1.0);
+                    if (hxhi) nh_l = fmax(nh_l, fabs(xhi) + 1.0);
+                }
+                if (cW && s < N) {          // ŵ(s) = 0 at the starting point
+                    const double s0 = fmax(0.0 - wlo, 1.0), s1 = fmax(whi - 0.0, 1.0);
+                    S(sm.WR + 4 * s + 0) = s0; S(sm.WR + 4 * s + 1) = lam0 / s0;
+                    S(sm.WR + 4 * s + 2) = s1; S(sm.WR + 4 * s + 3) = lam0 / s1;
+                    m_l += (hwlo ? 1 : 0) + (hwhi ? 1 : 0);
+                    if (hwlo) nh_l = fmax(nh_l, fabs(wlo) + 1.0);
+                    if (hwhi) nh_l = fmax(nh_l, fabs(whi) + 1.0);
+                }
+                if (cV && i >= 0) {
+                    O::ld(cst + cm.Cm, RL, T);
+                    const double vv = ei - op.mv(T, xc);
+                    const double s0 = fmax(vv - vlo, 1.0), s1 = fmax(vhi - vv, 1.0);
+                    S(sm.VR + 4 * i + 0) = s0; S(sm.VR + 4 * i + 1) = lam0 / s0;
+                    S(sm.VR + 4 * i + 2) = s1; S(sm.VR + 4 * i + 3) = lam0 / s1;
+                    m_l += (hvlo ? 1 : 0) + (hvhi ? 1 : 0);
+                    if (hvlo) nh_l = fmax(nh_l, fabs(vlo) + 1.0);
+                    if (hvhi) nh_l = fmax(nh_l, fabs(vhi) + 1.0);
+                } else if (cV && i < 0) {
+                    // (no v̂ row at this state)
+                }
+                if (s < N) {                 // x(s+1) = Â x(s) + g(s)
+                    O::ld(cst + cm.A, RL, T);
+                    xc = op.mv(T, xc) + gs;
+                }
+                gprev = gs;
+            }
+        }
+        const double nh = w.rmax(nh_l);
+        const double mrows = w.rsum((double)m_l);
+        const bool norows = !(mrows > 0.0);
+        const double delta = d.dual_reg;
+
+        int st = 1, it = 0;
+        bool done = false;
+        double laststep = 1e300, rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0, rpn = 0.0;
+
+        for (int pass = 0; pass < d.max_iter; ++pass) {
+            double mu = 0.0, smu = 0.0, aaff = 1.0, alpha = 1.0;
+            bool ok = true;
+            for (int phase = 0; phase < 2; ++phase) {
+                // ---------------- forward sweep: residuals (phase 0), right-hand side, factorisation (phase 0), t = S⁻¹ b̃
+                double rpn_l = 0.0, mu_l = 0.0, rdn_l = 0.0, ndd_l = 0.0;
+                {
+                    Row Si, Oprev, Bs, U;
+                    double xm = 0.0, xc = S(sm.X + 0), tprev = 0.0;
+                    double dd_carry = 0.0, gl_carry = 0.0, cr_carry = 0.0;
+                    double dxam = 0.0, dxac = phase ? S(sm.DXA + 0) : 0.0;
+                    for (int s = 0; s <= N; ++s) {
+                        const double xp = s < N ? S(sm.X + s + 1) : 0.0;
+                        const double dxap = (phase && s < N) ? S(sm.DXA + s + 1) : 0.0;
+                        double gl = gl_carry, dd = dd_carry, cr = cr_carry;
+                        dd_carry = gl_carry = cr_carry = 0.0;
+                        double Dtw = 0.0;
+                        if (cX) {
+                            const double s0 = S(sm.XR + 4 * s + 0), l0 = S(sm.XR + 4 * s + 1);
+                            const double s1 = S(sm.XR + 4 * s + 2), l1 = S(sm.XR + 4 * s + 3);
+                            const double rp0 = -xc + s0 + xlo, rp1 = xc + s1 - xhi;
+                            double e0 = 0.0, e1 = 0.0;
+                            if (phase) {
+                                double ds, dl;
+                                row_dir(hxlo, s0, l0, rp0, -dxac, 0.0, delta, ds, dl); e0 = ds * dl - smu;
+                                row_dir(hxhi, s1, l1, rp1, dxac, 0.0, delta, ds, dl); e1 = ds * dl - smu;
+                            }
+                            const RowK k0 = row_rhs(hxlo, s0, l0, rp0, e0, delta), k1 = row_rhs(hxhi, s1, l1, rp1, e1, delta);
+                            gl += (hxhi ? l1 : 0.0) - (hxlo ? l0 : 0.0);
+                            dd += k0.Dt + k1.Dt;
+                            cr += k1.c - k0.c;
+                            if (!phase) {
+                                if (hxlo) { rpn_l = fmax(rpn_l, fabs(rp0)); mu_l += s0 * l0; }
+                                if (hxhi) { rpn_l = fmax(rpn_l, fabs(rp1)); mu_l += s1 * l1; }
+                            }
+                        }
+                        Row A;
+                        if (cW && s < N) {
+                            O::ld(cst + cm.A, RL, A);
+                            double wv;
+                            if (!phase) { wv = xp - op.mv(A, xc) - S(sm.G + s); S(sm.WW + s) = wv; }
+                            else wv = S(sm.WW + s);
+                            const double s0 = S(sm.WR + 4 * s + 0), l0 = S(sm.WR + 4 * s + 1);
+                            const double s1 = S(sm.WR + 4 * s + 2), l1 = S(sm.WR + 4 * s + 3);
+                            const double rp0 = -wv + s0 + wlo, rp1 = wv + s1 - whi;
+                            double e0 = 0.0, e1 = 0.0;
+                            if (phase) {
+                                const double gda = S(sm.WGA + s);
+                                double ds, dl;
+                                row_dir(hwlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
+                                row_dir(hwhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
+                            }
+                            const RowK k0 = row_rhs(hwlo, s0, l0, rp0, e0, delta), k1 = row_rhs(hwhi, s1, l1, rp1, e1, delta);
+                            const double lw = (hwhi ? l1 : 0.0) - (hwlo ? l0 : 0.0), cw = k1.c - k0.c;
+                            Dtw = k0.Dt + k1.Dt;
+                            if (!phase) S(sm.WD + s) = Dtw;
+                            Row At;
+                            O::ld(cst + cm.At, RL, At);
+                            gl -= op.mv(At, lw);
+                            cr -= op.mv(At, cw);
+                            gl_carry = lw; cr_carry = cw; dd_carry = Dtw;
+                            if (!phase) {
+                                if (hwlo) { rpn_l = fmax(rpn_l, fabs(rp0)); mu_l += s0 * l0; }
+                                if (hwhi) { rpn_l = fmax(rpn_l, fabs(rp1)); mu_l += s1 * l1; }
+                            }
+                        }
+                        const int im = meas_of(s);
+                        double Dtv = 0.0;
+                        if (cV && im >= 0) {
+                            Row Cm;
+                            O::ld(cst + cm.Cm, RL, Cm);
+                            double vv;
+                            if (!phase) { vv = S(sm.E + im) - op.mv(Cm, xc); S(sm.VV + im) = vv; }
+                            else vv = S(sm.VV + im);
+                            const double s0 = S(sm.VR + 4 * im + 0), l0 = S(sm.VR + 4 * im + 1);
+                            const double s1 = S(sm.VR + 4 * im + 2), l1 = S(sm.VR + 4 * im + 3);
+                            const double rp0 = -vv + s0 + vlo, rp1 = vv + s1 - vhi;
+                            double e0 = 0.0, e1 = 0.0;
+                            if (phase) {
+                                const double gda = S(sm.VGA + im);
+                                double ds, dl;
+                                row_dir(hvlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
+                                row_dir(hvhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
+                            }
+                            const RowK k0 = row_rhs(hvlo, s0, l0, rp0, e0, delta), k1 = row_rhs(hvhi, s1, l1, rp1, e1, delta);
+                            const double lv = (hvhi ? l1 : 0.0) - (hvlo ? l0 : 0.0), cv = k1.c - k0.c;
+                            Dtv = k0.Dt + k1.Dt;
+                            if (!phase) S(sm.VD + im) = Dtv;
+                            Row Ct;
+                            O::ld(cst + cm.Ct, RL, Ct);
+                            gl -= op.mv(Ct, lv);            // v̂ = e - Ĉm x: the rows' gradient is -Ĉm'
+                            cr -= op.mv(Ct, cv);
+                            if (!phase) {
+                                if (hvlo) { rpn_l = fmax(rpn_l, fabs(rp0)); mu_l += s0 * l0; }
+                                if (hvhi) { rpn_l = fmax(rpn_l, fabs(rp1)); mu_l += s1 * l1; }
+                            }
+                        }
+                        double rd;
+                        if (!phase) {
+                            base_block(s, Bs);
+                            double hz = op.mv(Bs, xc);
+                            if (s > 0) { O::ld(L_Oc(), WAVE, U); hz += op.mv(U, xm); }
+                            if (s < N) { O::ld(L_OcT(), WAVE, U); hz += op.mv(U, xp); }
+                            const double q = S(sm.Q + s);
+                            rd = hz + q + gl;
+                            S(sm.RD + s) = rd;
+                            rdn_l = fmax(rdn_l, fabs(rd));
+                            ndd_l = fmax(ndd_l, fmax(fabs(q), fmax(fabs(hz), fabs(gl))));
+                        } else {
+                            rd = S(sm.RD + s);
+                        }
+                        const double rhs = -rd + cr;
+                        // ---- S(s) = Φ(s,s) - O(s-1) Si(s-1) O(s-1)'
+                        if (!phase) {
+                            O::add_diag(Bs, r, dd);
+                            if (cW && s < N) {            // + Â' D̃w Â
+                                Row At;
+                                O::ld(cst + cm.At, RL, At);
+                                sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; U[c] = Dtw * A[c]; });
+                                sfor<NX>([&](auto ic) {
+                                    constexpr int c = decltype(ic)::v;
+                                    double acc = 0.0;
+                                    sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(At[k], w.template rowbc<k>(U[c]), acc); });
+                                    Bs[c] += acc;
+                                });
+                            }
+                            if (cV && im >= 0) {          // + Ĉm' D̃v Ĉm
+                                Row Cm, Ct;
+                                O::ld(cst + cm.Cm, RL, Cm);
+                                O::ld(cst + cm.Ct, RL, Ct);
+                                sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; U[c] = Dtv * Cm[c]; });
+                                sfor<NX>([&](auto ic) {
+                                    constexpr int c = decltype(ic)::v;
+                                    double acc = 0.0;
+                                    sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(Ct[k], w.template rowbc<k>(U[c]), acc); });
+                                    Bs[c] += acc;
+                                });
+                            }
+                            if (s > 0) {
+                                op.mm(Oprev, Si, U);
+                                op.mmt_acc(U, Oprev, Bs, -1.0);
+                            }
+                            ok = op.gj(Bs, r) && ok;
+                            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Si[c] = Bs[c]; });
+                            O::st(&S(sm.SI + s * NX), WAVE, Si);
+                        } else {
+                            if (s > 0) {                   // O(s-1) of this sweep (the previous Si is not needed)
+                                O::ld(L_Oc(), WAVE, Oprev);
+                                if (cW) {
+                                    const double Dp = S(sm.WD + s - 1);
+                                    Row Ap;
+                                    O::ld(cst + cm.A, RL, Ap);
+                                    sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Oprev[c] -= Dp * Ap[c]; });
+                                }
+                            }
+                            O::ld(&S(sm.SI + s * NX), WAVE, Si);
+                        }
+                        const double bt = rhs - (s > 0 ? op.mv(Oprev, tprev) : 0.0);
+                        const double t = op.mv(Si, bt);
+                        S(sm.T + s) = t;
+                        tprev = t;
+                        if (!phase && s < N) {             // O(s) = Oc - D̃w Â for the next stage
+                            O::ld(L_Oc(), WAVE, Oprev);
+                            if (cW) sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Oprev[c] -= Dtw * A[c]; });
+                        }
+                        xm = xc; xc = xp;
+                        dxam = dxac; dxac = dxap;
+                    }
+                    (void)dxam;
+                }
+                if (!phase) {
+                    rpn = w.rmax(rpn_l);
+                    const double rdn = w.rmax(rdn_l), ndd = w.rmax(ndd_l) + 1.0;
+                    mu = norows ? 0.0 : w.rsum(mu_l) / mrows;
+                    if (!done) {
+                        it = pass;
+                        if (!(mu == mu) || !(rdn == rdn)) { st = 2; done = true; }
+                        const bool stalled = rdn >= 0.5 * rdn_prev && lastscale <= 0.1;
+                        rdn_prev = rdn;
+                        const bool pstalled = rpn >= 0.5 * rpn_prev && lastscale <= 0.1 && rpn <= 1e-9 * nh;
+                        rpn_prev = rpn;
+                        if (!done && mu <= d.gap_tol && (rdn <= d.res_tol * ndd || stalled) &&
+                            (rpn <= 10.0 * d.res_tol * nh || pstalled) && laststep <= 1e-6) { st = 0; done = true; }
+                        if (!done && !ok) { st = 2; done = true; }
+                    }
+                    if (!w.any(!done)) break;
+                }
+                // ---------------- backward sweep: dx(s) = t(s) - Si(s) O(s)' dx(s+1); step ratios of the rows
+                double amin_l = 1e300;
+                {
+                    Row Si, U;
+                    double dxn = 0.0;
+                    const int sDX = phase ? sm.DX : sm.DXA;
+                    for (int s = N; s >= 0; --s) {
+                        O::ld(&S(sm.SI + s * NX), WAVE, Si);
+                        double dx = S(sm.T + s);
+                        if (s < N) {
+                            O::ld(L_OcT(), WAVE, U);
+                            double u = op.mv(U, dxn);
+                            if (cW) {
+                                Row At;
+                                O::ld(cst + cm.At, RL, At);
+                                u -= op.mv(At, S(sm.WD + s) * dxn);
+                            }
+                            dx -= op.mv(Si, u);
+                        }
+                        S(sDX + s) = dx;
+                        const double xc = S(sm.X + s);
+                        if (cX) {
+                            const double s0 = S(sm.XR + 4 * s + 0), l0 = S(sm.XR + 4 * s + 1);
+                            const double s1 = S(sm.XR + 4 * s + 2), l1 = S(sm.XR + 4 * s + 3);
+                            const double rp0 = -xc + s0 + xlo, rp1 = xc + s1 - xhi;
+                            double e0 = 0.0, e1 = 0.0, ds, dl;
+                            if (phase) {
+                                const double dxa = S(sm.DXA + s);
+                                row_dir(hxlo, s0, l0, rp0, -dxa, 0.0, delta, ds, dl); e0 = ds * dl - smu;
+                                row_dir(hxhi, s1, l1, rp1, dxa, 0.0, delta, ds, dl); e1 = ds * dl - smu;
+                            }
+                            row_dir(hxlo, s0, l0, rp0, -dx, e0, delta, ds, dl);
+                            amin_l = fmin(amin_l, fmin(ratio(s0, ds), ratio(l0, dl)));
+                            row_dir(hxhi, s1, l1, rp1, dx, e1, delta, ds, dl);
+                            amin_l = fmin(amin_l, fmin(ratio(s1, ds), ratio(l1, dl)));
+                        }
+                        if (cW && s < N) {
+                            Row A;
+                            O::ld(cst + cm.A, RL, A);
+                            const double gd = dxn - op.mv(A, dx);
+                            S((phase ? sm.WG : sm.WGA) + s) = gd;
+                            const double wv = S(sm.WW + s);
+                            const double s0 = S(sm.WR + 4 * s + 0), l0 = S(sm.WR + 4 * s + 1);
+                            const double s1 = S(sm.WR + 4 * s + 2), l1 = S(sm.WR + 4 * s + 3);
+                            const double rp0 = -wv + s0 + wlo, rp1 = wv + s1 - whi;
+                            double e0 = 0.0, e1 = 0.0, ds, dl;
+                            if (phase) {
+                                const double gda = S(sm.WGA + s);
+                                row_dir(hwlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
+                                row_dir(hwhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
+                            }
+                            row_dir(hwlo, s0, l0, rp0, -gd, e0, delta, ds, dl);
+                            amin_l = fmin(amin_l, fmin(ratio(s0, ds), ratio(l0, dl)));
+                            row_dir(hwhi, s1, l1, rp1, gd, e1, delta, ds, dl);
+                            amin_l = fmin(amin_l, fmin(ratio(s1, ds), ratio(l1, dl)));
+                        }
+                        const int im = meas_of(s);
+                        if (cV && im >= 0) {
+                            Row Cm;
+                            O::ld(cst + cm.Cm, RL, Cm);
+                            const double gd = -op.mv(Cm, dx);
+                            S((phase ? sm.VG : sm.VGA) + im) = gd;
+                            const double vv = S(sm.VV + im);
+                            const double s0 = S(sm.VR + 4 * im + 0), l0 = S(sm.VR + 4 * im + 1);
+                            const double s1 = S(sm.VR + 4 * im + 2), l1 = S(sm.VR + 4 * im + 3);
+                            const double rp0 = -vv + s0 + vlo, rp1 = vv + s1 - vhi;
+                            double e0 = 0.0, e1 = 0.0, ds, dl;
+                            if (phase) {
+                                const double gda = S(sm.VGA + im);
+                                row_dir(hvlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
+                                row_dir(hvhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
+                            }
+                            row_dir(hvlo, s0, l0, rp0, -gd, e0, delta, ds, dl);
+                            amin_l = fmin(amin_l, fmin(ratio(s0, ds), ratio(l0, dl)));
+                            row_dir(hvhi, s1, l1, rp1, gd, e1, delta, ds, dl);
+                            amin_l = fmin(amin_l, fmin(ratio(s1, ds), ratio(l1, dl)));
+                        }
+                        dxn = dx;
+                    }
+                }
+                const double amin = w.rmin(amin_l);
+                if (norows) {          // no finite bound: one Newton step is the optimum
+                    alpha = 1.0;
+                    // the affine direction is the step
+                    for (int s = 0; s <= N; ++s) S(sm.DX + s) = S(sm.DXA + s);
+                    break;
+                }
+                // ---------------- row pass: centring (phase 0) / neighbourhood test (phase 1)
+                const double atry = phase ? fmin(1.0, 0.9999 * amin) : fmin(1.0, amin);
+                double psum_l = 0.0, pmin_l = 1e300;
+                auto prod = [&](bool has, double sv, double lv, double rp, double gda, double gd) {
+                    if (!has) return;
+                    double ds, dl, e = 0.0;
+                    if (phase) { row_dir(true, sv, lv, rp, gda, 0.0, delta, ds, dl); e = ds * dl - smu; }
+                    row_dir(true, sv, lv, rp, phase ? gd : gda, e, delta, ds, dl);
+                    const double pr = (sv + atry * ds) * (lv + atry * dl);
+                    psum_l += pr;
+                    pmin_l = fmin(pmin_l, pr);
+                };
+                for (int s = 0; s <= N; ++s) {
+                    if (cX) {
+                        const double xc = S(sm.X + s), dxa = S(sm.DXA + s), dx = phase ? S(sm.DX + s) : 0.0;
+                        const double s0 = S(sm.XR + 4 * s + 0), l0 = S(sm.XR + 4 * s + 1);
+                        const double s1 = S(sm.XR + 4 * s + 2), l1 = S(sm.XR + 4 * s + 3);
+                        prod(hxlo, s0, l0, -xc + s0 + xlo, -dxa, -dx);
+                        prod(hxhi, s1, l1, xc + s1 - xhi, dxa, dx);
+                    }
+                    if (cW && s < N) {
+                        const double wv = S(sm.WW + s), gda = S(sm.WGA + s), gd = phase ? S(sm.WG + s) : 0.0;
+                        const double s0 = S(sm.WR + 4 * s + 0), l0 = S(sm.WR + 4 * s + 1);
+                        const double s1 = S(sm.WR + 4 * s + 2), l1 = S(sm.WR + 4 * s + 3);
+                        prod(hwlo, s0, l0, -wv + s0 + wlo, -gda, -gd);
+                        prod(hwhi, s1, l1, wv + s1 - whi, gda, gd);
+                    }
+                    const int im = meas_of(s);
+                    if (cV && im >= 0) {
+                        const double vv = S(sm.VV + im), gda = S(sm.VGA + im), gd = phase ? S(sm.VG + im) : 0.0;
+                        const double s0 = S(sm.VR + 4 * im + 0), l0 = S(sm.VR + 4 * im + 1);
+                        const double s1 = S(sm.VR + 4 * im + 2), l1 = S(sm.VR + 4 * im + 3);
+                        prod(hvlo, s0, l0, -vv + s0 + vlo, -gda, -gd);
+                        prod(hvhi, s1, l1, vv + s1 - vhi, gda, gd);
+                    }
+                }
+                const double psum = w.rsum(psum_l);
+                if (!phase) {
+                    aaff = atry;
+                    const double sig = (psum / mrows) / mu;
+                    smu = sig * sig * sig * mu;
+                } else {
+                    const double pmin = w.rmin(pmin_l);
+                    alpha = atry;
+                    if (!(pmin * mrows >= 0.01 * psum)) alpha = fmin(1.0, 0.99 * amin);
+                }
+            }
+            (void)aaff;
+            if (!w.any(!done)) break;
+            // ---------------- update (a finished estimator of the wavefront keeps its iterate)
+            {
+                const double al = done ? 0.0 : alpha;
+                double zm_l = 1.0, dm_l = 0.0;
+                auto upd = [&](bool has, int slot, double rp, double gda, double gd) {
+                    if (!has) return;
+                    const double sv = S(slot), lv = S(slot + 1);
+                    double ds, dl;
+                    row_dir(true, sv, lv, rp, gda, 0.0, delta, ds, dl);
+                    const double e = ds * dl - smu;
+                    row_dir(true, sv, lv, rp, gd, e, delta, ds, dl);
+                    S(slot) = sv + al * ds;
+                    S(slot + 1) = lv + al * dl;
+                };
+                for (int s = 0; s <= N; ++s) {
+                    const double xc = S(sm.X + s), dx = S(sm.DX + s);
+                    if (cX) {
+                        const double dxa = S(sm.DXA + s);
+                        upd(hxlo, sm.XR + 4 * s + 0, -xc + S(sm.XR + 4 * s + 0) + xlo, -dxa, -dx);
+                        upd(hxhi, sm.XR + 4 * s + 2, xc + S(sm.XR + 4 * s + 2) - xhi, dxa, dx);
+                    }
+                    if (cW && s < N) {
+                        const double wv = S(sm.WW + s), gda = S(sm.WGA + s), gd = S(sm.WG + s);
+                        upd(hwlo, sm.WR + 4 * s + 0, -wv + S(sm.WR + 4 * s + 0) + wlo, -gda, -gd);
+                        upd(hwhi, sm.WR + 4 * s + 2, wv + S(sm.WR + 4 * s + 2) - whi, gda, gd);
+                    }
+                    const int im = meas_of(s);
+                    if (cV && im >= 0) {
+                        const double vv = S(sm.VV + im), gda = S(sm.VGA + im), gd = S(sm.VG + im);
+                        upd(hvlo, sm.VR + 4 * im + 0, -vv + S(sm.VR + 4 * im + 0) + vlo, -gda, -gd);
+                        upd(hvhi, sm.VR + 4 * im + 2, vv + S(sm.VR + 4 * im + 2) - vhi, gda, gd);
+                    }
+                    zm_l = fmax(zm_l, fabs(xc));
+                    dm_l = fmax(dm_l, fabs(al * dx));
+                    S(sm.X + s) = xc + al * dx;
+                }
+                if (!done) {
+                    laststep = w.rmax(dm_l) / w.rmax(zm_l);
+                    lastscale = 1.0 - alpha;
+                    if (norows) { st = 0; done = true; it = 0; }
+                } else {
+                    (void)w.rmax(dm_l); (void)w.rmax(zm_l);
+                }
+            }
+            if (!w.any(!done)) break;
+        }
+        if (st == 1 && !(rpn <= 1e-6 * nh)) st = 2;
+        write_outputs(st, it, xbar);
+    }
+
+    // getstate! (execute.jl:629-643): x̂0(k+p) = x(N); Z̃ = [x̂0arr; Ŵ]; optional V̂, X̂
+    MPCQP_HD void write_outputs(int st, int it, double xbar) {
+        const int nx = d.nx, nym = d.nym, He = d.He;
+        Row A, Cm;
+        O::ld(cst + cm.A, RL, A);
+        O::ld(cst + cm.Cm, RL, Cm);
+        const bool bad = st == 2;
+        // a failed solve keeps the open-loop window: x(0) = x̄, ŵ = 0 (the starting point)
+        double xc = bad ? xbar : S(sm.X + 0);
+        if (live && a.Zt && r < nx) a.Zt[(size_t)b * (nx + He * nx) + r] = xc;
+        for (int s = 0; s < N; ++s) {
+            const double gs = S(sm.G + s);
+            const double ax = op.mv(A, xc) + gs;
+            const double xn = bad ? ax : S(sm.X + s + 1);
+            if (live && r < nx) {
+                if (a.Zt) a.Zt[(size_t)b * (nx + He * nx) + nx + s * nx + r] = xn - ax;
+                if (a.Xhat) a.Xhat[(size_t)b * He * nx + s * nx + r] = xn;
+            }
+            xc = xn;
+            if (a.Vhat) {
+                const int i = p ? s : s;       // v̂(i) pairs with state i+1-p
+                (void)i;
+            }
+        }
+        if (live && a.Zt && r < nx)
+            for (int s = N; s < He; ++s) a.Zt[(size_t)b * (nx + He * nx) + nx + s * nx + r] = 0.0;
+        if (a.Vhat) {
+            double xs = bad ? xbar : S(sm.X + 0);
+            for (int s = 0; s <= N; ++s) {
+                const int i = meas_of(s);
+                const double cx = op.mv(Cm, xs);
+                if (i >= 0 && live && r < nym) a.Vhat[(size_t)b * He * nym + i * nym + r] = S(sm.E + i) - cx;
+                if (s < N) xs = bad ? op.mv(A, xs) + S(sm.G + s) : S(sm.X + s + 1);
+            }
+        }
+        if (live) {
+            if (r < nx) a.xhat0[(size_t)b * nx + r] = xc;
+            if (r == 0) {
+                a.status[b] = st;
+                if (a.iters) a.iters[b] = it;
+            }
+        }
+    }
+};
+
+template <class W, int NX>
+MPCQP_HD void step_body(W& w, const Dims& d, const Args& a, int wave_id, double* smem) {
+    Solver<W, NX> sv(w, d, a, smem, wave_id);
+    const CstMap cm = cst_map(NX, d.nu, d.nd);
+    for (int wg = wave_id; wg * GPW < d.B; wg += d.nwaves) {
+        const int bq = wg * GPW + sv.g;
+        sv.live = bq < d.B;
+        sv.b = sv.live ? bq : d.B - 1;
+        sv.cst = a.cst + (size_t)sv.b * cm.stride + sv.r;
+        sv.run();
+        w.sync();
+    }
+}
+
+MPCQP_HD inline size_t step_lds_doubles(int NX) { return (size_t)3 * NX * WAVE; }
+
+}  // namespace mhe
+}  // namespace mpcqp

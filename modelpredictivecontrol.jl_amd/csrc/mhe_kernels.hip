@@ -1,0 +1,66 @@
+// mhe_kernels.hip -- gfx950 kernels of the batched linear MovingHorizonEstimator (bodies: mhe_bodies.h).
+// One wavefront per workgroup, four estimators per wavefront (one per DPP row), persistent grid.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "mhe_bodies.h"
+#include "mhe_devwave.h"
+#include "mhe_launch.h"
+
+namespace mpcqp {
+namespace mhe {
+
+template <int NX>
+__global__ __launch_bounds__(64) void k_mhe_setup(Dims d, Raw in, double* cst) {
+    MheDevWave w{(int)threadIdx.x};
+    setup_body<MheDevWave, NX>(w, d, in, cst, (int)blockIdx.x);
+}
+template <int NX>
+__global__ __launch_bounds__(64) void k_mhe_cov(Dims d, Args a, int mode, const double* P0, double* Pout) {
+    MheDevWave w{(int)threadIdx.x};
+    cov_body<MheDevWave, NX>(w, d, a, mode, P0, Pout, (int)blockIdx.x);
+}
+template <int NX>
+__global__ __launch_bounds__(64) void k_mhe_step(Dims d, Args a) {
+    MheDevWave w{(int)threadIdx.x};
+    step_body<MheDevWave, NX>(w, d, a, (int)blockIdx.x, mpcqp_smem);
+}
+
+#define MHE_DISPATCH(NXV, CALL)                 \
+    switch (NXV) {                              \
+        case 4: { constexpr int NX = 4; CALL; } break;   \
+        case 8: { constexpr int NX = 8; CALL; } break;   \
+        case 12: { constexpr int NX = 12; CALL; } break; \
+        case 16: { constexpr int NX = 16; CALL; } break; \
+        default: return hipErrorInvalidValue;   \
+    }
+
+hipError_t launch_setup(const Dims& d, const Raw& in, double* cst, hipStream_t st) {
+    MHE_DISPATCH(d.NX, hipLaunchKernelGGL(k_mhe_setup<NX>, dim3(d.nwaves), dim3(WAVE), 0, st, d, in, cst));
+    return hipGetLastError();
+}
+hipError_t launch_cov(const Dims& d, const Args& a, int mode, const double* P0, double* Pout, hipStream_t st) {
+    MHE_DISPATCH(d.NX, hipLaunchKernelGGL(k_mhe_cov<NX>, dim3(d.nwaves), dim3(WAVE), 0, st, d, a, mode, P0, Pout));
+    return hipGetLastError();
+}
+hipError_t launch_step(const Dims& d, const Args& a, hipStream_t st) {
+    const size_t lds = step_lds_doubles(d.NX) * sizeof(double);
+    MHE_DISPATCH(d.NX, hipLaunchKernelGGL(k_mhe_step<NX>, dim3(d.nwaves), dim3(WAVE), lds, st, d, a));
+    return hipGetLastError();
+}
+
+int waves_for(int device, int B, int NX) {
+    (void)NX;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int per_cu = 8;
+    if (const char* e = getenv("MPCQP_MHE_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    const int groups = (B + GPW - 1) / GPW;
+    const int cap = cus * per_cu;
+    return groups < cap ? groups : cap;
+}
+
+}  // namespace mhe
+}  // namespace mpcqp

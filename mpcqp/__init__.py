@@ -8,4 +8,5 @@ from .api import *  # noqa: F401,F403,E402
 from .api import (BatchLinMPC, Handle, MultiHandle, MpcqpError, load_library, move_blocking, colmajor,  # noqa: F401,E402
                   steady_kalman_gain,
                   EXPORTS, DEFAULT_LIB)
-from . import synth, api, sharding  # noqa: F401,E402
+from . import synth, api, sharding, mhe  # noqa: F401,E402
+from .mhe import BatchMHE, MheHandle  # noqa: F401,E402

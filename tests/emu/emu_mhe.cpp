@@ -1,0 +1,96 @@
+// TEST INFRASTRUCTURE ONLY: runs the MovingHorizonEstimator kernel bodies (csrc/mhe_bodies.h) on the
+// CPU, one host thread per lane of a 64-wide "wavefront", wavefronts one after the other.
+#include <barrier>
+#include <thread>
+#include <vector>
+
+#include "mhe_bodies.h"
+#include "mhe_launch.h"
+
+namespace mpcqp {
+namespace mhe {
+
+struct EmuShared {
+    std::barrier<> bar{WAVE};
+    double xd[2][WAVE];
+    int xi[2][WAVE];
+};
+
+// every cross-lane operation writes buffer (n % 2) of its n-th call, waits once, reads: a lane can
+// only reach call n + 2 (same buffer) after all lanes passed the barrier of call n + 1, i.e. after
+// all of them finished reading call n
+struct EmuWave {
+    int lane;
+    EmuShared* sh;
+    unsigned n = 0;
+    void sync() { sh->bar.arrive_and_wait(); }
+    double* xchg(double v) {
+        double* buf = sh->xd[n++ & 1];
+        buf[lane] = v;
+        sh->bar.arrive_and_wait();
+        return buf;
+    }
+    template <int C>
+    double rowbc(double v) { return xchg(v)[(lane & ~(RL - 1)) + C]; }
+    template <class Op>
+    double rowred(double v, Op op) {
+        const double* buf = xchg(v);
+        const int r0 = lane & ~(RL - 1);
+        double s = buf[r0];
+        for (int i = 1; i < RL; ++i) s = op(s, buf[r0 + i]);
+        return s;
+    }
+    double rsum(double v) { return rowred(v, [](double x, double y) { return x + y; }); }
+    double rmin(double v) { return rowred(v, [](double x, double y) { return fmin(x, y); }); }
+    double rmax(double v) { return rowred(v, [](double x, double y) { return fmax(x, y); }); }
+    bool any(bool p) {
+        const double* buf = xchg(p ? 1.0 : 0.0);
+        for (int i = 0; i < WAVE; ++i) if (buf[i] != 0.0) return true;
+        return false;
+    }
+};
+
+template <class F>
+static void run_waves(int nwaves, size_t lds_doubles, F body) {
+    std::vector<double> smem(lds_doubles + 16, 0.0);
+    EmuShared sh;
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < WAVE; ++lane)
+        th.emplace_back([&, lane] {
+            EmuWave w{lane, &sh};
+            for (int wv = 0; wv < nwaves; ++wv) {
+                body(w, wv, smem.data());
+                w.sync();
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+#define MHE_DISPATCH(NXV, CALL)                          \
+    switch (NXV) {                                       \
+        case 4: { constexpr int NX = 4; CALL; } break;   \
+        case 8: { constexpr int NX = 8; CALL; } break;   \
+        case 12: { constexpr int NX = 12; CALL; } break; \
+        case 16: { constexpr int NX = 16; CALL; } break; \
+        default: return hipErrorInvalidValue;            \
+    }
+
+hipError_t launch_setup(const Dims& d, const Raw& in, double* cst, hipStream_t) {
+    MHE_DISPATCH(d.NX, run_waves(d.nwaves, 0, [&](EmuWave& w, int wv, double*) { setup_body<EmuWave, NX>(w, d, in, cst, wv); }));
+    return hipSuccess;
+}
+hipError_t launch_cov(const Dims& d, const Args& a, int mode, const double* P0, double* Pout, hipStream_t) {
+    MHE_DISPATCH(d.NX, run_waves(d.nwaves, 0, [&](EmuWave& w, int wv, double*) { cov_body<EmuWave, NX>(w, d, a, mode, P0, Pout, wv); }));
+    return hipSuccess;
+}
+hipError_t launch_step(const Dims& d, const Args& a, hipStream_t) {
+    MHE_DISPATCH(d.NX, run_waves(d.nwaves, step_lds_doubles(d.NX), [&](EmuWave& w, int wv, double* sm) { step_body<EmuWave, NX>(w, d, a, wv, sm); }));
+    return hipSuccess;
+}
+int waves_for(int, int B, int) {
+    const int groups = (B + GPW - 1) / GPW;
+    return groups < 2 ? groups : 2;       // two "persistent" wavefronts: the grid-stride loop is exercised
+}
+
+}  // namespace mhe
+}  // namespace mpcqp
