@@ -603,6 +603,9 @@ struct Solver {
                     rpn = w.rmax(rpn_l);
                     const double rdn = w.rmax(rdn_l), ndd = w.rmax(ndd_l) + 1.0;
                     mu = norows ? 0.0 : w.rsum(mu_l) / mrows;
+#ifdef MHE_DEBUG_PRINT
+                    if (r == 0) printf("[b%d] pass %d mu %.3e rpn %.3e rdn %.3e ndd %.3e laststep %.3e ok %d done %d\n", b, pass, mu, rpn, rdn, ndd, laststep, (int)ok, (int)done);
+#endif
                     if (!done) {
                         it = pass;
                         if (!(mu == mu) || !(rdn == rdn)) { st = 2; done = true; }

@@ -111,3 +111,97 @@ def make_batch(cfg: Config, B: int, seed: int = 0, lo: int = 0):
     res = {k: np.ascontiguousarray(np.concatenate(v)[a:b]) for k, v in out.items()}
     res["cfg"] = cfg
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear MovingHorizonEstimator workloads (BASELINE.json configs[4])
+@dataclass
+class MheConfig:
+    """Dimensions, covariances and per-channel hard bounds of one synthetic MHE workload.  The
+    augmented model is a stable plant with one integrator per measured output
+    (estimator/construct.jl:365-376), so nx̂ = nx + nym."""
+    name: str
+    nx: int
+    nu: int
+    nym: int
+    nd: int
+    He: int
+    direct: bool = True
+    sigmaQ: float = 0.1
+    sigmaQint: float = 0.1
+    sigmaR: float = 0.2
+    sigmaP0: float = 1.0
+    xabs: float = np.inf       # |x̂0| <= xabs on every state (arrival and window)
+    wabs: float = np.inf       # |ŵ| <= wabs
+    vabs: float = np.inf       # |v̂| <= vabs
+
+    @property
+    def nxh(self):
+        return self.nx + self.nym
+
+
+# BASELINE.json configs[4]: He = 20, nx̂ = 12 (8 plant states + 4 output integrators), hard state bounds
+C5 = MheConfig("C5: linear MHE nx̂=12 (8+4 integrators) nu=4 nym=4 He=20, hard x̂ bounds", nx=8, nu=4, nym=4, nd=0,
+               He=20, xabs=1.5)
+MHE_CONFIGS = {"C5": C5}
+
+
+def get_mhe_config(name: str) -> MheConfig:
+    """"C5", or "nx,nu,nym,nd,He" for a C5-style workload of other dimensions."""
+    if name in MHE_CONFIGS:
+        return MHE_CONFIGS[name]
+    nx, nu, nym, nd, He = (int(v) for v in name.split(","))
+    return MheConfig(f"custom MHE: nx={nx} nu={nu} nym={nym} nd={nd} He={He}, hard x̂ bounds", nx=nx, nu=nu, nym=nym,
+                     nd=nd, He=He, xabs=1.5)
+
+
+def make_mhe_batch(cfg: MheConfig, B: int, seed: int = 0, lo: int = 0):
+    """Estimators lo .. lo+B-1 of the seeded workload: Ahat (B,nx̂,nx̂) Bhu (B,nx̂,nu) Chm (B,nym,nx̂)
+    Bhd (B,nx̂,nd) Dhdm (B,nym,nd) Qhat (B,nx̂,nx̂) Rhat (B,nym,nym) P0 (B,nx̂,nx̂), plus the plant
+    (A, Bu, C, Bd) for make_mhe_data."""
+    nx, nu, nym, nd, nxh = cfg.nx, cfg.nu, cfg.nym, cfg.nd, cfg.nxh
+    keys = ("Ahat", "Bhu", "Chm", "Bhd", "Dhdm", "A", "Bu", "C", "Bd")
+    out = {k: [] for k in keys}
+    c0, c1 = lo // CHUNK, (lo + B - 1) // CHUNK
+    for c in range(c0, c1 + 1):
+        rng = np.random.default_rng([seed, c, 5])
+        A = _stable_A(rng, nx, CHUNK)
+        Bu = rng.standard_normal((CHUNK, nx, nu)) / np.sqrt(nx)
+        C = rng.standard_normal((CHUNK, nym, nx)) / np.sqrt(nx)
+        Bd = rng.standard_normal((CHUNK, nx, nd)) / np.sqrt(nx)
+        Ah = np.zeros((CHUNK, nxh, nxh))
+        Ah[:, :nx, :nx] = A
+        Ah[:, nx:, nx:] = np.eye(nym)
+        Bh = np.zeros((CHUNK, nxh, nu)); Bh[:, :nx] = Bu
+        Bhd = np.zeros((CHUNK, nxh, nd)); Bhd[:, :nx] = Bd
+        Ch = np.concatenate([C, np.broadcast_to(np.eye(nym), (CHUNK, nym, nym))], axis=2)
+        for k, v in zip(keys, (Ah, Bh, Ch, Bhd, np.zeros((CHUNK, nym, nd)), A, Bu, C, Bd)):
+            out[k].append(v)
+    a, b = lo - c0 * CHUNK, lo - c0 * CHUNK + B
+    res = {k: np.ascontiguousarray(np.concatenate(v)[a:b]) for k, v in out.items()}
+    sq = np.concatenate([np.full(nx, cfg.sigmaQ), np.full(nym, cfg.sigmaQint)]) ** 2
+    res["Qhat"] = np.broadcast_to(np.diag(sq), (B, nxh, nxh)).copy()
+    res["Rhat"] = np.broadcast_to(np.eye(nym) * cfg.sigmaR ** 2, (B, nym, nym)).copy()
+    res["P0"] = np.broadcast_to(np.eye(nxh) * cfg.sigmaP0 ** 2, (B, nxh, nxh)).copy()
+    res["cfg"] = cfg
+    return res
+
+
+def make_mhe_data(cfg: MheConfig, bt, nper: int, seed: int = 0, lo: int = 0):
+    """nper periods of plant data for every estimator of `bt`: Y (nper,B,nym), U (nper,B,nu), D (nper,B,nd)
+    in deviation variables: x+ = A x + Bu u + Bd d + w, y = C x + bias + v with a slowly drifting output bias."""
+    B = bt["A"].shape[0]
+    rng = np.random.default_rng([seed, lo, 55])
+    x = 0.5 * rng.standard_normal((B, cfg.nx))
+    bias = 0.3 * rng.standard_normal((B, cfg.nym))
+    u = 0.5 * rng.standard_normal((B, cfg.nu))
+    Y, U, D = [], [], []
+    for _ in range(nper):
+        d = 0.5 * rng.standard_normal((B, cfg.nd))
+        y = np.einsum("bij,bj->bi", bt["C"], x) + bias + cfg.sigmaR * rng.standard_normal((B, cfg.nym))
+        Y.append(y); U.append(u.copy()); D.append(d)
+        x = (np.einsum("bij,bj->bi", bt["A"], x) + np.einsum("bij,bj->bi", bt["Bu"], u)
+             + np.einsum("bij,bj->bi", bt["Bd"], d) + cfg.sigmaQ * rng.standard_normal((B, cfg.nx)))
+        bias = bias + cfg.sigmaQint * rng.standard_normal((B, cfg.nym))
+        u = 0.9 * u + 0.3 * rng.standard_normal((B, cfg.nu))
+    return np.array(Y), np.array(U), np.array(D)

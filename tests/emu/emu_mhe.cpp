@@ -1,6 +1,11 @@
 // TEST INFRASTRUCTURE ONLY: runs the MovingHorizonEstimator kernel bodies (csrc/mhe_bodies.h) on the
 // CPU, one host thread per lane of a 64-wide "wavefront", wavefronts one after the other.
+#include <algorithm>
+#include <atomic>
 #include <barrier>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -13,7 +18,7 @@ namespace mhe {
 struct EmuShared {
     std::barrier<> bar{WAVE};
     double xd[2][WAVE];
-    int xi[2][WAVE];
+    unsigned long calls[WAVE] = {};      // cross-lane operations of every lane (MPCQP_EMU_WATCHDOG)
 };
 
 // every cross-lane operation writes buffer (n % 2) of its n-th call, waits once, reads: a lane can
@@ -27,6 +32,7 @@ struct EmuWave {
     double* xchg(double v) {
         double* buf = sh->xd[n++ & 1];
         buf[lane] = v;
+        ++sh->calls[lane];
         sh->bar.arrive_and_wait();
         return buf;
     }
@@ -55,6 +61,24 @@ static void run_waves(int nwaves, size_t lds_doubles, F body) {
     std::vector<double> smem(lds_doubles + 16, 0.0);
     EmuShared sh;
     std::vector<std::thread> th;
+    std::atomic<bool> stop{false};
+    std::thread dog;
+    if (getenv("MPCQP_EMU_WATCHDOG"))      // lanes that stopped agreeing on the number of cross-lane operations
+        dog = std::thread([&] {
+            unsigned long last = 0;
+            while (!stop) {
+                std::this_thread::sleep_for(std::chrono::seconds(3));
+                unsigned long mn = ~0ul, mx = 0;
+                for (int i = 0; i < WAVE; ++i) { mn = std::min(mn, sh.calls[i]); mx = std::max(mx, sh.calls[i]); }
+                if (mx == last && mx != mn) {
+                    fprintf(stderr, "[emu watchdog] lanes disagree:");
+                    for (int i = 0; i < WAVE; ++i) fprintf(stderr, " %lu", sh.calls[i]);
+                    fprintf(stderr, "\n");
+                }
+                if (getenv("MPCQP_EMU_WATCHDOG")[0] == '2') fprintf(stderr, "[emu watchdog] %lu..%lu cross-lane ops\n", mn, mx);
+                last = mx;
+            }
+        });
     for (int lane = 0; lane < WAVE; ++lane)
         th.emplace_back([&, lane] {
             EmuWave w{lane, &sh};
@@ -64,6 +88,8 @@ static void run_waves(int nwaves, size_t lds_doubles, F body) {
             }
         });
     for (auto& t : th) t.join();
+    stop = true;
+    if (dog.joinable()) dog.join();
 }
 
 #define MHE_DISPATCH(NXV, CALL)                          \

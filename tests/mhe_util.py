@@ -1,0 +1,84 @@
+"""Shared helpers of the MovingHorizonEstimator parity tests: the same seeded batch through the product
+(BatchMHE over the C-ABI) and through oracle/mhe.py, estimator by estimator."""
+import numpy as np
+
+import mpcqp
+from mpcqp import mhe as pm
+from mpcqp import synth
+from oracle import estim as es
+from oracle import mhe as om
+
+
+def bounds_of(cfg):
+    b = {}
+    if np.isfinite(cfg.xabs):
+        b.update(xhatmin=np.full(cfg.nxh, -cfg.xabs), xhatmax=np.full(cfg.nxh, cfg.xabs))
+    if np.isfinite(cfg.wabs):
+        b.update(whatmin=np.full(cfg.nxh, -cfg.wabs), whatmax=np.full(cfg.nxh, cfg.wabs))
+    if np.isfinite(cfg.vabs):
+        b.update(vhatmin=np.full(cfg.nym, -cfg.vabs), vhatmax=np.full(cfg.nym, cfg.vabs))
+    return b
+
+
+PRODUCT_KEYS = {"xhatmin": "x̂min", "xhatmax": "x̂max", "whatmin": "ŵmin", "whatmax": "ŵmax", "vhatmin": "v̂min",
+                "vhatmax": "v̂max"}
+
+
+def make_product(cfg, bt, lib=None, bounds=None, **kw):
+    nd = cfg.nd
+    bm = pm.BatchMHE(bt["Ahat"], bt["Bhu"], bt["Chm"], bt["Bhd"] if nd else None, bt["Dhdm"] if nd else None,
+                     He=cfg.He, Q̂=bt["Qhat"], R̂=bt["Rhat"], P̂_0=bt["P0"], direct=cfg.direct, lib=lib, **kw)
+    bounds = bounds_of(cfg) if bounds is None else bounds
+    if bounds:
+        bm.setconstraint(**{PRODUCT_KEYS[k]: v for k, v in bounds.items()})
+    return bm
+
+
+def make_oracles(cfg, bt, members, bounds=None):
+    """One MHEOracle per listed member, on the plant + output integrators the batch was built from."""
+    bounds = bounds_of(cfg) if bounds is None else bounds
+    out = []
+    for b in members:
+        model = es.LinModelOracle(bt["A"][b], bt["Bu"][b], bt["C"][b], bt["Bd"][b] if cfg.nd else None,
+                                  np.zeros((cfg.nym, cfg.nd)) if cfg.nd else None)
+        e = om.MHEOracle(model, He=cfg.He, direct=cfg.direct, sigmaQ=np.full(cfg.nx, cfg.sigmaQ),
+                         sigmaR=np.full(cfg.nym, cfg.sigmaR), sigmaQint_ym=np.full(cfg.nym, cfg.sigmaQint),
+                         sigmaP_0=np.full(cfg.nx, cfg.sigmaP0), sigmaPint_ym_0=np.full(cfg.nym, cfg.sigmaP0),
+                         nint_ym=[1] * cfg.nym)
+        assert np.allclose(e.Ah, bt["Ahat"][b]) and np.allclose(e.Chm, bt["Chm"][b]) and np.allclose(e.Q, bt["Qhat"][b])
+        if bounds:
+            e.setconstraint(**bounds)
+        out.append(e)
+    return out
+
+
+def run_periods(cfg, bt, nper, members, lib=None, seed=0, bounds=None):
+    """Drive product and oracles through nper periods of the same data.  Returns per period the worst
+    |x̂ - x̂_oracle|, |Ŵ - Ŵ_oracle|, |P̄ - P̄_oracle| over `members`, and the product's statuses."""
+    Y, U, D = synth.make_mhe_data(cfg, bt, nper, seed=seed)
+    bm = make_product(cfg, bt, lib=lib, bounds=bounds)
+    ors = make_oracles(cfg, bt, members, bounds=bounds)
+    nxh = cfg.nxh
+    rows = []
+    for k in range(nper):
+        y, u, d = Y[k], U[k], (D[k] if cfg.nd else None)
+        xg = bm.preparestate(y, d)
+        xo = np.array([e.preparestate(y[b], d[b] if cfg.nd else ()) for e, b in zip(ors, members)])
+        if not cfg.direct:
+            xg = bm.updatestate(u, y, d)
+            xo = np.array([e.updatestate(u[b], y[b], d[b] if cfg.nd else ()) for e, b in zip(ors, members)])
+        info = bm.getinfo()
+        Nk = info["Nk"]
+        Wo = np.array([e.Zt[nxh:nxh + Nk * nxh] for e in ors])
+        ex = np.abs(xg[members] - xo).max()
+        ew = np.abs(info["Ŵ"][members] - Wo).max()
+        scale = max(1.0, np.abs(xo).max())
+        if cfg.direct:
+            bm.updatestate(u, y, d)
+            for e, b in zip(ors, members):
+                e.updatestate(u[b], y[b], d[b] if cfg.nd else ())
+        Po = np.array([e.Parr_old for e in ors])
+        ep = np.abs(bm.handle.get(pm.GET_PBAR)[members] - Po).max() / max(1.0, np.abs(Po).max())
+        rows.append(dict(k=k, Nk=Nk, ex=ex / scale, ew=ew / scale, ep=ep, status=info["status"].copy(),
+                         iters=info["iters"].copy(), ostatus=[e.status for e in ors]))
+    return rows, bm
