@@ -1,0 +1,117 @@
+"""CPU-side checks of the batched linear MovingHorizonEstimator: the HIP library
+exports every symbol include/mpcqp_mhe.h declares, the header is plain C, the host mirror validates
+arguments like the reference, and the kernel bodies (csrc/mhe_bodies.h), run on the CPU wave emulator of
+tests/emu, reproduce oracle/mhe.py -- window bookkeeping, arrival covariance, both forms, every bound
+class.  The GPU parity tests are in test_gpu_mhe.py."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import mpcqp
+from mpcqp import mhe as pm
+from mpcqp import synth
+from tests import mhe_util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emulib():
+    d = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", d])
+    return mpcqp.api.load_library(os.path.join(d, "libmpcqp_emu.so"))
+
+
+def test_library_exports_every_declared_mhe_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mpcqp_mhe.h")).read()
+    declared = set(re.findall(r"\b(mpcqp_mhe_[a-z_]+)\s*\(", hdr))
+    assert declared == set(pm.EXPORTS)
+    lib = ctypes.CDLL(mpcqp.DEFAULT_LIB)          # fails loudly if the HIP build is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.run(["strings", "-a", mpcqp.DEFAULT_LIB], capture_output=True, text=True).stdout
+    assert "k_mhe_step" in out
+
+
+def test_mhe_header_is_plain_c(tmp_path):
+    exe = str(tmp_path / "abi_mhe_client")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_mhe_client.c"), "-o", exe,
+                           "-L", os.path.dirname(mpcqp.DEFAULT_LIB), "-lmpcqp",
+                           "-Wl,-rpath," + os.path.dirname(mpcqp.DEFAULT_LIB)])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "15 mhe entry points" in out.stdout, out.stdout + out.stderr
+
+
+def _tiny(**kw):
+    base = dict(nx=2, nu=2, nym=2, nd=0, He=3)
+    base.update(kw)
+    return synth.MheConfig("tiny", **base)
+
+
+def test_batchmhe_argument_checks(emulib):
+    cfg = _tiny()
+    bt = synth.make_mhe_batch(cfg, 2, seed=0)
+    args = (bt["Ahat"], bt["Bhu"], bt["Chm"])
+    with pytest.raises(ValueError, match="He"):
+        pm.BatchMHE(*args, He=0, lib=emulib)
+    with pytest.raises(mpcqp.MpcqpError, match="Cwt"):
+        pm.BatchMHE(*args, He=3, Cwt=1e5, lib=emulib)
+    with pytest.raises(ValueError, match="inconsistent"):
+        pm.BatchMHE(bt["Ahat"], bt["Bhu"][:, :3], bt["Chm"], He=3, lib=emulib)
+    bm = pm.BatchMHE(*args, He=3, lib=emulib)
+    with pytest.raises(ValueError, match="size"):
+        bm.setconstraint(x̂min=[0.0, 0.0])                       # nx̂ = 4
+    with pytest.raises(ValueError, match="infeasible"):
+        bm.setconstraint(x̂min=np.ones(4), x̂max=np.zeros(4))
+    with pytest.raises(mpcqp.MpcqpError, match="soft"):
+        bm.setconstraint(c_x̂min=np.ones(4))
+    with pytest.raises(mpcqp.MpcqpError, match="window-long"):
+        bm.setconstraint(X̂min=np.zeros(16))
+    with pytest.raises(ValueError, match="ym size"):
+        bm.preparestate(np.zeros(3))
+    # more than 16 augmented states: one estimator no longer fits a DPP row
+    big = synth.make_mhe_batch(_tiny(nx=15), 1, seed=0)
+    with pytest.raises(mpcqp.MpcqpError, match="not supported"):
+        pm.BatchMHE(big["Ahat"], big["Bhu"], big["Chm"], He=3, lib=emulib)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("direct", [True, False])
+def test_unconstrained_mhe_on_emulator_matches_oracle(emulib, direct):
+    """No finite bound: one Newton step; growing then moving window, arrival covariance updates, nd > 0.
+    (The oracle itself is pinned on MHE == KalmanFilter, tests/test_oracle_mhe.py.)"""
+    cfg = _tiny(nd=1, direct=direct)
+    bt = synth.make_mhe_batch(cfg, 6, seed=3)              # 6 estimators: a partly filled second wavefront
+    rows, bm = mhe_util.run_periods(cfg, bt, 6, [0, 3, 5], lib=emulib, bounds={})
+    for r in rows:
+        assert np.all(r["status"] == 0) and r["ex"] <= 1e-12 and r["ew"] <= 1e-12 and r["ep"] <= 1e-13, r
+    assert rows[-1]["Nk"] == cfg.He
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("kw", [dict(xabs=0.8), dict(wabs=0.25), dict(vabs=0.3), dict(xabs=1.0, vabs=0.5, direct=False)],
+                         ids=["xhat", "what", "vhat", "xhat+vhat predictor form"])
+def test_constrained_mhe_on_emulator_matches_oracle(emulib, kw):
+    cfg = _tiny(**kw)
+    bt = synth.make_mhe_batch(cfg, 5, seed=4)
+    rows, bm = mhe_util.run_periods(cfg, bt, 5, [0, 2, 4], lib=emulib)
+    active = 0
+    for r in rows:
+        assert r["ostatus"] == [0, 0, 0]
+        assert np.all(r["status"] == 0), r
+        assert r["ex"] <= 1e-7 and r["ew"] <= 1e-7 and r["ep"] <= 1e-13, r      # interior point vs exact active set
+        active += int(r["iters"].max() > 0)
+    assert active == len(rows)                              # every period needed interior-point iterations
+    info = bm.getinfo()
+    tol = 1e-7
+    if np.isfinite(cfg.xabs):
+        assert np.abs(info["X̂"]).max() <= cfg.xabs + tol and np.abs(info["x̂arr"]).max() <= cfg.xabs + tol
+    if np.isfinite(cfg.wabs):
+        assert np.abs(info["Ŵ"]).max() <= cfg.wabs + tol
+    if np.isfinite(cfg.vabs):
+        assert np.abs(info["V̂"]).max() <= cfg.vabs + tol
