@@ -16,6 +16,9 @@ Workload (BASELINE.json):
 After the timed region the ranks gather status and first moves of the whole batch with ONE all_gather
 each over RCCL (the scatter/gather of the north star; it is outside the step).
 
+`--config C5` runs BASELINE configs[4] instead (linear MovingHorizonEstimator, one estimator period per
+step): see bench_mhe.py.
+
 Prints ONE JSON line (rank 0) with `roofline` (FP64 flops of the dominant kernel k_step against the
 chip's FP64 peak, kernel time from HIP events on the launch stream) and `cpu_baseline` (the oracle's C
 port on the host cores, bounded sample, rank 0 at N = 1 only).
@@ -157,6 +160,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    if args.config in synth.MHE_CONFIGS or args.config.startswith("mhe:"):
+        # the linear MovingHorizonEstimator (BASELINE configs[4]) -- bench_mhe.py
+        import bench_mhe
+        args.config = args.config[4:] if args.config.startswith("mhe:") else args.config
+        bench_mhe.run(args, rank, world, local, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     cfg = synth.get_config(args.config)
     PER_GPU = 65536
     GLOBAL4 = 262144
