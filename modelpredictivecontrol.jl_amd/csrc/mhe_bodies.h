@@ -25,6 +25,8 @@
 #pragma once
 #include <math.h>
 
+#include <type_traits>
+
 #include "mhe_types.h"
 
 namespace mpcqp {
@@ -95,6 +97,20 @@ struct Ops {
     }
     MPCQP_HD static void st(double* p, int stride, const Row& M) {
         sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; p[(size_t)c * stride] = M[c]; });
+    }
+    // element `idx` of an array with a wave-uniform base: the byte offset is formed in 32 bits, which lets the
+    // access use the SGPR-base + 32-bit-VGPR-offset form of global_load / global_store (arrays < 4 GB)
+    template <class T>
+    MPCQP_HD static T* at(T* base, int idx) {
+        return (T*)((char*)const_cast<typename std::remove_const<T>::type*>(base) + (uint32_t)((uint32_t)idx * (uint32_t)sizeof(T)));
+    }
+    // the same with a wave-uniform base pointer and a 32-bit per-lane element offset: the address is formed
+    // at the access (SGPR base + VGPR offset) instead of living in a 64-bit register pair per array
+    MPCQP_HD static void ldo(const double* base, int off, int stride, Row& M) {
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] = *at(base, off + c * stride); });
+    }
+    MPCQP_HD static void sto(double* base, int off, int stride, const Row& M) {
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; *at(base, off + c * stride) = M[c]; });
     }
     MPCQP_HD static void add_diag(Row& M, int r, double v) {
         sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] += (r == c) ? v : 0.0; });
@@ -244,7 +260,8 @@ MPCQP_HD inline void row_dir(bool has, double sv, double lv, double rp, double g
 MPCQP_HD inline double ratio(double v, double dv) { return dv < 0.0 ? -v / dv : 1e300; }
 
 // ---------------------------------------------------------------------------------------------
-template <class W, int NX>
+// CM: compile-time set of bound classes the code is generated for (a handle whose classes are a subset runs it)
+template <class W, int NX, unsigned CM = 7u>
 struct Solver {
     using O = Ops<W, NX>;
     using Row = typename O::Row;
@@ -257,8 +274,10 @@ struct Solver {
     const SlotMap sm;
     int b;
     bool live;
-    const double* cst;
-    double* sc;      // this lane's column of the wave scratch
+    const double* cbase;   // constant blocks of this wavefront's first estimator (wave-uniform)
+    int coff;           // this lane's offset into them: (b - first) * stride + r
+    double* sb;      // scratch of this wavefront (wave-uniform base; a slot is 64 doubles, one per lane)
+    int first;       // first estimator of the wavefront's current group of four
     double* lds;     // this lane's column of the wave's LDS: Oc, OcT, Bmid rows
     int N, p;
     bool cX, cW, cV;
@@ -268,13 +287,13 @@ struct Solver {
     MPCQP_HD Solver(W& w_, const Dims& d_, const Args& a_, double* smem, int wave_id)
         : w(w_), d(d_), a(a_), op{w_}, lane(w_.lane), r(w_.lane & (RL - 1)), g(w_.lane >> 4),
           cm(cst_map(NX, d_.nu, d_.nd)), sm(slot_map(NX, d_.He, d_.cls)) {
-        sc = a.scratch + (size_t)wave_id * d.nslot * WAVE + lane;
+        sb = a.scratch + (size_t)wave_id * d.nslot * WAVE;
         lds = smem + lane;
         N = d.N;
         p = d.direct ? 0 : 1;
-        cX = d.cls & CLS_X; cW = d.cls & CLS_W; cV = d.cls & CLS_V;
+        cX = (CM & CLS_X) && (d.cls & CLS_X); cW = (CM & CLS_W) && (d.cls & CLS_W); cV = (CM & CLS_V) && (d.cls & CLS_V);
     }
-    MPCQP_HD double& S(int slot) { return sc[(size_t)slot * WAVE]; }
+    MPCQP_HD double& S(int slot) { return *O::at(sb, slot * WAVE + lane); }
     MPCQP_HD const double* L_Oc() const { return lds; }
     MPCQP_HD const double* L_OcT() const { return lds + (size_t)NX * WAVE; }
     MPCQP_HD const double* L_Bmid() const { return lds + (size_t)2 * NX * WAVE; }
@@ -282,6 +301,17 @@ struct Solver {
     MPCQP_HD int dslot(int i) const { return (d.hd + i) % (d.He + 1); }
     // measurement attached to state s (p = 0: i = s-1, p = 1: i = s), -1: none
     MPCQP_HD int meas_of(int s) const { const int i = s - 1 + p; return (i >= 0 && i < N) ? i : -1; }
+
+    // O(j) = Oc - D̃w(j) Â: sub-diagonal block (j+1, j) of the Newton matrix (D̃w(j) from the forward sweep of phase 0)
+    MPCQP_HD void load_O(int j, Row& Ob) {
+        O::ld(L_Oc(), WAVE, Ob);
+        if (cW) {
+            const double Dp = S(sm.WD + j);
+            Row Ap;
+            O::ldo(cbase, coff + cm.A, RL, Ap);
+            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ob[c] -= Dp * Ap[c]; });
+        }
+    }
 
     // diagonal block of the Hessian at stage s
     MPCQP_HD void base_block(int s, Row& Bs) {
@@ -291,15 +321,15 @@ struct Solver {
         }
         Row T;
         if (s == 0) {
-            O::ld(a.Pi2 + (size_t)b * NX * RL + r, RL, Bs);
-            O::ld(cst + cm.T1, RL, T);
+            O::ldo(a.Pi2 + (size_t)first * NX * RL, (b - first) * NX * RL + r, RL, Bs);
+            O::ldo(cbase, coff + cm.T1, RL, T);
         } else {
             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] = 0.0; });
-            O::ld(cst + cm.T2, RL, T);
+            O::ldo(cbase, coff + cm.T2, RL, T);
         }
         sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] += T[c]; });
         if (meas_of(s) >= 0) {
-            O::ld(cst + cm.T3, RL, T);
+            O::ldo(cbase, coff + cm.T3, RL, T);
             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] += T[c]; });
         }
     }
@@ -320,17 +350,17 @@ struct Solver {
     }
 
     MPCQP_HD double g_of(int j) {      // g(j)[r] = B̂u u0(j) + B̂d d0(j+p) + (f̂op - x̂op)
-        double acc = cst[cm.fx];
+        double acc = *O::at(cbase, coff + cm.fx);
         const double* u = a.U0 + ((size_t)b * d.He + yslot(j)) * d.nu;
-        for (int c = 0; c < d.nu; ++c) acc = fma(cst[cm.Bu + c * RL], u[c], acc);
+        for (int c = 0; c < d.nu; ++c) acc = fma(*O::at(cbase, coff + cm.Bu + c * RL), u[c], acc);
         const double* dd = a.D0 + ((size_t)b * (d.He + 1) + dslot(j + p)) * d.nd;
-        for (int c = 0; c < d.nd; ++c) acc = fma(cst[cm.Bd + c * RL], dd[c], acc);
+        for (int c = 0; c < d.nd; ++c) acc = fma(*O::at(cbase, coff + cm.Bd + c * RL), dd[c], acc);
         return acc;
     }
     MPCQP_HD double e_of(int i) {      // e(i)[r] = y0m(i) - D̂dm d0(i+1)        (lanes r < nym)
         double acc = r < d.nym ? a.Y0m[((size_t)b * d.He + yslot(i)) * d.nym + r] : 0.0;
         const double* dd = a.D0 + ((size_t)b * (d.He + 1) + dslot(i + 1)) * d.nd;
-        for (int c = 0; c < d.nd; ++c) acc = fma(-cst[cm.Ddm + c * RL], dd[c], acc);
+        for (int c = 0; c < d.nd; ++c) acc = fma(-*O::at(cbase, coff + cm.Ddm + c * RL), dd[c], acc);
         return acc;
     }
 
@@ -340,9 +370,9 @@ struct Solver {
         // ---- constants to LDS
         {
             Row T;
-            O::ld(cst + cm.Oc, RL, T); O::st(lds, WAVE, T);
-            O::ld(cst + cm.OcT, RL, T); O::st(lds + (size_t)NX * WAVE, WAVE, T);
-            O::ld(cst + cm.Bmid, RL, T); O::st(lds + (size_t)2 * NX * WAVE, WAVE, T);
+            O::ldo(cbase, coff + cm.Oc, RL, T); O::st(lds, WAVE, T);
+            O::ldo(cbase, coff + cm.OcT, RL, T); O::st(lds + (size_t)NX * WAVE, WAVE, T);
+            O::ldo(cbase, coff + cm.Bmid, RL, T); O::st(lds + (size_t)2 * NX * WAVE, WAVE, T);
         }
         auto bnd = [&](const double* p_, bool on, int n, double dflt) { return (on && p_ && r < n) ? p_[(size_t)b * RL + r] : dflt; };
         xlo = bnd(a.xmin, cX, nx, -BIG); xhi = bnd(a.xmax, cX, nx, BIG);
@@ -363,11 +393,11 @@ struct Solver {
                 if (s < N) S(sm.G + s) = gs;
                 double q = 0.0;
                 if (s == 0) {
-                    O::ld(a.Pi2 + (size_t)b * NX * RL + r, RL, T);
+                    O::ldo(a.Pi2 + (size_t)first * NX * RL, (b - first) * NX * RL + r, RL, T);
                     q -= op.mv(T, xbar);
                 }
                 if (s > 0) {
-                    O::ld(cst + cm.T2, RL, T);
+                    O::ldo(cbase, coff + cm.T2, RL, T);
                     q -= op.mv(T, gprev);
                 }
                 if (s < N) {
@@ -379,7 +409,7 @@ struct Solver {
                 if (i >= 0) {
                     ei = e_of(i);
                     S(sm.E + i) = ei;
-                    O::ld(cst + cm.CR, RL, T);
+                    O::ldo(cbase, coff + cm.CR, RL, T);
                     q -= op.mv(T, ei);
                 }
                 S(sm.Q + s) = q;
@@ -402,7 +432,7 @@ struct Solver {
                     if (hwhi) nh_l = fmax(nh_l, fabs(whi) + 1.0);
                 }
                 if (cV && i >= 0) {
-                    O::ld(cst + cm.Cm, RL, T);
+                    O::ldo(cbase, coff + cm.Cm, RL, T);
                     const double vv = ei - op.mv(T, xc);
                     const double s0 = fmax(vv - vlo, 1.0), s1 = fmax(vhi - vv, 1.0);
                     S(sm.VR + 4 * i + 0) = s0; S(sm.VR + 4 * i + 1) = lam0 / s0;
@@ -414,7 +444,7 @@ struct Solver {
                     // (no v̂ row at this state)
                 }
                 if (s < N) {                 // x(s+1) = Â x(s) + g(s)
-                    O::ld(cst + cm.A, RL, T);
+                    O::ldo(cbase, coff + cm.A, RL, T);
                     xc = op.mv(T, xc) + gs;
                 }
                 gprev = gs;
@@ -467,7 +497,7 @@ struct Solver {
                         }
                         Row A;
                         if (cW && s < N) {
-                            O::ld(cst + cm.A, RL, A);
+                            O::ldo(cbase, coff + cm.A, RL, A);
                             double wv;
                             if (!phase) { wv = xp - op.mv(A, xc) - S(sm.G + s); S(sm.WW + s) = wv; }
                             else wv = S(sm.WW + s);
@@ -486,7 +516,7 @@ struct Solver {
                             Dtw = k0.Dt + k1.Dt;
                             if (!phase) S(sm.WD + s) = Dtw;
                             Row At;
-                            O::ld(cst + cm.At, RL, At);
+                            O::ldo(cbase, coff + cm.At, RL, At);
                             gl -= op.mv(At, lw);
                             cr -= op.mv(At, cw);
                             gl_carry = lw; cr_carry = cw; dd_carry = Dtw;
@@ -499,7 +529,7 @@ struct Solver {
                         double Dtv = 0.0;
                         if (cV && im >= 0) {
                             Row Cm;
-                            O::ld(cst + cm.Cm, RL, Cm);
+                            O::ldo(cbase, coff + cm.Cm, RL, Cm);
                             double vv;
                             if (!phase) { vv = S(sm.E + im) - op.mv(Cm, xc); S(sm.VV + im) = vv; }
                             else vv = S(sm.VV + im);
@@ -518,7 +548,7 @@ struct Solver {
                             Dtv = k0.Dt + k1.Dt;
                             if (!phase) S(sm.VD + im) = Dtv;
                             Row Ct;
-                            O::ld(cst + cm.Ct, RL, Ct);
+                            O::ldo(cbase, coff + cm.Ct, RL, Ct);
                             gl -= op.mv(Ct, lv);            // v̂ = e - Ĉm x: the rows' gradient is -Ĉm'
                             cr -= op.mv(Ct, cv);
                             if (!phase) {
@@ -541,12 +571,19 @@ struct Solver {
                             rd = S(sm.RD + s);
                         }
                         const double rhs = -rd + cr;
+                        MPCQP_SCHED_FENCE();
+                        // ---- O(s-1) = Oc - D̃w(s-1) Â (re-materialised from LDS: not carried in registers)
+                        double otp = 0.0;
+                        if (s > 0) {
+                            load_O(s - 1, Oprev);
+                            otp = op.mv(Oprev, tprev);
+                        }
                         // ---- S(s) = Φ(s,s) - O(s-1) Si(s-1) O(s-1)'
                         if (!phase) {
                             O::add_diag(Bs, r, dd);
                             if (cW && s < N) {            // + Â' D̃w Â
                                 Row At;
-                                O::ld(cst + cm.At, RL, At);
+                                O::ldo(cbase, coff + cm.At, RL, At);
                                 sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; U[c] = Dtw * A[c]; });
                                 sfor<NX>([&](auto ic) {
                                     constexpr int c = decltype(ic)::v;
@@ -557,8 +594,8 @@ struct Solver {
                             }
                             if (cV && im >= 0) {          // + Ĉm' D̃v Ĉm
                                 Row Cm, Ct;
-                                O::ld(cst + cm.Cm, RL, Cm);
-                                O::ld(cst + cm.Ct, RL, Ct);
+                                O::ldo(cbase, coff + cm.Cm, RL, Cm);
+                                O::ldo(cbase, coff + cm.Ct, RL, Ct);
                                 sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; U[c] = Dtv * Cm[c]; });
                                 sfor<NX>([&](auto ic) {
                                     constexpr int c = decltype(ic)::v;
@@ -569,31 +606,20 @@ struct Solver {
                             }
                             if (s > 0) {
                                 op.mm(Oprev, Si, U);
+                                MPCQP_SCHED_FENCE();
                                 op.mmt_acc(U, Oprev, Bs, -1.0);
+                                MPCQP_SCHED_FENCE();
                             }
                             ok = op.gj(Bs, r) && ok;
                             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Si[c] = Bs[c]; });
-                            O::st(&S(sm.SI + s * NX), WAVE, Si);
+                            O::sto(sb, (sm.SI + s * NX) * WAVE + lane, WAVE, Si);
                         } else {
-                            if (s > 0) {                   // O(s-1) of this sweep (the previous Si is not needed)
-                                O::ld(L_Oc(), WAVE, Oprev);
-                                if (cW) {
-                                    const double Dp = S(sm.WD + s - 1);
-                                    Row Ap;
-                                    O::ld(cst + cm.A, RL, Ap);
-                                    sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Oprev[c] -= Dp * Ap[c]; });
-                                }
-                            }
-                            O::ld(&S(sm.SI + s * NX), WAVE, Si);
+                            O::ldo(sb, (sm.SI + s * NX) * WAVE + lane, WAVE, Si);
                         }
-                        const double bt = rhs - (s > 0 ? op.mv(Oprev, tprev) : 0.0);
-                        const double t = op.mv(Si, bt);
+                        const double t = op.mv(Si, rhs - otp);
                         S(sm.T + s) = t;
                         tprev = t;
-                        if (!phase && s < N) {             // O(s) = Oc - D̃w Â for the next stage
-                            O::ld(L_Oc(), WAVE, Oprev);
-                            if (cW) sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Oprev[c] -= Dtw * A[c]; });
-                        }
+                        MPCQP_SCHED_FENCE();
                         xm = xc; xc = xp;
                         dxam = dxac; dxac = dxap;
                     }
@@ -626,14 +652,14 @@ struct Solver {
                     double dxn = 0.0;
                     const int sDX = phase ? sm.DX : sm.DXA;
                     for (int s = N; s >= 0; --s) {
-                        O::ld(&S(sm.SI + s * NX), WAVE, Si);
+                        O::ldo(sb, (sm.SI + s * NX) * WAVE + lane, WAVE, Si);
                         double dx = S(sm.T + s);
                         if (s < N) {
                             O::ld(L_OcT(), WAVE, U);
                             double u = op.mv(U, dxn);
                             if (cW) {
                                 Row At;
-                                O::ld(cst + cm.At, RL, At);
+                                O::ldo(cbase, coff + cm.At, RL, At);
                                 u -= op.mv(At, S(sm.WD + s) * dxn);
                             }
                             dx -= op.mv(Si, u);
@@ -657,7 +683,7 @@ struct Solver {
                         }
                         if (cW && s < N) {
                             Row A;
-                            O::ld(cst + cm.A, RL, A);
+                            O::ldo(cbase, coff + cm.A, RL, A);
                             const double gd = dxn - op.mv(A, dx);
                             S((phase ? sm.WG : sm.WGA) + s) = gd;
                             const double wv = S(sm.WW + s);
@@ -678,7 +704,7 @@ struct Solver {
                         const int im = meas_of(s);
                         if (cV && im >= 0) {
                             Row Cm;
-                            O::ld(cst + cm.Cm, RL, Cm);
+                            O::ldo(cbase, coff + cm.Cm, RL, Cm);
                             const double gd = -op.mv(Cm, dx);
                             S((phase ? sm.VG : sm.VGA) + im) = gd;
                             const double vv = S(sm.VV + im);
@@ -809,8 +835,8 @@ struct Solver {
     MPCQP_HD void write_outputs(int st, int it, double xbar) {
         const int nx = d.nx, nym = d.nym, He = d.He;
         Row A, Cm;
-        O::ld(cst + cm.A, RL, A);
-        O::ld(cst + cm.Cm, RL, Cm);
+        O::ldo(cbase, coff + cm.A, RL, A);
+        O::ldo(cbase, coff + cm.Cm, RL, Cm);
         const bool bad = st == 2;
         // a failed solve keeps the open-loop window: x(0) = x̄, ŵ = 0 (the starting point)
         double xc = bad ? xbar : S(sm.X + 0);
@@ -850,15 +876,17 @@ struct Solver {
     }
 };
 
-template <class W, int NX>
+template <class W, int NX, unsigned CM = 7u>
 MPCQP_HD void step_body(W& w, const Dims& d, const Args& a, int wave_id, double* smem) {
-    Solver<W, NX> sv(w, d, a, smem, wave_id);
+    Solver<W, NX, CM> sv(w, d, a, smem, wave_id);
     const CstMap cm = cst_map(NX, d.nu, d.nd);
     for (int wg = wave_id; wg * GPW < d.B; wg += d.nwaves) {
         const int bq = wg * GPW + sv.g;
         sv.live = bq < d.B;
         sv.b = sv.live ? bq : d.B - 1;
-        sv.cst = a.cst + (size_t)sv.b * cm.stride + sv.r;
+        sv.first = wg * GPW;
+        sv.cbase = a.cst + (size_t)sv.first * cm.stride;
+        sv.coff = (sv.b - sv.first) * cm.stride + sv.r;
         sv.run();
         w.sync();
     }

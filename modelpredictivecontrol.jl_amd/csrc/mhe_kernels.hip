@@ -21,10 +21,14 @@ __global__ __launch_bounds__(64) void k_mhe_cov(Dims d, Args a, int mode, const 
     MheDevWave w{(int)threadIdx.x};
     cov_body<MheDevWave, NX>(w, d, a, mode, P0, Pout, (int)blockIdx.x);
 }
-template <int NX>
-__global__ __launch_bounds__(64) void k_mhe_step(Dims d, Args a) {
+#ifndef MPCQP_MHE_WAVES
+#define MPCQP_MHE_WAVES 2       // register budget of the step kernel, in waves per SIMD
+#endif
+// CM = 1: x̂ bounds only (or none) -- the common case, without the code and registers of the ŵ / v̂ rows
+template <int NX, unsigned CM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_MHE_WAVES, 8))) void k_mhe_step(Dims d, Args a) {
     MheDevWave w{(int)threadIdx.x};
-    step_body<MheDevWave, NX>(w, d, a, (int)blockIdx.x, mpcqp_smem);
+    step_body<MheDevWave, NX, CM>(w, d, a, (int)blockIdx.x, mpcqp_smem);
 }
 
 #define MHE_DISPATCH(NXV, CALL)                 \
@@ -46,7 +50,11 @@ hipError_t launch_cov(const Dims& d, const Args& a, int mode, const double* P0, 
 }
 hipError_t launch_step(const Dims& d, const Args& a, hipStream_t st) {
     const size_t lds = step_lds_doubles(d.NX) * sizeof(double);
-    MHE_DISPATCH(d.NX, hipLaunchKernelGGL(k_mhe_step<NX>, dim3(d.nwaves), dim3(WAVE), lds, st, d, a));
+    if ((d.cls & ~CLS_X) == 0) {
+        MHE_DISPATCH(d.NX, hipLaunchKernelGGL((k_mhe_step<NX, 1u>), dim3(d.nwaves), dim3(WAVE), lds, st, d, a));
+    } else {
+        MHE_DISPATCH(d.NX, hipLaunchKernelGGL((k_mhe_step<NX, 7u>), dim3(d.nwaves), dim3(WAVE), lds, st, d, a));
+    }
     return hipGetLastError();
 }
 
