@@ -48,16 +48,24 @@ struct Ops {
     W& w;
     using Row = double[NX];
 
+    // w.fmabc4<L0,L1,L2,L3>(acc, x0..x3, y0..y3): acc += sum_i (x_i of lane L_i of this row) * y_i -- four
+    // v_fmac_f64_dpp on gfx950 (the row broadcast is the DPP modifier of the multiply-add itself)
     MPCQP_HD double mv(const Row& M, double v) const {            // (M v)[r]
         double acc = 0.0;
-        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; acc = fma(M[c], w.template rowbc<c>(v), acc); });
+        sfor<NX / 4>([&](auto ij) {
+            constexpr int c = 4 * decltype(ij)::v;
+            w.template fmabc4<c, c + 1, c + 2, c + 3>(acc, v, v, v, v, M[c], M[c + 1], M[c + 2], M[c + 3]);
+        });
         return acc;
     }
     MPCQP_HD void mm(const Row& X, const Row& Y, Row& C) const {  // C = X Y
         sfor<NX>([&](auto ic) {
             constexpr int c = decltype(ic)::v;
             double acc = 0.0;
-            sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(X[k], w.template rowbc<k>(Y[c]), acc); });
+            sfor<NX / 4>([&](auto ij) {
+                constexpr int k = 4 * decltype(ij)::v;
+                w.template fmabc4<k, k + 1, k + 2, k + 3>(acc, Y[c], Y[c], Y[c], Y[c], X[k], X[k + 1], X[k + 2], X[k + 3]);
+            });
             C[c] = acc;
         });
     }
@@ -65,7 +73,10 @@ struct Ops {
         sfor<NX>([&](auto ic) {
             constexpr int c = decltype(ic)::v;
             double acc = 0.0;
-            sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(X[k], w.template rowbc<c>(Y[k]), acc); });
+            sfor<NX / 4>([&](auto ij) {
+                constexpr int k = 4 * decltype(ij)::v;
+                w.template fmabc4<c, c, c, c>(acc, Y[k], Y[k + 1], Y[k + 2], Y[k + 3], X[k], X[k + 1], X[k + 2], X[k + 3]);
+            });
             C[c] = fma(sign, acc, C[c]);
         });
     }
@@ -79,16 +90,16 @@ struct Ops {
             ok = ok && (dk > 1e-280) && (dk < 1e280);
             const double pinv = 1.0 / dk;
             const bool piv = (r == k);
-            const double f = piv ? -1.0 : a[k];      // pivot row: a[c] <- a[c]/dk  ==  0*a[c] + 1*rk
+            // a[c] <- m a[c] + g (a[c] of lane k):  pivot row (m = 0, g = 1/dk): a[c]/dk;  other rows (m = 1,
+            // g = -a[k]/dk): a[c] - a[k] a_k[c] / dk
+            const double g = piv ? pinv : -a[k] * pinv;
             const double m = piv ? 0.0 : 1.0;
-            sfor<NX>([&](auto ic) {
-                constexpr int c = decltype(ic)::v;
-                if constexpr (c != k) {
-                    const double rk = w.template rowbc<k>(a[c]) * pinv;
-                    a[c] = fma(-f, rk, a[c] * m);
-                }
+            // (column k is computed too and then replaced: the four-element groups stay uniform)
+            sfor<NX / 4>([&](auto ij) {
+                constexpr int c = 4 * decltype(ij)::v;
+                w.template gjrow4<k>(a[c], a[c + 1], a[c + 2], a[c + 3], m, g);
             });
-            a[k] = piv ? pinv : -f * pinv;
+            a[k] = g;
         });
         return ok;
     }
@@ -588,7 +599,7 @@ struct Solver {
                                 sfor<NX>([&](auto ic) {
                                     constexpr int c = decltype(ic)::v;
                                     double acc = 0.0;
-                                    sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(At[k], w.template rowbc<k>(U[c]), acc); });
+                                    sfor<NX / 4>([&](auto ij) { constexpr int k = 4 * decltype(ij)::v; w.template fmabc4<k, k + 1, k + 2, k + 3>(acc, U[c], U[c], U[c], U[c], At[k], At[k + 1], At[k + 2], At[k + 3]); });
                                     Bs[c] += acc;
                                 });
                             }
@@ -600,7 +611,7 @@ struct Solver {
                                 sfor<NX>([&](auto ic) {
                                     constexpr int c = decltype(ic)::v;
                                     double acc = 0.0;
-                                    sfor<NX>([&](auto ik) { constexpr int k = decltype(ik)::v; acc = fma(Ct[k], w.template rowbc<k>(U[c]), acc); });
+                                    sfor<NX / 4>([&](auto ij) { constexpr int k = 4 * decltype(ij)::v; w.template fmabc4<k, k + 1, k + 2, k + 3>(acc, U[c], U[c], U[c], U[c], Ct[k], Ct[k + 1], Ct[k + 2], Ct[k + 3]); });
                                     Bs[c] += acc;
                                 });
                             }

@@ -13,6 +13,38 @@ struct MheDevWave : DevWave {
     __device__ __forceinline__ double rowbc(double v) const {
         return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + C, 0xf, 0xf, true);
     }
+    // acc += sum_i (x_i of lane L_i of this lane's row) * y_i: the broadcast is the DPP modifier of the
+    // multiply-add itself.  One asm block per four terms: the hardware does not interlock a DPP read of a
+    // VGPR that a VALU instruction wrote within the previous two wait states, and the compiler's hazard
+    // recogniser does not see inside inline asm -- the leading s_nop covers every source of the block (none
+    // of them is written inside it).
+    template <int L0, int L1, int L2, int L3>
+    __device__ __forceinline__ void fmabc4(double& acc, double x0, double x1, double x2, double x3, double y0, double y1,
+                                           double y2, double y3) const {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc)
+            : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
+    }
+    // Gauss-Jordan row update of four elements: a_i <- m a_i + g (a_i of lane K)
+    template <int K>
+    __device__ __forceinline__ void gjrow4(double& a0, double& a1, double& a2, double& a3, double m, double g) const {
+        double t0, t1, t2, t3;
+        asm("v_mul_f64 %0, %4, %8\n\t"
+            "v_mul_f64 %1, %5, %8\n\t"
+            "v_mul_f64 %2, %6, %8\n\t"
+            "v_mul_f64 %3, %7, %8\n\t"
+            "v_fmac_f64_dpp %0, %4, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %5, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %6, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %3, %7, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(m), "v"(g), "n"(K));
+        a0 = t0; a1 = t1; a2 = t2; a3 = t3;
+    }
     template <class Op>
     static __device__ __forceinline__ double rowred(double v, Op op) {
         v = op(v, dpp<0xB1>(v));     // quad_perm [1,0,3,2]
