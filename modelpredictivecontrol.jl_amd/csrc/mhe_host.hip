@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -126,6 +127,7 @@ int mpcqp_mhe_create(const mpcqp_mhe_dims* in, mpcqp_mhe* out) {
     d.dual_reg = in->dual_reg > 0 ? in->dual_reg : 1e-12;
     d.nwaves = mhe::waves_for(in->device, d.B, d.NX);
     d.cst_stride = mhe::cst_map(d.NX, d.nu, d.nd).stride;
+    d.opt = getenv("MPCQP_MHE_OPT") ? (uint32_t)atoi(getenv("MPCQP_MHE_OPT")) : 0u;
     h->device = in->device;
     h->flags = in->flags;
     int rc = MPCQP_OK;

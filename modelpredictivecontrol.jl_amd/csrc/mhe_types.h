@@ -34,6 +34,7 @@ struct Dims {
     int nwaves;        // wavefronts launched (each loops over groups of four estimators)
     int nslot;         // 64-double slots of scratch per wavefront
     int cst_stride;    // doubles per estimator in the constant block
+    uint32_t opt;      // experiment switches (MPCQP_MHE_OPT), 0 in production
 };
 
 // offsets (doubles) inside one estimator's constant block; a matrix is a "row-lane" array:
