@@ -29,6 +29,10 @@
 
 #include "mhe_types.h"
 
+#ifndef MPCQP_MHE_BMID_LDS
+#define MPCQP_MHE_BMID_LDS 1     // middle diagonal block of the Hessian in LDS (18 KB per wave) or read from the constant block (12 KB)
+#endif
+
 namespace mpcqp {
 namespace mhe {
 
@@ -118,10 +122,10 @@ struct Ops {
     // the same with a wave-uniform base pointer and a 32-bit per-lane element offset: the address is formed
     // at the access (SGPR base + VGPR offset) instead of living in a 64-bit register pair per array
     MPCQP_HD static void ldo(const double* base, int off, int stride, Row& M) {
-        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] = *at(base, off + c * stride); });
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] = at(base, off)[c * stride]; });
     }
     MPCQP_HD static void sto(double* base, int off, int stride, const Row& M) {
-        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; *at(base, off + c * stride) = M[c]; });
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; at(base, off)[c * stride] = M[c]; });
     }
     MPCQP_HD static void add_diag(Row& M, int r, double v) {
         sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] += (r == c) ? v : 0.0; });
@@ -304,7 +308,7 @@ struct Solver {
         p = d.direct ? 0 : 1;
         cX = (CM & CLS_X) && (d.cls & CLS_X); cW = (CM & CLS_W) && (d.cls & CLS_W); cV = (CM & CLS_V) && (d.cls & CLS_V);
     }
-    MPCQP_HD double& S(int slot) { return *O::at(sb, slot * WAVE + lane); }
+    MPCQP_HD double& S(int slot) { return *O::at(w.uniform(sb + (size_t)slot * WAVE), lane); }
     MPCQP_HD const double* L_Oc() const { return lds; }
     MPCQP_HD const double* L_OcT() const { return lds + (size_t)NX * WAVE; }
     MPCQP_HD const double* L_Bmid() const { return lds + (size_t)2 * NX * WAVE; }
@@ -319,7 +323,7 @@ struct Solver {
         if (cW) {
             const double Dp = S(sm.WD + j);
             Row Ap;
-            O::ldo(cbase, coff + cm.A, RL, Ap);
+            O::ldo(w.uniform(cbase + cm.A), coff, RL, Ap);
             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ob[c] -= Dp * Ap[c]; });
         }
     }
@@ -327,20 +331,24 @@ struct Solver {
     // diagonal block of the Hessian at stage s
     MPCQP_HD void base_block(int s, Row& Bs) {
         if (s > 0 && s < N) {
+#if MPCQP_MHE_BMID_LDS
             O::ld(L_Bmid(), WAVE, Bs);
+#else
+            O::ldo(w.uniform(cbase + cm.Bmid), coff, RL, Bs);      // once per stage and iteration: not worth LDS
+#endif
             return;
         }
         Row T;
         if (s == 0) {
             O::ldo(a.Pi2 + (size_t)first * NX * RL, (b - first) * NX * RL + r, RL, Bs);
-            O::ldo(cbase, coff + cm.T1, RL, T);
+            O::ldo(w.uniform(cbase + cm.T1), coff, RL, T);
         } else {
             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] = 0.0; });
-            O::ldo(cbase, coff + cm.T2, RL, T);
+            O::ldo(w.uniform(cbase + cm.T2), coff, RL, T);
         }
         sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] += T[c]; });
         if (meas_of(s) >= 0) {
-            O::ldo(cbase, coff + cm.T3, RL, T);
+            O::ldo(w.uniform(cbase + cm.T3), coff, RL, T);
             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Bs[c] += T[c]; });
         }
     }
@@ -361,17 +369,17 @@ struct Solver {
     }
 
     MPCQP_HD double g_of(int j) {      // g(j)[r] = B̂u u0(j) + B̂d d0(j+p) + (f̂op - x̂op)
-        double acc = *O::at(cbase, coff + cm.fx);
+        double acc = *O::at(cbase + cm.fx, coff);
         const double* u = a.U0 + ((size_t)b * d.He + yslot(j)) * d.nu;
-        for (int c = 0; c < d.nu; ++c) acc = fma(*O::at(cbase, coff + cm.Bu + c * RL), u[c], acc);
+        for (int c = 0; c < d.nu; ++c) acc = fma(O::at(cbase + cm.Bu, coff)[c * RL], u[c], acc);
         const double* dd = a.D0 + ((size_t)b * (d.He + 1) + dslot(j + p)) * d.nd;
-        for (int c = 0; c < d.nd; ++c) acc = fma(*O::at(cbase, coff + cm.Bd + c * RL), dd[c], acc);
+        for (int c = 0; c < d.nd; ++c) acc = fma(O::at(cbase + cm.Bd, coff)[c * RL], dd[c], acc);
         return acc;
     }
     MPCQP_HD double e_of(int i) {      // e(i)[r] = y0m(i) - D̂dm d0(i+1)        (lanes r < nym)
         double acc = r < d.nym ? a.Y0m[((size_t)b * d.He + yslot(i)) * d.nym + r] : 0.0;
         const double* dd = a.D0 + ((size_t)b * (d.He + 1) + dslot(i + 1)) * d.nd;
-        for (int c = 0; c < d.nd; ++c) acc = fma(-*O::at(cbase, coff + cm.Ddm + c * RL), dd[c], acc);
+        for (int c = 0; c < d.nd; ++c) acc = fma(-O::at(cbase + cm.Ddm, coff)[c * RL], dd[c], acc);
         return acc;
     }
 
@@ -381,9 +389,11 @@ struct Solver {
         // ---- constants to LDS
         {
             Row T;
-            O::ldo(cbase, coff + cm.Oc, RL, T); O::st(lds, WAVE, T);
-            O::ldo(cbase, coff + cm.OcT, RL, T); O::st(lds + (size_t)NX * WAVE, WAVE, T);
-            O::ldo(cbase, coff + cm.Bmid, RL, T); O::st(lds + (size_t)2 * NX * WAVE, WAVE, T);
+            O::ldo(w.uniform(cbase + cm.Oc), coff, RL, T); O::st(lds, WAVE, T);
+            O::ldo(w.uniform(cbase + cm.OcT), coff, RL, T); O::st(lds + (size_t)NX * WAVE, WAVE, T);
+#if MPCQP_MHE_BMID_LDS
+            O::ldo(w.uniform(cbase + cm.Bmid), coff, RL, T); O::st(lds + (size_t)2 * NX * WAVE, WAVE, T);
+#endif
         }
         auto bnd = [&](const double* p_, bool on, int n, double dflt) { return (on && p_ && r < n) ? p_[(size_t)b * RL + r] : dflt; };
         xlo = bnd(a.xmin, cX, nx, -BIG); xhi = bnd(a.xmax, cX, nx, BIG);
@@ -408,7 +418,7 @@ struct Solver {
                     q -= op.mv(T, xbar);
                 }
                 if (s > 0) {
-                    O::ldo(cbase, coff + cm.T2, RL, T);
+                    O::ldo(w.uniform(cbase + cm.T2), coff, RL, T);
                     q -= op.mv(T, gprev);
                 }
                 if (s < N) {
@@ -420,7 +430,7 @@ struct Solver {
                 if (i >= 0) {
                     ei = e_of(i);
                     S(sm.E + i) = ei;
-                    O::ldo(cbase, coff + cm.CR, RL, T);
+                    O::ldo(w.uniform(cbase + cm.CR), coff, RL, T);
                     q -= op.mv(T, ei);
                 }
                 S(sm.Q + s) = q;
@@ -443,7 +453,7 @@ struct Solver {
                     if (hwhi) nh_l = fmax(nh_l, fabs(whi) + 1.0);
                 }
                 if (cV && i >= 0) {
-                    O::ldo(cbase, coff + cm.Cm, RL, T);
+                    O::ldo(w.uniform(cbase + cm.Cm), coff, RL, T);
                     const double vv = ei - op.mv(T, xc);
                     const double s0 = fmax(vv - vlo, 1.0), s1 = fmax(vhi - vv, 1.0);
                     S(sm.VR + 4 * i + 0) = s0; S(sm.VR + 4 * i + 1) = lam0 / s0;
@@ -455,7 +465,7 @@ struct Solver {
                     // (no v̂ row at this state)
                 }
                 if (s < N) {                 // x(s+1) = Â x(s) + g(s)
-                    O::ldo(cbase, coff + cm.A, RL, T);
+                    O::ldo(w.uniform(cbase + cm.A), coff, RL, T);
                     xc = op.mv(T, xc) + gs;
                 }
                 gprev = gs;
@@ -508,7 +518,7 @@ struct Solver {
                         }
                         Row A;
                         if (cW && s < N) {
-                            O::ldo(cbase, coff + cm.A, RL, A);
+                            O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
                             double wv;
                             if (!phase) { wv = xp - op.mv(A, xc) - S(sm.G + s); S(sm.WW + s) = wv; }
                             else wv = S(sm.WW + s);
@@ -527,7 +537,7 @@ struct Solver {
                             Dtw = k0.Dt + k1.Dt;
                             if (!phase) S(sm.WD + s) = Dtw;
                             Row At;
-                            O::ldo(cbase, coff + cm.At, RL, At);
+                            O::ldo(w.uniform(cbase + cm.At), coff, RL, At);
                             gl -= op.mv(At, lw);
                             cr -= op.mv(At, cw);
                             gl_carry = lw; cr_carry = cw; dd_carry = Dtw;
@@ -540,7 +550,7 @@ struct Solver {
                         double Dtv = 0.0;
                         if (cV && im >= 0) {
                             Row Cm;
-                            O::ldo(cbase, coff + cm.Cm, RL, Cm);
+                            O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
                             double vv;
                             if (!phase) { vv = S(sm.E + im) - op.mv(Cm, xc); S(sm.VV + im) = vv; }
                             else vv = S(sm.VV + im);
@@ -559,7 +569,7 @@ struct Solver {
                             Dtv = k0.Dt + k1.Dt;
                             if (!phase) S(sm.VD + im) = Dtv;
                             Row Ct;
-                            O::ldo(cbase, coff + cm.Ct, RL, Ct);
+                            O::ldo(w.uniform(cbase + cm.Ct), coff, RL, Ct);
                             gl -= op.mv(Ct, lv);            // v̂ = e - Ĉm x: the rows' gradient is -Ĉm'
                             cr -= op.mv(Ct, cv);
                             if (!phase) {
@@ -594,7 +604,7 @@ struct Solver {
                             O::add_diag(Bs, r, dd);
                             if (cW && s < N) {            // + Â' D̃w Â
                                 Row At;
-                                O::ldo(cbase, coff + cm.At, RL, At);
+                                O::ldo(w.uniform(cbase + cm.At), coff, RL, At);
                                 sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; U[c] = Dtw * A[c]; });
                                 sfor<NX>([&](auto ic) {
                                     constexpr int c = decltype(ic)::v;
@@ -605,8 +615,8 @@ struct Solver {
                             }
                             if (cV && im >= 0) {          // + Ĉm' D̃v Ĉm
                                 Row Cm, Ct;
-                                O::ldo(cbase, coff + cm.Cm, RL, Cm);
-                                O::ldo(cbase, coff + cm.Ct, RL, Ct);
+                                O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
+                                O::ldo(w.uniform(cbase + cm.Ct), coff, RL, Ct);
                                 sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; U[c] = Dtv * Cm[c]; });
                                 sfor<NX>([&](auto ic) {
                                     constexpr int c = decltype(ic)::v;
@@ -623,9 +633,9 @@ struct Solver {
                             }
                             ok = op.gj(Bs, r) && ok;
                             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Si[c] = Bs[c]; });
-                            O::sto(sb, (sm.SI + s * NX) * WAVE + lane, WAVE, Si);
+                            O::sto(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, Si);
                         } else {
-                            O::ldo(sb, (sm.SI + s * NX) * WAVE + lane, WAVE, Si);
+                            O::ldo(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, Si);
                         }
                         const double t = op.mv(Si, rhs - otp);
                         S(sm.T + s) = t;
@@ -663,14 +673,14 @@ struct Solver {
                     double dxn = 0.0;
                     const int sDX = phase ? sm.DX : sm.DXA;
                     for (int s = N; s >= 0; --s) {
-                        O::ldo(sb, (sm.SI + s * NX) * WAVE + lane, WAVE, Si);
+                        O::ldo(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, Si);
                         double dx = S(sm.T + s);
                         if (s < N) {
                             O::ld(L_OcT(), WAVE, U);
                             double u = op.mv(U, dxn);
                             if (cW) {
                                 Row At;
-                                O::ldo(cbase, coff + cm.At, RL, At);
+                                O::ldo(w.uniform(cbase + cm.At), coff, RL, At);
                                 u -= op.mv(At, S(sm.WD + s) * dxn);
                             }
                             dx -= op.mv(Si, u);
@@ -696,7 +706,7 @@ struct Solver {
                         }
                         if (cW && s < N) {
                             Row A;
-                            O::ldo(cbase, coff + cm.A, RL, A);
+                            O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
                             const double gd = dxn - op.mv(A, dx);
                             S((phase ? sm.WG : sm.WGA) + s) = gd;
                             const double wv = S(sm.WW + s);
@@ -719,7 +729,7 @@ struct Solver {
                         const int im = meas_of(s);
                         if (cV && im >= 0) {
                             Row Cm;
-                            O::ldo(cbase, coff + cm.Cm, RL, Cm);
+                            O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
                             const double gd = -op.mv(Cm, dx);
                             S((phase ? sm.VG : sm.VGA) + im) = gd;
                             const double vv = S(sm.VV + im);
@@ -813,8 +823,8 @@ struct Solver {
     MPCQP_HD void write_outputs(int st, int it, double xbar) {
         const int nx = d.nx, nym = d.nym, He = d.He;
         Row A, Cm;
-        O::ldo(cbase, coff + cm.A, RL, A);
-        O::ldo(cbase, coff + cm.Cm, RL, Cm);
+        O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
+        O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
         const bool bad = st == 2;
         // a failed solve keeps the open-loop window: x(0) = x̄, ŵ = 0 (the starting point)
         double xc = bad ? xbar : S(sm.X + 0);
@@ -870,7 +880,7 @@ MPCQP_HD void step_body(W& w, const Dims& d, const Args& a, int wave_id, double*
     }
 }
 
-MPCQP_HD inline size_t step_lds_doubles(int NX) { return (size_t)3 * NX * WAVE; }
+MPCQP_HD inline size_t step_lds_doubles(int NX) { return (size_t)(MPCQP_MHE_BMID_LDS ? 3 : 2) * NX * WAVE; }
 
 }  // namespace mhe
 }  // namespace mpcqp

@@ -13,6 +13,14 @@ struct MheDevWave : DevWave {
     __device__ __forceinline__ double rowbc(double v) const {
         return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + C, 0xf, 0xf, true);
     }
+    // a wave-uniform pointer, pinned to scalar registers: keeps loop strength reduction from merging it with
+    // a lane offset into a per-lane 64-bit pointer that lives in two VGPRs for the whole loop
+    template <class T>
+    __device__ __forceinline__ T* uniform(T* p) const {
+        const uint64_t v = (uint64_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return (T*)(((uint64_t)hi << 32) | lo);
+    }
     // acc += sum_i (x_i of lane L_i of this lane's row) * y_i: the broadcast is the DPP modifier of the
     // multiply-add itself.  One asm block per four terms: the hardware does not interlock a DPP read of a
     // VGPR that a VALU instruction wrote within the previous two wait states, and the compiler's hazard

@@ -63,7 +63,7 @@ int waves_for(int device, int B, int NX) {
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int per_cu = 8;
+    int per_cu = MPCQP_MHE_BMID_LDS ? 8 : 12;      // LDS: 160 KB / (2 or 3 matrices x NX x 512 B)
     if (const char* e = getenv("MPCQP_MHE_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     const int groups = (B + GPW - 1) / GPW;
     const int cap = cus * per_cu;

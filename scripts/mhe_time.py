@@ -7,6 +7,8 @@ import torch
 import mpcqp
 from mpcqp import synth, mhe as pm
 import mhe_util
+if os.environ.get('MPCQP_LIB'):
+    mpcqp.api.load_library(os.environ['MPCQP_LIB']); mpcqp.api._lib = mpcqp.api.load_library(os.environ['MPCQP_LIB'])
 
 cfg = synth.get_mhe_config(sys.argv[1] if len(sys.argv) > 1 else "C5")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536

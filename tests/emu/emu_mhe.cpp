@@ -38,6 +38,8 @@ struct EmuWave {
     }
     template <int C>
     double rowbc(double v) { return xchg(v)[(lane & ~(RL - 1)) + C]; }
+    template <class T>
+    T* uniform(T* p) const { return p; }
     template <int L0, int L1, int L2, int L3>
     void fmabc4(double& acc, double x0, double x1, double x2, double x3, double y0, double y1, double y2, double y3) {
         acc = fma(rowbc<L0>(x0), y0, acc); acc = fma(rowbc<L1>(x1), y1, acc);
