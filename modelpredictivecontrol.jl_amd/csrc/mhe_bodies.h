@@ -29,6 +29,16 @@
 
 #include "mhe_types.h"
 
+// prefetch distance (stages) of the sweeps' scratch loads: factorisation sweep / solve sweeps / update pass
+#ifndef MPCQP_MHE_DEPTH_F0
+#define MPCQP_MHE_DEPTH_F0 1
+#endif
+#ifndef MPCQP_MHE_DEPTH
+#define MPCQP_MHE_DEPTH 1
+#endif
+#ifndef MPCQP_MHE_DEPTH_U
+#define MPCQP_MHE_DEPTH_U 2
+#endif
 #ifndef MPCQP_MHE_BMID_LDS
 #define MPCQP_MHE_BMID_LDS 1     // middle diagonal block of the Hessian in LDS (18 KB per wave) or read from the constant block (12 KB)
 #endif
@@ -383,6 +393,76 @@ struct Solver {
         return acc;
     }
 
+    // ---- everything one stage of a sweep reads from the scratch.  The sweeps load it DEPTH stages ahead of its
+    // use (software pipeline in registers): a stage of the light sweeps computes for ~0.3 us, a scratch access
+    // (HBM / MALL, the working set of the resident wavefronts is ~0.5 GB) takes a few us.
+    struct RowIn { double s0, l0, s1, l1; };
+    struct StageIn {
+        double x;        // forward: X(s+1); backward, update: X(s)
+        double a0;       // F0: Q(s), F1: RD(s), B0/B1: T(s), U: DX(s)
+        double dxa;      // DXA(s)
+        RowIn xr, wr, vr;
+        double ww, wga, wg, wd;      // ŵ(s), affine / final direction of the ŵ rows, D̃w(s)
+        double vv, vga, vg;          // v̂(im), directions of the v̂ rows
+        double gs, es;               // g(s), e(im)
+        Row Si;
+    };
+    enum { K_F0, K_F1, K_B0, K_B1, K_U };
+    MPCQP_HD void load_rows(int slot, RowIn& q) {
+        q.s0 = S(slot + 0); q.l0 = S(slot + 1); q.s1 = S(slot + 2); q.l1 = S(slot + 3);
+    }
+    template <int K>
+    MPCQP_HD void load_stage(int s, StageIn& in) {
+        constexpr bool fwd = K == K_F0 || K == K_F1, ph1 = K == K_F1 || K == K_B1;
+        const int im = meas_of(s);
+        in.x = fwd ? (s < N ? S(sm.X + s + 1) : 0.0) : S(sm.X + s);
+        in.a0 = S((K == K_F0 ? sm.Q : K == K_F1 ? sm.RD : K == K_U ? sm.DX : sm.T) + s);
+        if (K == K_F1 || K == K_B1 || K == K_U) in.dxa = S(sm.DXA + s);
+        if (cX) load_rows(sm.XR + 4 * s, in.xr);
+        if (cW && s < N) {
+            load_rows(sm.WR + 4 * s, in.wr);
+            if (K == K_F0) in.gs = S(sm.G + s);
+            else in.ww = S(sm.WW + s);
+            if (ph1 || K == K_U) in.wga = S(sm.WGA + s);
+            if (K == K_U) in.wg = S(sm.WG + s);
+            if (K == K_B0 || K == K_B1) in.wd = S(sm.WD + s);
+        }
+        if (cV && im >= 0) {
+            load_rows(sm.VR + 4 * im, in.vr);
+            if (K == K_F0) in.es = S(sm.E + im);
+            else in.vv = S(sm.VV + im);
+            if (ph1 || K == K_U) in.vga = S(sm.VGA + im);
+            if (K == K_U) in.vg = S(sm.VG + im);
+        }
+        if (K == K_F1 || K == K_B0 || K == K_B1) O::ldo(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, in.Si);
+    }
+    // stages 0..N (forward) or N..0 with the inputs of stage s +- DEPTH already in flight while stage s computes
+    template <int K, int DEPTH, class F>
+    MPCQP_HD void sweep(bool forward, F&& comp) {
+        StageIn c, n1, n2;
+        const int s0 = forward ? 0 : N, ds = forward ? 1 : -1;
+        if (DEPTH == 0) {
+            for (int k = 0; k <= N; ++k) {
+                load_stage<K>(s0 + k * ds, c);
+                comp(s0 + k * ds, c);
+            }
+            return;
+        }
+        load_stage<K>(s0, c);
+        if (DEPTH >= 2 && N >= 1) load_stage<K>(s0 + ds, n1);
+        for (int k = 0; k <= N; ++k) {
+            const int s = s0 + k * ds;
+            if (DEPTH >= 2) {
+                if (k + 2 <= N) load_stage<K>(s + 2 * ds, n2);
+            } else {
+                if (k + 1 <= N) load_stage<K>(s + ds, n1);
+            }
+            comp(s, c);
+            c = n1;
+            if (DEPTH >= 2) n1 = n2;
+        }
+    }
+
     MPCQP_HD void run() {
         const int nx = d.nx, nym = d.nym;
         push_data();
@@ -481,7 +561,7 @@ struct Solver {
         double laststep = 1e300, rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0, rpn = 0.0;
 
         for (int pass = 0; pass < d.max_iter; ++pass) {
-            double mu = 0.0, smu = 0.0, aaff = 1.0, alpha = 1.0;
+            double mu = 0.0, smu = 0.0, alpha = 1.0;
             bool ok = true;
             for (int phase = 0; phase < 2; ++phase) {
                 // ---------------- forward sweep: residuals (phase 0), right-hand side, factorisation (phase 0), t = S⁻¹ b̃
@@ -490,50 +570,43 @@ struct Solver {
                     Row Si, Oprev, Bs, U;
                     double xm = 0.0, xc = S(sm.X + 0), tprev = 0.0;
                     double dd_carry = 0.0, gl_carry = 0.0, cr_carry = 0.0;
-                    double dxam = 0.0, dxac = phase ? S(sm.DXA + 0) : 0.0;
-                    for (int s = 0; s <= N; ++s) {
-                        const double xp = s < N ? S(sm.X + s + 1) : 0.0;
-                        const double dxap = (phase && s < N) ? S(sm.DXA + s + 1) : 0.0;
+                    auto stage = [&](int s, StageIn& in) {
+                        const double xp = in.x;
                         double gl = gl_carry, dd = dd_carry, cr = cr_carry;
                         dd_carry = gl_carry = cr_carry = 0.0;
                         double Dtw = 0.0;
+                        // phase 1: the rows' complementarity target carries the second-order term of the affine step
+                        auto extra = [&](bool has, double sv, double lv, double rp, double gda) {
+                            double ds, dl;
+                            row_dir(has, sv, lv, rp, gda, 0.0, delta, ds, dl);
+                            return ds * dl - smu;
+                        };
+                        auto tally = [&](bool has, double sv, double lv, double rp) {
+                            if (has) { rpn_l = fmax(rpn_l, fabs(rp)); mu_l += sv * lv; }
+                        };
                         if (cX) {
-                            const double s0 = S(sm.XR + 4 * s + 0), l0 = S(sm.XR + 4 * s + 1);
-                            const double s1 = S(sm.XR + 4 * s + 2), l1 = S(sm.XR + 4 * s + 3);
-                            const double rp0 = -xc + s0 + xlo, rp1 = xc + s1 - xhi;
+                            const RowIn& q = in.xr;
+                            const double rp0 = -xc + q.s0 + xlo, rp1 = xc + q.s1 - xhi;
                             double e0 = 0.0, e1 = 0.0;
-                            if (phase) {
-                                double ds, dl;
-                                row_dir(hxlo, s0, l0, rp0, -dxac, 0.0, delta, ds, dl); e0 = ds * dl - smu;
-                                row_dir(hxhi, s1, l1, rp1, dxac, 0.0, delta, ds, dl); e1 = ds * dl - smu;
-                            }
-                            const RowK k0 = row_rhs(hxlo, s0, l0, rp0, e0, delta), k1 = row_rhs(hxhi, s1, l1, rp1, e1, delta);
-                            gl += (hxhi ? l1 : 0.0) - (hxlo ? l0 : 0.0);
+                            if (phase) { e0 = extra(hxlo, q.s0, q.l0, rp0, -in.dxa); e1 = extra(hxhi, q.s1, q.l1, rp1, in.dxa); }
+                            const RowK k0 = row_rhs(hxlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hxhi, q.s1, q.l1, rp1, e1, delta);
+                            gl += (hxhi ? q.l1 : 0.0) - (hxlo ? q.l0 : 0.0);
                             dd += k0.Dt + k1.Dt;
                             cr += k1.c - k0.c;
-                            if (!phase) {
-                                if (hxlo) { rpn_l = fmax(rpn_l, fabs(rp0)); mu_l += s0 * l0; }
-                                if (hxhi) { rpn_l = fmax(rpn_l, fabs(rp1)); mu_l += s1 * l1; }
-                            }
+                            if (!phase) { tally(hxlo, q.s0, q.l0, rp0); tally(hxhi, q.s1, q.l1, rp1); }
                         }
                         Row A;
                         if (cW && s < N) {
                             O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
                             double wv;
-                            if (!phase) { wv = xp - op.mv(A, xc) - S(sm.G + s); S(sm.WW + s) = wv; }
-                            else wv = S(sm.WW + s);
-                            const double s0 = S(sm.WR + 4 * s + 0), l0 = S(sm.WR + 4 * s + 1);
-                            const double s1 = S(sm.WR + 4 * s + 2), l1 = S(sm.WR + 4 * s + 3);
-                            const double rp0 = -wv + s0 + wlo, rp1 = wv + s1 - whi;
+                            if (!phase) { wv = xp - op.mv(A, xc) - in.gs; S(sm.WW + s) = wv; }
+                            else wv = in.ww;
+                            const RowIn& q = in.wr;
+                            const double rp0 = -wv + q.s0 + wlo, rp1 = wv + q.s1 - whi;
                             double e0 = 0.0, e1 = 0.0;
-                            if (phase) {
-                                const double gda = S(sm.WGA + s);
-                                double ds, dl;
-                                row_dir(hwlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
-                                row_dir(hwhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
-                            }
-                            const RowK k0 = row_rhs(hwlo, s0, l0, rp0, e0, delta), k1 = row_rhs(hwhi, s1, l1, rp1, e1, delta);
-                            const double lw = (hwhi ? l1 : 0.0) - (hwlo ? l0 : 0.0), cw = k1.c - k0.c;
+                            if (phase) { e0 = extra(hwlo, q.s0, q.l0, rp0, -in.wga); e1 = extra(hwhi, q.s1, q.l1, rp1, in.wga); }
+                            const RowK k0 = row_rhs(hwlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hwhi, q.s1, q.l1, rp1, e1, delta);
+                            const double lw = (hwhi ? q.l1 : 0.0) - (hwlo ? q.l0 : 0.0), cw = k1.c - k0.c;
                             Dtw = k0.Dt + k1.Dt;
                             if (!phase) S(sm.WD + s) = Dtw;
                             Row At;
@@ -541,10 +614,7 @@ struct Solver {
                             gl -= op.mv(At, lw);
                             cr -= op.mv(At, cw);
                             gl_carry = lw; cr_carry = cw; dd_carry = Dtw;
-                            if (!phase) {
-                                if (hwlo) { rpn_l = fmax(rpn_l, fabs(rp0)); mu_l += s0 * l0; }
-                                if (hwhi) { rpn_l = fmax(rpn_l, fabs(rp1)); mu_l += s1 * l1; }
-                            }
+                            if (!phase) { tally(hwlo, q.s0, q.l0, rp0); tally(hwhi, q.s1, q.l1, rp1); }
                         }
                         const int im = meas_of(s);
                         double Dtv = 0.0;
@@ -552,30 +622,21 @@ struct Solver {
                             Row Cm;
                             O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
                             double vv;
-                            if (!phase) { vv = S(sm.E + im) - op.mv(Cm, xc); S(sm.VV + im) = vv; }
-                            else vv = S(sm.VV + im);
-                            const double s0 = S(sm.VR + 4 * im + 0), l0 = S(sm.VR + 4 * im + 1);
-                            const double s1 = S(sm.VR + 4 * im + 2), l1 = S(sm.VR + 4 * im + 3);
-                            const double rp0 = -vv + s0 + vlo, rp1 = vv + s1 - vhi;
+                            if (!phase) { vv = in.es - op.mv(Cm, xc); S(sm.VV + im) = vv; }
+                            else vv = in.vv;
+                            const RowIn& q = in.vr;
+                            const double rp0 = -vv + q.s0 + vlo, rp1 = vv + q.s1 - vhi;
                             double e0 = 0.0, e1 = 0.0;
-                            if (phase) {
-                                const double gda = S(sm.VGA + im);
-                                double ds, dl;
-                                row_dir(hvlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
-                                row_dir(hvhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
-                            }
-                            const RowK k0 = row_rhs(hvlo, s0, l0, rp0, e0, delta), k1 = row_rhs(hvhi, s1, l1, rp1, e1, delta);
-                            const double lv = (hvhi ? l1 : 0.0) - (hvlo ? l0 : 0.0), cv = k1.c - k0.c;
+                            if (phase) { e0 = extra(hvlo, q.s0, q.l0, rp0, -in.vga); e1 = extra(hvhi, q.s1, q.l1, rp1, in.vga); }
+                            const RowK k0 = row_rhs(hvlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hvhi, q.s1, q.l1, rp1, e1, delta);
+                            const double lv = (hvhi ? q.l1 : 0.0) - (hvlo ? q.l0 : 0.0), cv = k1.c - k0.c;
                             Dtv = k0.Dt + k1.Dt;
                             if (!phase) S(sm.VD + im) = Dtv;
                             Row Ct;
                             O::ldo(w.uniform(cbase + cm.Ct), coff, RL, Ct);
                             gl -= op.mv(Ct, lv);            // v̂ = e - Ĉm x: the rows' gradient is -Ĉm'
                             cr -= op.mv(Ct, cv);
-                            if (!phase) {
-                                if (hvlo) { rpn_l = fmax(rpn_l, fabs(rp0)); mu_l += s0 * l0; }
-                                if (hvhi) { rpn_l = fmax(rpn_l, fabs(rp1)); mu_l += s1 * l1; }
-                            }
+                            if (!phase) { tally(hvlo, q.s0, q.l0, rp0); tally(hvhi, q.s1, q.l1, rp1); }
                         }
                         double rd;
                         if (!phase) {
@@ -583,13 +644,13 @@ struct Solver {
                             double hz = op.mv(Bs, xc);
                             if (s > 0) { O::ld(L_Oc(), WAVE, U); hz += op.mv(U, xm); }
                             if (s < N) { O::ld(L_OcT(), WAVE, U); hz += op.mv(U, xp); }
-                            const double q = S(sm.Q + s);
+                            const double q = in.a0;
                             rd = hz + q + gl;
                             S(sm.RD + s) = rd;
                             rdn_l = fmax(rdn_l, fabs(rd));
                             ndd_l = fmax(ndd_l, fmax(fabs(q), fmax(fabs(hz), fabs(gl))));
                         } else {
-                            rd = S(sm.RD + s);
+                            rd = in.a0;
                         }
                         const double rhs = -rd + cr;
                         MPCQP_SCHED_FENCE();
@@ -635,21 +696,21 @@ struct Solver {
                             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Si[c] = Bs[c]; });
                             O::sto(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, Si);
                         } else {
-                            O::ldo(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, Si);
+                            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Si[c] = in.Si[c]; });
                         }
                         const double t = op.mv(Si, rhs - otp);
                         S(sm.T + s) = t;
                         tprev = t;
                         MPCQP_SCHED_FENCE();
                         xm = xc; xc = xp;
-                        dxam = dxac; dxac = dxap;
-                    }
-                    (void)dxam;
+                    };
+                    if (!phase) sweep<K_F0, MPCQP_MHE_DEPTH_F0>(true, stage); else sweep<K_F1, MPCQP_MHE_DEPTH>(true, stage);
                 }
                 if (!phase) {
                     rpn = w.rmax(rpn_l);
                     const double rdn = w.rmax(rdn_l), ndd = w.rmax(ndd_l) + 1.0;
-                    mu = norows ? 0.0 : w.rsum(mu_l) / mrows;
+                    const double musum = w.rsum(mu_l);
+                    mu = norows ? 0.0 : musum / mrows;
 #ifdef MHE_DEBUG_PRINT
                     if (r == 0) printf("[b%d] pass %d mu %.3e rpn %.3e rdn %.3e ndd %.3e laststep %.3e ok %d done %d\n", b, pass, mu, rpn, rdn, ndd, laststep, (int)ok, (int)done);
 #endif
@@ -669,62 +730,44 @@ struct Solver {
                 // ---------------- backward sweep: dx(s) = t(s) - Si(s) O(s)' dx(s+1); step ratios of the rows
                 double amin_l = 1e300, q1_l = 0.0, q2_l = 0.0;
                 {
-                    Row Si, U;
+                    Row U;
                     double dxn = 0.0;
                     const int sDX = phase ? sm.DX : sm.DXA;
-                    for (int s = N; s >= 0; --s) {
-                        O::ldo(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, Si);
-                        double dx = S(sm.T + s);
+                    auto rows2 = [&](bool h0, bool h1, const RowIn& q, double val, double lo, double hi, double gda, double gd) {
+                        // both rows of one bounded quantity `val` (lo <= val <= hi) with direction gd
+                        const double rp0 = -val + q.s0 + lo, rp1 = val + q.s1 - hi;
+                        double e0 = 0.0, e1 = 0.0, ds, dl;
+                        if (phase) {
+                            row_dir(h0, q.s0, q.l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
+                            row_dir(h1, q.s1, q.l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
+                        }
+                        row_dir(h0, q.s0, q.l0, rp0, -gd, e0, delta, ds, dl);
+                        amin_l = fmin(amin_l, fmin(ratio(q.s0, ds), ratio(q.l0, dl)));
+                        q1_l += q.s0 * dl + q.l0 * ds; q2_l += ds * dl;
+                        row_dir(h1, q.s1, q.l1, rp1, gd, e1, delta, ds, dl);
+                        amin_l = fmin(amin_l, fmin(ratio(q.s1, ds), ratio(q.l1, dl)));
+                        q1_l += q.s1 * dl + q.l1 * ds; q2_l += ds * dl;
+                    };
+                    auto stage = [&](int s, StageIn& in) {
+                        double dx = in.a0;
                         if (s < N) {
                             O::ld(L_OcT(), WAVE, U);
                             double u = op.mv(U, dxn);
                             if (cW) {
                                 Row At;
                                 O::ldo(w.uniform(cbase + cm.At), coff, RL, At);
-                                u -= op.mv(At, S(sm.WD + s) * dxn);
+                                u -= op.mv(At, in.wd * dxn);
                             }
-                            dx -= op.mv(Si, u);
+                            dx -= op.mv(in.Si, u);
                         }
                         S(sDX + s) = dx;
-                        const double xc = S(sm.X + s);
-                        if (cX) {
-                            const double s0 = S(sm.XR + 4 * s + 0), l0 = S(sm.XR + 4 * s + 1);
-                            const double s1 = S(sm.XR + 4 * s + 2), l1 = S(sm.XR + 4 * s + 3);
-                            const double rp0 = -xc + s0 + xlo, rp1 = xc + s1 - xhi;
-                            double e0 = 0.0, e1 = 0.0, ds, dl;
-                            if (phase) {
-                                const double dxa = S(sm.DXA + s);
-                                row_dir(hxlo, s0, l0, rp0, -dxa, 0.0, delta, ds, dl); e0 = ds * dl - smu;
-                                row_dir(hxhi, s1, l1, rp1, dxa, 0.0, delta, ds, dl); e1 = ds * dl - smu;
-                            }
-                            row_dir(hxlo, s0, l0, rp0, -dx, e0, delta, ds, dl);
-                            amin_l = fmin(amin_l, fmin(ratio(s0, ds), ratio(l0, dl)));
-                            q1_l += s0 * dl + l0 * ds; q2_l += ds * dl;
-                            row_dir(hxhi, s1, l1, rp1, dx, e1, delta, ds, dl);
-                            amin_l = fmin(amin_l, fmin(ratio(s1, ds), ratio(l1, dl)));
-                            q1_l += s1 * dl + l1 * ds; q2_l += ds * dl;
-                        }
+                        if (cX) rows2(hxlo, hxhi, in.xr, in.x, xlo, xhi, in.dxa, dx);
                         if (cW && s < N) {
                             Row A;
                             O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
                             const double gd = dxn - op.mv(A, dx);
                             S((phase ? sm.WG : sm.WGA) + s) = gd;
-                            const double wv = S(sm.WW + s);
-                            const double s0 = S(sm.WR + 4 * s + 0), l0 = S(sm.WR + 4 * s + 1);
-                            const double s1 = S(sm.WR + 4 * s + 2), l1 = S(sm.WR + 4 * s + 3);
-                            const double rp0 = -wv + s0 + wlo, rp1 = wv + s1 - whi;
-                            double e0 = 0.0, e1 = 0.0, ds, dl;
-                            if (phase) {
-                                const double gda = S(sm.WGA + s);
-                                row_dir(hwlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
-                                row_dir(hwhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
-                            }
-                            row_dir(hwlo, s0, l0, rp0, -gd, e0, delta, ds, dl);
-                            amin_l = fmin(amin_l, fmin(ratio(s0, ds), ratio(l0, dl)));
-                            q1_l += s0 * dl + l0 * ds; q2_l += ds * dl;
-                            row_dir(hwhi, s1, l1, rp1, gd, e1, delta, ds, dl);
-                            amin_l = fmin(amin_l, fmin(ratio(s1, ds), ratio(l1, dl)));
-                            q1_l += s1 * dl + l1 * ds; q2_l += ds * dl;
+                            rows2(hwlo, hwhi, in.wr, in.ww, wlo, whi, in.wga, gd);
                         }
                         const int im = meas_of(s);
                         if (cV && im >= 0) {
@@ -732,32 +775,18 @@ struct Solver {
                             O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
                             const double gd = -op.mv(Cm, dx);
                             S((phase ? sm.VG : sm.VGA) + im) = gd;
-                            const double vv = S(sm.VV + im);
-                            const double s0 = S(sm.VR + 4 * im + 0), l0 = S(sm.VR + 4 * im + 1);
-                            const double s1 = S(sm.VR + 4 * im + 2), l1 = S(sm.VR + 4 * im + 3);
-                            const double rp0 = -vv + s0 + vlo, rp1 = vv + s1 - vhi;
-                            double e0 = 0.0, e1 = 0.0, ds, dl;
-                            if (phase) {
-                                const double gda = S(sm.VGA + im);
-                                row_dir(hvlo, s0, l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
-                                row_dir(hvhi, s1, l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
-                            }
-                            row_dir(hvlo, s0, l0, rp0, -gd, e0, delta, ds, dl);
-                            amin_l = fmin(amin_l, fmin(ratio(s0, ds), ratio(l0, dl)));
-                            q1_l += s0 * dl + l0 * ds; q2_l += ds * dl;
-                            row_dir(hvhi, s1, l1, rp1, gd, e1, delta, ds, dl);
-                            amin_l = fmin(amin_l, fmin(ratio(s1, ds), ratio(l1, dl)));
-                            q1_l += s1 * dl + l1 * ds; q2_l += ds * dl;
+                            rows2(hvlo, hvhi, in.vr, in.vv, vlo, vhi, in.vga, gd);
                         }
                         dxn = dx;
-                    }
+                    };
+                    if (!phase) sweep<K_B0, MPCQP_MHE_DEPTH>(false, stage); else sweep<K_B1, MPCQP_MHE_DEPTH>(false, stage);
                 }
                 const double amin = w.rmin(amin_l);
+                const double q1 = w.rsum(q1_l), q2 = w.rsum(q2_l);
                 if (!phase) {
                     // centring: mean complementarity after the affine step of length aaff, a quadratic in aaff whose
                     // coefficients the sweep accumulated -- no extra pass over the rows
-                    aaff = fmin(1.0, amin);
-                    const double q1 = w.rsum(q1_l), q2 = w.rsum(q2_l);
+                    const double aaff = fmin(1.0, amin);
                     const double mas = mu * mrows + aaff * (q1 + aaff * q2);
                     const double sig = (mas / mrows) / mu;
                     smu = sig * sig * sig * mu;
@@ -767,50 +796,45 @@ struct Solver {
                     alpha = fmin(1.0, 0.9999 * amin);
                 }
             }
-            (void)aaff;
             if (!w.any(!done)) break;
             // ---------------- update (a finished estimator of the wavefront keeps its iterate)
             {
                 const double al = done ? 0.0 : alpha;
                 double zm_l = 1.0, dm_l = 0.0;
-                auto upd = [&](bool has, int slot, double rp, double gda, double gd) {
-                    if (!has) return;
-                    const double sv = S(slot), lv = S(slot + 1);
+                auto upd2 = [&](bool h0, bool h1, int slot, const RowIn& q, double val, double lo, double hi, double gda, double gd) {
+                    const double rp0 = -val + q.s0 + lo, rp1 = val + q.s1 - hi;
                     double ds, dl;
-                    row_dir(true, sv, lv, rp, gda, 0.0, delta, ds, dl);
-                    const double e = ds * dl - smu;
-                    row_dir(true, sv, lv, rp, gd, e, delta, ds, dl);
-                    S(slot) = sv + al * ds;
-                    S(slot + 1) = lv + al * dl;
+                    if (h0) {
+                        row_dir(true, q.s0, q.l0, rp0, -gda, 0.0, delta, ds, dl);
+                        const double e = ds * dl - smu;
+                        row_dir(true, q.s0, q.l0, rp0, -gd, e, delta, ds, dl);
+                        S(slot + 0) = q.s0 + al * ds;
+                        S(slot + 1) = q.l0 + al * dl;
+                    }
+                    if (h1) {
+                        row_dir(true, q.s1, q.l1, rp1, gda, 0.0, delta, ds, dl);
+                        const double e = ds * dl - smu;
+                        row_dir(true, q.s1, q.l1, rp1, gd, e, delta, ds, dl);
+                        S(slot + 2) = q.s1 + al * ds;
+                        S(slot + 3) = q.l1 + al * dl;
+                    }
                 };
-                for (int s = 0; s <= N; ++s) {
-                    const double xc = S(sm.X + s), dx = S(sm.DX + s);
-                    if (cX) {
-                        const double dxa = S(sm.DXA + s);
-                        upd(hxlo, sm.XR + 4 * s + 0, -xc + S(sm.XR + 4 * s + 0) + xlo, -dxa, -dx);
-                        upd(hxhi, sm.XR + 4 * s + 2, xc + S(sm.XR + 4 * s + 2) - xhi, dxa, dx);
-                    }
-                    if (cW && s < N) {
-                        const double wv = S(sm.WW + s), gda = S(sm.WGA + s), gd = S(sm.WG + s);
-                        upd(hwlo, sm.WR + 4 * s + 0, -wv + S(sm.WR + 4 * s + 0) + wlo, -gda, -gd);
-                        upd(hwhi, sm.WR + 4 * s + 2, wv + S(sm.WR + 4 * s + 2) - whi, gda, gd);
-                    }
+                auto stage = [&](int s, StageIn& in) {
+                    const double xc = in.x, dx = in.a0;
+                    if (cX) upd2(hxlo, hxhi, sm.XR + 4 * s, in.xr, xc, xlo, xhi, in.dxa, dx);
+                    if (cW && s < N) upd2(hwlo, hwhi, sm.WR + 4 * s, in.wr, in.ww, wlo, whi, in.wga, in.wg);
                     const int im = meas_of(s);
-                    if (cV && im >= 0) {
-                        const double vv = S(sm.VV + im), gda = S(sm.VGA + im), gd = S(sm.VG + im);
-                        upd(hvlo, sm.VR + 4 * im + 0, -vv + S(sm.VR + 4 * im + 0) + vlo, -gda, -gd);
-                        upd(hvhi, sm.VR + 4 * im + 2, vv + S(sm.VR + 4 * im + 2) - vhi, gda, gd);
-                    }
+                    if (cV && im >= 0) upd2(hvlo, hvhi, sm.VR + 4 * im, in.vr, in.vv, vlo, vhi, in.vga, in.vg);
                     zm_l = fmax(zm_l, fabs(xc));
                     dm_l = fmax(dm_l, fabs(al * dx));
                     S(sm.X + s) = xc + al * dx;
-                }
+                };
+                sweep<K_U, MPCQP_MHE_DEPTH_U>(true, stage);
+                const double dm = w.rmax(dm_l), zm = w.rmax(zm_l);
                 if (!done) {
-                    laststep = w.rmax(dm_l) / w.rmax(zm_l);
+                    laststep = dm / zm;
                     lastscale = 1.0 - alpha;
                     if (norows) { st = 0; done = true; it = 0; }
-                } else {
-                    (void)w.rmax(dm_l); (void)w.rmax(zm_l);
                 }
             }
             if (!w.any(!done)) break;
