@@ -117,6 +117,13 @@ def run(args, rank, world, local, dist):
     kms = float(np.mean(sh.kern_ms))
     achieved = flops * B / (kms * 1e-3) / 1e12
     Zt = sh.h.get(pm.GET_ZTILDE)
+    traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/
+    try:
+        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_k_mhe_step.json")))
+        if tr["config"] == args.config and tr["batch"] == B:
+            traffic = tr["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     out = {
         "metric": "QP solves/sec (MovingHorizonEstimator period)",
         "value": Bglobal * args.steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -134,11 +141,14 @@ def run(args, rank, world, local, dist):
                    "register_columns": sh.h.register_columns(),
                    "kernels_per_period": "k_mhe_cov (correct) + k_mhe_step + k_mhe_cov (predict)"},
         "roofline": {"bound": "mfma", "kernel": "k_mhe_step", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel_ms": kms,
+                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "kernel_ms": kms,
+                     "hbm_measured_GBps": (traffic / (kms * 1e-3) / 1e9) if traffic else None,
                      "flops_per_solve": flops,
                      "note": "FP64 vector peak (v_fma_f64; the kernel's blocks are 12 x 12, below the 16 x 16 x 4 MFMA "
                              "tile, and run on v_fma_f64 + DPP row broadcasts); flops = setup + I W_iter, block "
-                             "tridiagonal count, I = mean factorisations per solve"},
+                             "tridiagonal count, I = mean factorisations per solve; the window state of a wavefront (257 KB) "
+                             "streams through HBM: traffic / kernel_ms is the measured HBM rate (peak 8000 GB/s), the "
+                             "limiter of this kernel next to its dependent sweeps"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args)

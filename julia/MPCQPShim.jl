@@ -172,4 +172,77 @@ function moveinput!(b::BatchLinMPC, ry::AbstractMatrix, d::AbstractMatrix=zeros(
     return u0 .+ uop
 end
 
+# ------------------------------------------------------------------------------------------------
+# Batch of linear MovingHorizonEstimator objects (include/mpcqp_mhe.h; SURVEY 8 row f2).  The estimators keep
+# their Julia fields; preparestate! / updatestate! of the BATCH run on the device.  Call sequence = the one of
+# modelpredictivecontrol.jl_amd/mhe.py (BatchMHE), which the GPU tests drive.
+import ModelPredictiveControl: preparestate!, updatestate!, MovingHorizonEstimator
+
+struct MheDims                        # == mpcqp_mhe_dims
+    batch::Cint; nxhat::Cint; nu::Cint; nym::Cint; nd::Cint; He::Cint; direct::Cint; device::Cint
+    flags::Cuint; max_iter::Cint; gap_tol::Cdouble; res_tol::Cdouble; dual_reg::Cdouble
+end
+
+mutable struct BatchMHE
+    h::Ptr{Cvoid}
+    estims::Vector{MovingHorizonEstimator}
+    x̂0::Matrix{Float64}              # (nx̂, B)
+end
+
+function BatchMHE(estims::Vector{<:MovingHorizonEstimator}; device::Integer=0)
+    e = estims[1]; B = length(estims); model = e.model
+    isinf(e.C) || error("finite Cwt (soft constraints) is not supported by libmpcqp's MHE path")
+    d = MheDims(B, e.nx̂, model.nu, e.nym, model.nd, e.He, e.direct ? 1 : 0, device, 0, 0, 0.0, 0.0, 0.0)
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:mpcqp_mhe_create, lib), Cint, (Ref{MheDims}, Ref{Ptr{Cvoid}}), d, h))
+    cat3(f) = cat((Matrix(f(c)) for c in estims)...; dims=3)
+    cat2(f) = hcat((f(c) for c in estims)...)
+    nd = model.nd
+    check(ccall((:mpcqp_mhe_set_model, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+          Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[],
+          cat3(c -> c.Â), cat3(c -> c.B̂u), cat3(c -> c.Ĉm), nd > 0 ? cat3(c -> c.B̂d) : C_NULL,
+          nd > 0 ? cat3(c -> c.D̂dm) : C_NULL, cat2(c -> c.f̂op - c.x̂op), cat3(c -> c.cov.Q̂), cat3(c -> c.cov.R̂)))
+    # per-channel hard bounds (setconstraint! x̂min, ..., v̂max): the first block of the window-long vectors
+    nx̂, nym = e.nx̂, e.nym
+    first(v, n) = v[1:n]
+    check(ccall((:mpcqp_mhe_set_bounds, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+          Ptr{Float64}, Ptr{Float64}), h[],
+          cat2(c -> c.con.x̂0min), cat2(c -> c.con.x̂0max), cat2(c -> first(c.con.Ŵmin, nx̂)), cat2(c -> first(c.con.Ŵmax, nx̂)),
+          cat2(c -> first(c.con.V̂min, nym)), cat2(c -> first(c.con.V̂max, nym))))
+    x̂0 = cat2(c -> c.x̂0)
+    check(ccall((:mpcqp_mhe_init, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[],
+          x̂0, cat3(c -> c.cov.P̂_0), nd > 0 ? cat2(c -> c.D0[1:nd]) : C_NULL, cat2(c -> c.lastu0)))
+    return BatchMHE(h[], estims, x̂0)
+end
+
+function pull_state!(b::BatchMHE)
+    check(ccall((:mpcqp_mhe_get, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), b.h, 0 #= MPCQP_MHE_XHAT0 =#, b.x̂0))
+    for (i, c) in enumerate(b.estims); c.x̂0 .= @view b.x̂0[:, i]; end
+    return b.x̂0 .+ hcat((c.x̂op for c in b.estims)...)
+end
+
+# preparestate!(estim, ym, d) over the batch (execute.jl:44-57): ym (nym, B), d (nd, B)
+function preparestate!(b::BatchMHE, ym::AbstractMatrix, d::AbstractMatrix=zeros(0, size(ym, 2)))
+    e = b.estims[1]
+    y0m = ym .- hcat((c.model.yop[c.i_ym] for c in b.estims)...)
+    d0 = d .- hcat((c.model.dop for c in b.estims)...)
+    nbad = ccall((:mpcqp_mhe_prepare, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), b.h, y0m,
+                 e.model.nd > 0 ? d0 : C_NULL)
+    nbad < 0 && check(nbad)
+    nbad > 0 && @warn "MHE termination status not OPTIMAL for $nbad estimators: keeping the open-loop estimate"
+    return pull_state!(b)
+end
+
+# updatestate!(estim, u, ym, d) over the batch (execute.jl:76-88)
+function updatestate!(b::BatchMHE, u::AbstractMatrix, ym::AbstractMatrix, d::AbstractMatrix=zeros(0, size(ym, 2)))
+    e = b.estims[1]
+    u0 = u .- hcat((c.model.uop for c in b.estims)...)
+    y0m = ym .- hcat((c.model.yop[c.i_ym] for c in b.estims)...)
+    d0 = d .- hcat((c.model.dop for c in b.estims)...)
+    nbad = ccall((:mpcqp_mhe_update, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), b.h, u0, y0m,
+                 e.model.nd > 0 ? d0 : C_NULL)
+    nbad < 0 && check(nbad)
+    return pull_state!(b)
+end
+
 end # module

@@ -530,3 +530,40 @@ def readme_example(lib=None, B=2, steps=40):
         gpu.updatestate(np.tile(uo, (B, 1)), y)
         U.append(uo.copy()); Y.append(y.copy())
     return worst, np.array(U), np.array(Y), Hp, kf.nxh
+
+
+def setmodel_after_first_step(lib=None, B=4, cfg=None):
+    """`setmodel!` between two periods (src/controller/execute.jl:684-790): a controller that has already
+    stepped gets a new plant model AND new weights; its next `moveinput!` must equal, bit for bit, the one
+    of a controller constructed with the new model (same warm start), and match the oracle."""
+    cfg = cfg or synth.C2
+    bt1 = synth.make_batch(cfg, B, seed=21)
+    bt2 = synth.make_batch(cfg, B, seed=22)
+    a = make_controller(cfg, bt1, lib=lib)
+    a.lastu0 = bt1["lastu0"].copy()
+    a.moveinput(bt1["xhat0"], bt1["ry"])
+    assert np.all(a.status == 0)
+    Z1, lu1 = a.Z.copy(), a.lastu0.copy()
+    a.setmodel(bt2["Ahat"], bt2["Bhu"], bt2["Chat"])
+    a.setweights(Mwt=np.full(cfg.ny, 2.0 * cfg.Mwt), Nwt=np.full(cfg.nu, 0.5 * cfg.Nwt))
+    ua = a.moveinput(bt2["xhat0"], bt2["ry"])
+    b = mpcqp.BatchLinMPC(bt2["Ahat"], bt2["Bhu"], bt2["Chat"], Hp=cfg.Hp, Hc=cfg.Hc, Cwt=cfg.Cwt,
+                          Mwt=np.full(cfg.ny, 2.0 * cfg.Mwt), Nwt=np.full(cfg.nu, 0.5 * cfg.Nwt),
+                          Lwt=np.full(cfg.nu, cfg.Lwt), lib=lib)
+    b.setconstraint(**constraint_kwargs(cfg))
+    b.Z[:] = Z1                    # same warm start and last input as the controller that has history
+    b.lastu0 = lu1.copy()
+    ub = b.moveinput(bt2["xhat0"], bt2["ry"])
+    assert np.all(a.status == 0) and np.array_equal(a.Z, b.Z) and np.array_equal(ua, ub)
+    worst = 0.0
+    nDU = cfg.nu * cfg.Hc
+    for i in range(B):
+        m = cd.LinMPCOracle(bt2["Ahat"][i], bt2["Bhu"][i], bt2["Chat"][i], Hp=cfg.Hp, Hc=cfg.Hc, Cwt=cfg.Cwt,
+                            Mwt=np.full(cfg.ny, 2.0 * cfg.Mwt), Nwt=np.full(cfg.nu, 0.5 * cfg.Nwt),
+                            Lwt=np.full(cfg.nu, cfg.Lwt))
+        m.setconstraint(**constraint_kwargs(cfg, oracle=True))
+        m.initpred(bt2["xhat0"][i], lu1[i], bt2["ry"][i])
+        m.linconstraint()
+        z, st, info = qp.solve_qp(*m.qp_data(), m.warmstart(), return_info=True)
+        worst = max(worst, np.abs(a.Z[i, :nDU] - z[:nDU]).max() / max(1.0, np.abs(z[:nDU]).max()))
+    return worst

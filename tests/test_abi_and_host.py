@@ -317,3 +317,10 @@ def test_random_horizon_wide_forms_on_cpu_emulator(seed, emulib):
     from tests.parity_util import run_random_case2
     e = run_random_case2(seed, lib=emulib, B=1, small=True)
     assert e is not None and e <= 1e-5
+
+
+@pytest.mark.slow
+def test_setmodel_after_first_step_on_cpu_emulator(emulib):
+    from tests.parity_util import setmodel_after_first_step
+    cfg = synth.Config("setmodel", nx=2, nu=2, ny=2, Hp=6, Hc=3, umin=-0.8, umax=0.8, ymax=1.0)
+    assert setmodel_after_first_step(lib=emulib, B=2, cfg=cfg) <= 1e-6

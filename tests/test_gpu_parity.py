@@ -514,3 +514,11 @@ def test_random_horizon_wide_forms_on_gpu(seed, hiplib):
     from tests.parity_util import run_random_case2
     e = run_random_case2(seed, B=4)
     assert e is not None and e <= TOL, e
+
+
+def test_setmodel_after_first_step_on_gpu(hiplib):
+    """setmodel! + new weights on a controller that has already stepped: K1 + K2 re-run, next step equals a
+    freshly constructed controller's bit for bit and the oracle's optimum (C2 and C3 shapes)."""
+    from tests.parity_util import setmodel_after_first_step
+    assert setmodel_after_first_step(B=6, cfg=synth.C2) <= TOL
+    assert setmodel_after_first_step(B=3, cfg=synth.C3) <= TOL
