@@ -459,7 +459,15 @@ class BatchLinMPC:
     def __init__(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None, *, Hp, Hc=2, Mwt=None, Nwt=None,
                  Lwt=None, M_Hp=None, Cwt=1e5, Wy=None, Wu=None, Wd=None, Wr=None, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
                  cold_start=False, keep_qp=False, warm_dual=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
-                 lib=None):
+                 transcription="SingleShooting", lib=None):
+        # `transcription` (LinMPC keyword, linmpc.jl:288-316).  For a LinModel the MultipleShooting QP
+        # (Z = [ΔU; X̂0] with the model as equality constraints, transcription.jl:217-240, 373-414) has the same
+        # optimal ΔU as the condensed one: the batch is solved by the condensed kernels either way, and getinfo
+        # returns the decision vector in the chosen transcription's layout.  The sparse structured solve that
+        # makes MultipleShooting attractive for ill-conditioned H̃ is NOT what runs here.
+        if transcription not in ("SingleShooting", "MultipleShooting"):
+            raise NotImplementedError(f"transcription {transcription!r}: only SingleShooting / MultipleShooting (LinModel)")
+        self.transcription = transcription
         Ahat, Bhu, Chat = (np.asarray(a, float) for a in (Ahat, Bhu, Chat))
         if Ahat.ndim != 3 or Bhu.ndim != 3 or Chat.ndim != 3:
             raise ValueError("model matrices need a leading batch axis")
@@ -830,12 +838,18 @@ class BatchLinMPC:
         x = xhat0.copy()
         dop_x = self.fhop - self.xhop
         U0s = U0.reshape(self.B, Hp, nu)
+        X0 = np.empty((self.B, Hp, self.nxh))
         for t in range(Hp):
             x = np.einsum("bij,bj->bi", self._Ahat, x) + np.einsum("bij,bj->bi", self._Bhu, U0s[:, t]) + dop_x
             if nd > 0:
                 dt = d0 if t == 0 else Dh0[:, (t - 1) * nd:t * nd]
                 x = x + np.einsum("bij,bj->bi", self._Bhd, dt)
+            X0[:, t] = x
         info["x̂end"] = x + self.xhop
+        # decision vector in the transcription's layout: [ΔU; ϵ] or [ΔU; X̂0(k+1..k+Hp); ϵ] (get_nZ_mpc, transcription.jl:2-7)
+        parts = [DU] + ([X0.reshape(self.B, -1)] if self.transcription == "MultipleShooting" else []) + ([eps[:, None]] if self.neps else [])
+        info["Z̃"] = np.concatenate(parts, axis=1)
+        info["X̂0"] = X0.reshape(self.B, -1)
         if self._Yhat0 is not None:
             info["Ŷ"] = self._Yhat0 + self.Yop
             # J = (Ŷ-R̂y)'M(Ŷ-R̂y) + ΔU'N ΔU + (U-R̂u)'L(U-R̂u) + C ϵ²   (obj_nonlinprog!, general.jl:107 with r)
@@ -864,7 +878,7 @@ class BatchLinMPC:
                     Wv = Wv + np.einsum("bij,btj->bti", self.Wd, de)
                 info["W"] = Wv.reshape(self.B, -1)
         for a, k in (("DeltaU", "ΔU"), ("epsilon", "ϵ"), ("Dhat", "D̂"), ("xhat", "x̂"), ("yhat", "ŷ"), ("Yhat", "Ŷ"),
-                     ("xhatend", "x̂end"), ("Yhats", "Ŷs"), ("Rhaty", "R̂y"), ("Rhatu", "R̂u")):
+                     ("xhatend", "x̂end"), ("Yhats", "Ŷs"), ("Rhaty", "R̂y"), ("Rhatu", "R̂u"), ("Ztilde", "Z̃"), ("Xhat0", "X̂0")):
             if k in info:
                 info[a] = info[k]
         return info

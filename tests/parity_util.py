@@ -6,7 +6,7 @@ import numpy as np
 
 import mpcqp
 from mpcqp import synth
-from oracle import condense as cd, qp
+from oracle import condense as cd, estim as es, qp
 
 
 def constraint_kwargs(cfg, oracle=False):
@@ -567,3 +567,34 @@ def setmodel_after_first_step(lib=None, B=4, cfg=None):
         z, st, info = qp.solve_qp(*m.qp_data(), m.warmstart(), return_info=True)
         worst = max(worst, np.abs(a.Z[i, :nDU] - z[:nDU]).max() / max(1.0, np.abs(z[:nDU]).max()))
     return worst
+
+
+def multiple_shooting_known_answers(lib=None, B=2):
+    """The reference's MultipleShooting LinMPC tests (test/3_test_predictive_control.jl:120-127, 570-579):
+    Hp = 1000, Hc = 1; u ≈ 1 and Ŷ[end] ≈ 15 for `linmodel` (gain 5 after the operating points); a second plant
+    tf(5,[2,1]): u ≈ 3 for r = 15, and after setmodel!(tf(10,[2,1])) u ≈ 4 for r = 40 (atol 1e-2 there).  Also
+    checks the returned MultipleShooting decision vector [ΔU; X̂0; ϵ]: X̂0 obeys the model equality constraints
+    and reproduces Ŷ."""
+    rep = lambda M: np.repeat(np.asarray(M, float)[None], B, 0)
+    out = {}
+    model = es.LinModelOracle(*es.tf1_zoh(5.0, 2.0, 3.0), Ts=3.0)
+    kf = es.SteadyKalmanFilterOracle(model)
+    mpc = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), Hp=1000, Hc=1, Nwt=[0], transcription="MultipleShooting", lib=lib)
+    u = mpc.moveinput(np.zeros((B, kf.nxh)), [15.0], want_info=True)
+    info = mpc.getinfo()
+    out["u3"] = u.copy()
+    Z = info["Z̃"]
+    nxh, Hp = kf.nxh, 1000
+    assert Z.shape == (B, 1 + nxh * Hp + 1)
+    X0 = Z[:, 1:1 + nxh * Hp].reshape(B, Hp, nxh)
+    U0 = info["U"].reshape(B, Hp, 1)
+    xprev = np.concatenate([np.zeros((B, 1, nxh)), X0[:, :-1]], axis=1)
+    defect = X0 - (np.einsum("ij,btj->bti", kf.Ah, xprev) + np.einsum("ij,btj->bti", kf.Bhu, U0))
+    out["defect"] = np.abs(defect).max()
+    out["yerr"] = np.abs(np.einsum("ij,btj->bti", kf.Ch, X0).reshape(B, -1) - info["Ŷ"]).max()
+    out["yend"] = info["Ŷ"][:, -1].copy()
+    model2 = es.LinModelOracle(*es.tf1_zoh(10.0, 2.0, 3.0), Ts=3.0)
+    kf2 = es.SteadyKalmanFilterOracle(model2)
+    mpc.setmodel(rep(kf2.Ah), rep(kf2.Bhu), rep(kf2.Ch))
+    out["u4"] = mpc.moveinput(np.zeros((B, kf.nxh)), [40.0]).copy()
+    return out

@@ -324,3 +324,15 @@ def test_setmodel_after_first_step_on_cpu_emulator(emulib):
     from tests.parity_util import setmodel_after_first_step
     cfg = synth.Config("setmodel", nx=2, nu=2, ny=2, Hp=6, Hc=3, umin=-0.8, umax=0.8, ymax=1.0)
     assert setmodel_after_first_step(lib=emulib, B=2, cfg=cfg) <= 1e-6
+
+
+@pytest.mark.slow
+def test_multiple_shooting_known_answers_on_cpu_emulator(emulib):
+    """f4 at the API level: `transcription="MultipleShooting"` (LinModel) -- the reference's own known answers,
+    and the returned [ΔU; X̂0; ϵ] satisfies the model equality constraints."""
+    from tests.parity_util import multiple_shooting_known_answers
+    r = multiple_shooting_known_answers(lib=emulib, B=1)
+    assert np.allclose(r["u3"], 3.0, atol=1e-2) and np.allclose(r["u4"], 4.0, atol=1e-2)
+    assert np.allclose(r["yend"], 15.0, atol=1e-2) and r["defect"] <= 1e-9 and r["yerr"] <= 1e-8
+    with pytest.raises(NotImplementedError, match="transcription"):
+        mpcqp.BatchLinMPC(np.eye(2)[None], np.ones((1, 2, 1)), np.ones((1, 1, 2)), Hp=4, transcription="OrthogonalCollocation", lib=emulib)

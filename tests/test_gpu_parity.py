@@ -522,3 +522,11 @@ def test_setmodel_after_first_step_on_gpu(hiplib):
     from tests.parity_util import setmodel_after_first_step
     assert setmodel_after_first_step(B=6, cfg=synth.C2) <= TOL
     assert setmodel_after_first_step(B=3, cfg=synth.C3) <= TOL
+
+
+def test_multiple_shooting_known_answers_on_gpu(hiplib):
+    """test/3_test_predictive_control.jl:570-579 (MultipleShooting, Hp = 1000, Hc = 1, setmodel!) through the C-ABI."""
+    from tests.parity_util import multiple_shooting_known_answers
+    r = multiple_shooting_known_answers(B=5)
+    assert np.allclose(r["u3"], 3.0, atol=1e-2) and np.allclose(r["u4"], 4.0, atol=1e-2)
+    assert np.allclose(r["yend"], 15.0, atol=1e-2) and r["defect"] <= 1e-9 and r["yerr"] <= 1e-8
