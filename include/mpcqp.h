@@ -248,6 +248,12 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
  *   mpcqp_prepare      after mpcqp_set_bounds (the pattern of constraint groups is part of the key):
  *                      compiles if needed (seconds, once per shape and machine), loads, returns the
  *                      MPCQP_KERNEL_* kind the steps will run on (>= 0) or a negative error code.
+ *                      An on-demand kernel that has not been checked on this machine is first compared
+ *                      with the runtime-dimension kernel on a few controllers of the handle (one cold
+ *                      step, pseudo-random states and set points); it is used only if the two agree
+ *                      (marker <object>.ok), otherwise it is renamed <object>.bad, the generic kernel
+ *                      is used and mpcqp_last_build_error says why.  Objects are keyed by the kernel
+ *                      revision AND the identity of the compiler binary that built them.
  *   mpcqp_kernel_kind  the kind a step would run on right now; never compiles.
  *   mpcqp_row_groups   the handle's pattern of constraint groups (bit g: group g may hold finite rows;
  *                      0 box lower [eps >= 0, hard dUmin], 1 box upper, 2 Umin, 3 Umax, 4 soft dUmin,

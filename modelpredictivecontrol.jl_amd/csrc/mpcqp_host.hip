@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -718,10 +719,79 @@ static thread_local std::string g_build_err;
 
 const char* mpcqp_last_build_error(void) { return g_build_err.c_str(); }
 
+// One cold-started step of the first few controllers of the handle on pseudo-random states / set points, once
+// with the on-demand specialisation and once with the runtime-dimension kernel: same iterates up to rounding.
+static int self_test_spec(mpcqp_handle h, double* worst) {
+    Dims d = h->d;
+    d.B = d.B < 8 ? d.B : 8;
+    d.flags = (d.flags | MPCQP_FLAG_COLD_START) & ~(uint32_t)(MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL);
+    const size_t n = d.B, nry = (d.flags & MPCQP_FLAG_RY_CONSTANT) ? d.ny : d.nY;
+    const size_t cnt[] = {n * d.nxh, n * d.nu, n * nry, n * (d.nd ? d.nd : 1), n * (d.nD ? d.nD : 1), n * d.nZ, n * d.nZ, n * d.nu, n * d.nu};
+    std::vector<double> host(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4], 0.0);
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&] { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
+    for (size_t i = 0; i < cnt[0]; ++i) host[i] = rnd();
+    for (size_t i = 0; i < cnt[2]; ++i) host[cnt[0] + cnt[1] + i] = 2.0 * rnd();
+    DBuf in, out, sti;
+    size_t total_in = host.size(), total_out = cnt[5] + cnt[6] + cnt[7] + cnt[8];
+    int rc = dev_alloc(h, in, total_in * sizeof(double));
+    if (!rc) rc = dev_alloc(h, out, total_out * sizeof(double));
+    if (!rc) rc = dev_alloc(h, sti, 4 * n * sizeof(int32_t));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(in.p, host.data(), total_in * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(out.p, 0, total_out * sizeof(double), h->stream));
+    double* pin = (double*)in.p;
+    double* pout = (double*)out.p;
+    int32_t* pst = (int32_t*)sti.p;
+    StepIO io{};
+    io.xhat0 = pin; io.lastu0 = pin + cnt[0]; io.Ry = pin + cnt[0] + cnt[1];
+    if (d.nd) { io.d0 = pin + cnt[0] + cnt[1] + cnt[2]; io.Dhat0 = io.d0 + cnt[3]; }
+    io.Z = pout; io.u0 = pout + cnt[5] + cnt[6]; io.status = pst; io.iters = pst + n;
+    HIPCHK(launch_step(d, h->m, io, h->stream));
+    io.Z = pout + cnt[5]; io.u0 = pout + cnt[5] + cnt[6] + cnt[7]; io.status = pst + 2 * n; io.iters = pst + 3 * n;
+    HIPCHK(launch_step_generic(d, h->m, io, h->stream));
+    std::vector<double> z(cnt[5] + cnt[6]);
+    std::vector<int32_t> s(4 * n);
+    HIPCHK(hipMemcpyAsync(z.data(), pout, z.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(s.data(), pst, s.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double scale = 1.0, diff = 0.0;
+    for (size_t i = 0; i < cnt[5]; ++i) {
+        scale = std::fmax(scale, std::fabs(z[cnt[5] + i]));
+        diff = std::fmax(diff, std::fabs(z[i] - z[cnt[5] + i]));
+        if (!(z[i] == z[i])) diff = INFINITY;
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (s[i] != s[2 * n + i]) diff = INFINITY;
+    *worst = diff / scale;
+    return MPCQP_OK;
+}
+
 int mpcqp_prepare(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
     g_build_err.clear();
-    return prepare_step(h->d, &g_build_err);
+    int kind = prepare_step(h->d, &g_build_err);
+    // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
+    // it with the runtime-dimension kernel once; needs the model and weights (BatchLinMPC prepares before its first step)
+    if (kind == MPCQP_KERNEL_ONDEMAND && !spec_verified(h->d) && h->have_model && h->have_weights &&
+        step_lds_bytes(h->d) <= 160 * 1024) {
+        ON_DEVICE(h);
+        double worst = 0.0;
+        int rc = self_test_spec(h, &worst);
+        if (rc) return rc;
+        const char* tol_env = getenv("MPCQP_JIT_SELFTEST_TOL");       // (tests force a rejection with a negative value)
+        const double tol = tol_env ? atof(tol_env) : 1e-6;
+        if (worst <= tol) {
+            mark_spec_verified(h->d);
+        } else {
+            reject_spec(h->d);
+            g_build_err = "the on-demand specialisation disagrees with the runtime-dimension kernel (relative difference " +
+                          std::to_string(worst) + "): rejected, the runtime-dimension kernel is used";
+            fprintf(stderr, "[mpcqp] %s\n", g_build_err.c_str());
+            kind = MPCQP_KERNEL_GENERIC;
+        }
+    }
+    return kind;
 }
 
 int mpcqp_kernel_kind(mpcqp_handle h) {

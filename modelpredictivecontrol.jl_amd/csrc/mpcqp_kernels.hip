@@ -129,10 +129,24 @@ static std::string cache_dir() {
     return d;
 }
 
+static std::string hipcc_path() {
+    const char* hipcc = getenv("HIPCC");
+    return hipcc && hipcc[0] ? hipcc : "/opt/rocm/bin/hipcc";
+}
+
+// identity of the compiler the on-demand kernels are built with (size and mtime of the binary): part of the
+// object name, so that a cache filled by another hipcc is not reused (the same 32-bit value as
+// __graft_entry__.py computes for the objects it pre-builds)
+static unsigned compiler_id() {
+    struct stat sb;
+    if (stat(hipcc_path().c_str(), &sb) != 0) return 0u;
+    return (unsigned)(((unsigned long long)sb.st_size * 1000003ull) ^ (unsigned long long)sb.st_mtime);
+}
+
 static std::string spec_name(const Dims& d) {
-    char name[192];
-    snprintf(name, sizeof name, "spec_r%d_%d_%d_%d_%d_%d_%d_%x_%d.so", MPCQP_KERNEL_REV, d.nu, d.ny, d.nxh,
-             d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
+    char name[224];
+    snprintf(name, sizeof name, "spec_r%d_c%08x_%d_%d_%d_%d_%d_%d_%x_%d.so", MPCQP_KERNEL_REV, compiler_id(), d.nu, d.ny,
+             d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
     return name;
 }
 
@@ -176,12 +190,11 @@ static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
         return -1;
     }
     const std::string src = lib_dir() + "/../csrc";
-    const char* hipcc = getenv("HIPCC");
     char dims[160];
     snprintf(dims, sizeof dims, "-DMPCQP_SPEC_DIMS=%d,%d,%d,%d,%d,%d,%uu,%d", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps,
              d.gmask, d.default_nb);
     const std::string tmp = so + ".tmp" + std::to_string((long)getpid());   // (ranks of one job may build the same object)
-    std::vector<std::string> argv = {hipcc && hipcc[0] ? hipcc : "/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3",
+    std::vector<std::string> argv = {hipcc_path(), "--offload-arch=gfx950", "-O3",
                                      "-std=c++17", "-shared", "-fPIC", "-w", "-I" + src, dims};
     if (const char* extra = getenv("MPCQP_JIT_FLAGS")) {
         std::string tok;
@@ -270,6 +283,31 @@ int prebuild_step(const Dims& d, std::string* err) {
     if (aot_matches(d)) return 1;
     if (!jit_enabled() || !spec_eligible(d)) return 0;
     return build_spec(d, nullptr, err) == 0 ? 2 : -1;
+}
+
+// A freshly built specialisation is checked once against the runtime-dimension kernel (mpcqp_prepare, host side)
+// before it is trusted: `<object>.ok` records that it passed, a failing object is renamed `<object>.bad` and never
+// loaded again (the local hipcc builds these kernels: a compiler that miscompiles them must not go unnoticed).
+bool spec_verified(const Dims& d) {
+    struct stat sb;
+    return stat((cache_dir() + "/" + spec_name(d) + ".ok").c_str(), &sb) == 0;
+}
+void mark_spec_verified(const Dims& d) {
+    if (FILE* f = fopen((cache_dir() + "/" + spec_name(d) + ".ok").c_str(), "w")) fclose(f);
+}
+void reject_spec(const Dims& d) {
+    const std::string so = cache_dir() + "/" + spec_name(d);
+    (void)rename(so.c_str(), (so + ".bad").c_str());
+    std::lock_guard<std::mutex> lock(g_spec_mu);
+    g_spec[SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb}] = SpecLib{};
+}
+
+hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
+    size_t lds = (size_t)make_carve(d).total * sizeof(double);
+    hipError_t e = ensure_lds((const void*)k_step, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_step, dim3(d.B), dim3(WAVE), lds, st, d, m, io);
+    return hipGetLastError();
 }
 
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {

@@ -15,6 +15,11 @@ size_t step_lds_bytes(const Dims& d);
 int step_kernel_kind(const Dims& d);
 int prepare_step(const Dims& d, std::string* err);     // compile (if needed) + load; returns the kind
 int prebuild_step(const Dims& d, std::string* err);    // compile only; -1 on failure
+// one-time check of an on-demand kernel against the runtime-dimension kernel (see mpcqp_prepare)
+bool spec_verified(const Dims& d);
+void mark_spec_verified(const Dims& d);
+void reject_spec(const Dims& d);
+hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
 hipError_t launch_kf_correct(const Dims& d, const Model& m, const KfParams& kf, double* xhat0,
                              const double* y0m, const double* d0, hipStream_t st);
 hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const double* u0,

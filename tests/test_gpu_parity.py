@@ -530,3 +530,28 @@ def test_multiple_shooting_known_answers_on_gpu(hiplib):
     r = multiple_shooting_known_answers(B=5)
     assert np.allclose(r["u3"], 3.0, atol=1e-2) and np.allclose(r["u4"], 4.0, atol=1e-2)
     assert np.allclose(r["yend"], 15.0, atol=1e-2) and r["defect"] <= 1e-9 and r["yerr"] <= 1e-8
+
+
+def test_rejected_specialisation_falls_back_to_generic_kernel(hiplib, tmp_path, monkeypatch):
+    """mpcqp_prepare checks a fresh on-demand kernel against the runtime-dimension kernel; one that fails the check
+    (forced here with a negative tolerance, in a private cache directory) is renamed *.bad and the handle runs --
+    correctly -- on the generic kernel."""
+    import os
+    monkeypatch.setenv("MPCQP_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("MPCQP_JIT_SELFTEST_TOL", "-1")
+    cfg = synth.Config("reject", nx=3, nu=2, ny=2, Hp=9, Hc=3, umin=-0.7, umax=0.7, ymax=0.8)
+    bt = synth.make_batch(cfg, 4, seed=5)
+    got = run_batch(cfg, bt)
+    assert got["mpc"].hd.kernel_kind() == mpcqp.api.KERNEL_GENERIC
+    files = os.listdir(tmp_path)
+    assert any(f.endswith(".so.bad") for f in files) and not any(f.endswith(".ok") for f in files)
+    ref = oracle_batch(cfg, bt)
+    assert np.all(got["status"] == 0) and rel_err(got["Z"], ref["Z"], cfg.nu * cfg.Hc).max() <= TOL
+    # the same shape with the check enabled normally: accepted
+    monkeypatch.setenv("MPCQP_JIT_SELFTEST_TOL", "1e-6")
+    for f in files:
+        os.remove(os.path.join(tmp_path, f))
+    cfg2 = synth.Config("accept", nx=3, nu=2, ny=2, Hp=10, Hc=3, umin=-0.7, umax=0.7, ymax=0.8)
+    bt2 = synth.make_batch(cfg2, 4, seed=5)
+    got2 = run_batch(cfg2, bt2)
+    assert got2["mpc"].hd.kernel_kind() == mpcqp.api.KERNEL_ONDEMAND and any(f.endswith(".ok") for f in os.listdir(tmp_path))
