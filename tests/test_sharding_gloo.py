@@ -82,7 +82,7 @@ def test_shard_range_partitions_the_batch():
 
 
 def test_two_rank_sharding_equals_single_run(emulib):
-    world, B = 2, 11                 # odd: the shards differ by one controller
+    world, B = 2, 5                  # odd: the shards differ by one controller
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -101,7 +101,7 @@ def test_two_rank_sharding_equals_single_run(emulib):
 
 def test_multi_device_handle_equals_single_handle(emulib):
     """mpcqp_multi_*: two shards (the emulator's one device twice) behind one handle."""
-    B = 7
+    B = 5
     bt = synth.make_batch(CFG, B, seed=9)
     Z1, u1, st1 = _solve(CFG, bt, emulib)
     Z2, u2, st2 = _solve(CFG, bt, emulib, multi=[0, 0])
