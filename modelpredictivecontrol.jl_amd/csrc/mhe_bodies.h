@@ -301,7 +301,12 @@ struct Solver {
     bool live;
     const double* cbase;   // constant blocks of this wavefront's first estimator (wave-uniform)
     int coff;           // this lane's offset into them: (b - first) * stride + r
-    double* sb;      // scratch of this wavefront (wave-uniform base; a slot is 64 doubles, one per lane)
+    double* sb;      // scratch of this wavefront (wave-uniform base)
+    // A slot holds one double per ACTIVE lane: the NX lanes of each of the four groups, packed (SW = 4 NX doubles;
+    // 384 B instead of 512 B for NX = 12 -- a quarter of the HBM traffic of the sweeps would be padding).
+    static constexpr int SW = GPW * NX;
+    typename W::Buf sbuf;     // buffer resource over this wavefront's scratch
+    unsigned lvo;             // this lane's byte offset inside a slot; out of range for the idle lanes (r >= NX)
     int first;       // first estimator of the wavefront's current group of four
     double* lds;     // this lane's column of the wave's LDS: Oc, OcT, Bmid rows
     int N, p;
@@ -312,13 +317,25 @@ struct Solver {
     MPCQP_HD Solver(W& w_, const Dims& d_, const Args& a_, double* smem, int wave_id)
         : w(w_), d(d_), a(a_), op{w_}, lane(w_.lane), r(w_.lane & (RL - 1)), g(w_.lane >> 4),
           cm(cst_map(NX, d_.nu, d_.nd)), sm(slot_map(NX, d_.He, d_.cls)) {
-        sb = a.scratch + (size_t)wave_id * d.nslot * WAVE;
+        sb = a.scratch + (size_t)wave_id * wave_scratch_doubles(NX, d.nslot);
+        sbuf = w.make_buf(sb, wave_scratch_doubles(NX, d.nslot) * sizeof(double));
+        lvo = r < NX ? (unsigned)((g * NX + r) * 8) : W::BUF_OOB;
         lds = smem + lane;
         N = d.N;
         p = d.direct ? 0 : 1;
         cX = (CM & CLS_X) && (d.cls & CLS_X); cW = (CM & CLS_W) && (d.cls & CLS_W); cV = (CM & CLS_V) && (d.cls & CLS_V);
     }
-    MPCQP_HD double& S(int slot) { return *O::at(w.uniform(sb + (size_t)slot * WAVE), lane); }
+    // Scratch accesses are raw buffer loads / stores: the slot offset is the instruction's scalar offset, the lane's
+    // byte offset ONE register for the whole kernel, and the idle lanes carry an out-of-range offset -- the
+    // hardware returns zero for their loads and drops their stores (no exec masking, no trash area).
+    MPCQP_HD double Sld(int slot) { return w.bload(sbuf, lvo, slot * (SW * 8)); }
+    MPCQP_HD void Sst(int slot, double v) { w.bstore(sbuf, lvo, slot * (SW * 8), v); }
+    MPCQP_HD void Sld_rows(int slot, Row& M) {
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] = w.bload(sbuf, lvo, (slot + c) * (SW * 8)); });
+    }
+    MPCQP_HD void Sst_rows(int slot, const Row& M) {
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; w.bstore(sbuf, lvo, (slot + c) * (SW * 8), M[c]); });
+    }
     MPCQP_HD const double* L_Oc() const { return lds; }
     MPCQP_HD const double* L_OcT() const { return lds + (size_t)NX * WAVE; }
     MPCQP_HD const double* L_Bmid() const { return lds + (size_t)2 * NX * WAVE; }
@@ -331,7 +348,7 @@ struct Solver {
     MPCQP_HD void load_O(int j, Row& Ob) {
         O::ld(L_Oc(), WAVE, Ob);
         if (cW) {
-            const double Dp = S(sm.WD + j);
+            const double Dp = Sld(sm.WD + j);
             Row Ap;
             O::ldo(w.uniform(cbase + cm.A), coff, RL, Ap);
             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ob[c] -= Dp * Ap[c]; });
@@ -409,32 +426,32 @@ struct Solver {
     };
     enum { K_F0, K_F1, K_B0, K_B1, K_U };
     MPCQP_HD void load_rows(int slot, RowIn& q) {
-        q.s0 = S(slot + 0); q.l0 = S(slot + 1); q.s1 = S(slot + 2); q.l1 = S(slot + 3);
+        q.s0 = Sld(slot + 0); q.l0 = Sld(slot + 1); q.s1 = Sld(slot + 2); q.l1 = Sld(slot + 3);
     }
     template <int K>
     MPCQP_HD void load_stage(int s, StageIn& in) {
         constexpr bool fwd = K == K_F0 || K == K_F1, ph1 = K == K_F1 || K == K_B1;
         const int im = meas_of(s);
-        in.x = fwd ? (s < N ? S(sm.X + s + 1) : 0.0) : S(sm.X + s);
-        in.a0 = S((K == K_F0 ? sm.Q : K == K_F1 ? sm.RD : K == K_U ? sm.DX : sm.T) + s);
-        if (K == K_F1 || K == K_B1 || K == K_U) in.dxa = S(sm.DXA + s);
+        in.x = fwd ? (s < N ? Sld(sm.X + s + 1) : 0.0) : Sld(sm.X + s);
+        in.a0 = Sld((K == K_F0 ? sm.Q : K == K_F1 ? sm.RD : K == K_U ? sm.DX : sm.T) + s);
+        if (K == K_F1 || K == K_B1 || K == K_U) in.dxa = Sld(sm.DXA + s);
         if (cX) load_rows(sm.XR + 4 * s, in.xr);
         if (cW && s < N) {
             load_rows(sm.WR + 4 * s, in.wr);
-            if (K == K_F0) in.gs = S(sm.G + s);
-            else in.ww = S(sm.WW + s);
-            if (ph1 || K == K_U) in.wga = S(sm.WGA + s);
-            if (K == K_U) in.wg = S(sm.WG + s);
-            if (K == K_B0 || K == K_B1) in.wd = S(sm.WD + s);
+            if (K == K_F0) in.gs = Sld(sm.G + s);
+            else in.ww = Sld(sm.WW + s);
+            if (ph1 || K == K_U) in.wga = Sld(sm.WGA + s);
+            if (K == K_U) in.wg = Sld(sm.WG + s);
+            if (K == K_B0 || K == K_B1) in.wd = Sld(sm.WD + s);
         }
         if (cV && im >= 0) {
             load_rows(sm.VR + 4 * im, in.vr);
-            if (K == K_F0) in.es = S(sm.E + im);
-            else in.vv = S(sm.VV + im);
-            if (ph1 || K == K_U) in.vga = S(sm.VGA + im);
-            if (K == K_U) in.vg = S(sm.VG + im);
+            if (K == K_F0) in.es = Sld(sm.E + im);
+            else in.vv = Sld(sm.VV + im);
+            if (ph1 || K == K_U) in.vga = Sld(sm.VGA + im);
+            if (K == K_U) in.vg = Sld(sm.VG + im);
         }
-        if (K == K_F1 || K == K_B0 || K == K_B1) O::ldo(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, in.Si);
+        if (K == K_F1 || K == K_B0 || K == K_B1) Sld_rows(sm.SI + s * NX, in.Si);
     }
     // stages 0..N (forward) or N..0 with the inputs of stage s +- DEPTH already in flight while stage s computes
     template <int K, int DEPTH, class F>
@@ -491,7 +508,7 @@ struct Solver {
             double xc = xbar, gprev = 0.0;
             for (int s = 0; s <= N; ++s) {
                 const double gs = s < N ? g_of(s) : 0.0;
-                if (s < N) S(sm.G + s) = gs;
+                if (s < N) Sst(sm.G + s, gs);
                 double q = 0.0;
                 if (s == 0) {
                     O::ldo(a.Pi2 + (size_t)first * NX * RL, (b - first) * NX * RL + r, RL, T);
@@ -509,25 +526,25 @@ struct Solver {
                 double ei = 0.0;
                 if (i >= 0) {
                     ei = e_of(i);
-                    S(sm.E + i) = ei;
+                    Sst(sm.E + i, ei);
                     O::ldo(w.uniform(cbase + cm.CR), coff, RL, T);
                     q -= op.mv(T, ei);
                 }
-                S(sm.Q + s) = q;
-                S(sm.X + s) = xc;
+                Sst(sm.Q + s, q);
+                Sst(sm.X + s, xc);
                 // rows of this stage
                 if (cX) {
                     const double s0 = fmax(xc - xlo, 1.0), s1 = fmax(xhi - xc, 1.0);
-                    S(sm.XR + 4 * s + 0) = s0; S(sm.XR + 4 * s + 1) = lam0 / s0;
-                    S(sm.XR + 4 * s + 2) = s1; S(sm.XR + 4 * s + 3) = lam0 / s1;
+                    Sst(sm.XR + 4 * s + 0, s0); Sst(sm.XR + 4 * s + 1, lam0 / s0);
+                    Sst(sm.XR + 4 * s + 2, s1); Sst(sm.XR + 4 * s + 3, lam0 / s1);
                     m_l += (hxlo ? 1 : 0) + (hxhi ? 1 : 0);
                     if (hxlo) nh_l = fmax(nh_l, fabs(xlo) + 1.0);
                     if (hxhi) nh_l = fmax(nh_l, fabs(xhi) + 1.0);
                 }
                 if (cW && s < N) {          // ŵ(s) = 0 at the starting point
                     const double s0 = fmax(0.0 - wlo, 1.0), s1 = fmax(whi - 0.0, 1.0);
-                    S(sm.WR + 4 * s + 0) = s0; S(sm.WR + 4 * s + 1) = lam0 / s0;
-                    S(sm.WR + 4 * s + 2) = s1; S(sm.WR + 4 * s + 3) = lam0 / s1;
+                    Sst(sm.WR + 4 * s + 0, s0); Sst(sm.WR + 4 * s + 1, lam0 / s0);
+                    Sst(sm.WR + 4 * s + 2, s1); Sst(sm.WR + 4 * s + 3, lam0 / s1);
                     m_l += (hwlo ? 1 : 0) + (hwhi ? 1 : 0);
                     if (hwlo) nh_l = fmax(nh_l, fabs(wlo) + 1.0);
                     if (hwhi) nh_l = fmax(nh_l, fabs(whi) + 1.0);
@@ -536,8 +553,8 @@ struct Solver {
                     O::ldo(w.uniform(cbase + cm.Cm), coff, RL, T);
                     const double vv = ei - op.mv(T, xc);
                     const double s0 = fmax(vv - vlo, 1.0), s1 = fmax(vhi - vv, 1.0);
-                    S(sm.VR + 4 * i + 0) = s0; S(sm.VR + 4 * i + 1) = lam0 / s0;
-                    S(sm.VR + 4 * i + 2) = s1; S(sm.VR + 4 * i + 3) = lam0 / s1;
+                    Sst(sm.VR + 4 * i + 0, s0); Sst(sm.VR + 4 * i + 1, lam0 / s0);
+                    Sst(sm.VR + 4 * i + 2, s1); Sst(sm.VR + 4 * i + 3, lam0 / s1);
                     m_l += (hvlo ? 1 : 0) + (hvhi ? 1 : 0);
                     if (hvlo) nh_l = fmax(nh_l, fabs(vlo) + 1.0);
                     if (hvhi) nh_l = fmax(nh_l, fabs(vhi) + 1.0);
@@ -568,7 +585,7 @@ struct Solver {
                 double rpn_l = 0.0, mu_l = 0.0, rdn_l = 0.0, ndd_l = 0.0;
                 {
                     Row Si, Oprev, Bs, U;
-                    double xm = 0.0, xc = S(sm.X + 0), tprev = 0.0;
+                    double xm = 0.0, xc = Sld(sm.X + 0), tprev = 0.0;
                     double dd_carry = 0.0, gl_carry = 0.0, cr_carry = 0.0;
                     auto stage = [&](int s, StageIn& in) {
                         const double xp = in.x;
@@ -599,7 +616,7 @@ struct Solver {
                         if (cW && s < N) {
                             O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
                             double wv;
-                            if (!phase) { wv = xp - op.mv(A, xc) - in.gs; S(sm.WW + s) = wv; }
+                            if (!phase) { wv = xp - op.mv(A, xc) - in.gs; Sst(sm.WW + s, wv); }
                             else wv = in.ww;
                             const RowIn& q = in.wr;
                             const double rp0 = -wv + q.s0 + wlo, rp1 = wv + q.s1 - whi;
@@ -608,7 +625,7 @@ struct Solver {
                             const RowK k0 = row_rhs(hwlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hwhi, q.s1, q.l1, rp1, e1, delta);
                             const double lw = (hwhi ? q.l1 : 0.0) - (hwlo ? q.l0 : 0.0), cw = k1.c - k0.c;
                             Dtw = k0.Dt + k1.Dt;
-                            if (!phase) S(sm.WD + s) = Dtw;
+                            if (!phase) Sst(sm.WD + s, Dtw);
                             Row At;
                             O::ldo(w.uniform(cbase + cm.At), coff, RL, At);
                             gl -= op.mv(At, lw);
@@ -622,7 +639,7 @@ struct Solver {
                             Row Cm;
                             O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
                             double vv;
-                            if (!phase) { vv = in.es - op.mv(Cm, xc); S(sm.VV + im) = vv; }
+                            if (!phase) { vv = in.es - op.mv(Cm, xc); Sst(sm.VV + im, vv); }
                             else vv = in.vv;
                             const RowIn& q = in.vr;
                             const double rp0 = -vv + q.s0 + vlo, rp1 = vv + q.s1 - vhi;
@@ -631,7 +648,7 @@ struct Solver {
                             const RowK k0 = row_rhs(hvlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hvhi, q.s1, q.l1, rp1, e1, delta);
                             const double lv = (hvhi ? q.l1 : 0.0) - (hvlo ? q.l0 : 0.0), cv = k1.c - k0.c;
                             Dtv = k0.Dt + k1.Dt;
-                            if (!phase) S(sm.VD + im) = Dtv;
+                            if (!phase) Sst(sm.VD + im, Dtv);
                             Row Ct;
                             O::ldo(w.uniform(cbase + cm.Ct), coff, RL, Ct);
                             gl -= op.mv(Ct, lv);            // v̂ = e - Ĉm x: the rows' gradient is -Ĉm'
@@ -646,7 +663,7 @@ struct Solver {
                             if (s < N) { O::ld(L_OcT(), WAVE, U); hz += op.mv(U, xp); }
                             const double q = in.a0;
                             rd = hz + q + gl;
-                            S(sm.RD + s) = rd;
+                            Sst(sm.RD + s, rd);
                             rdn_l = fmax(rdn_l, fabs(rd));
                             ndd_l = fmax(ndd_l, fmax(fabs(q), fmax(fabs(hz), fabs(gl))));
                         } else {
@@ -694,12 +711,12 @@ struct Solver {
                             }
                             ok = op.gj(Bs, r) && ok;
                             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Si[c] = Bs[c]; });
-                            O::sto(w.uniform(sb + (size_t)(sm.SI + s * NX) * WAVE), lane, WAVE, Si);
+                            Sst_rows(sm.SI + s * NX, Si);
                         } else {
                             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Si[c] = in.Si[c]; });
                         }
                         const double t = op.mv(Si, rhs - otp);
-                        S(sm.T + s) = t;
+                        Sst(sm.T + s, t);
                         tprev = t;
                         MPCQP_SCHED_FENCE();
                         xm = xc; xc = xp;
@@ -760,13 +777,13 @@ struct Solver {
                             }
                             dx -= op.mv(in.Si, u);
                         }
-                        S(sDX + s) = dx;
+                        Sst(sDX + s, dx);
                         if (cX) rows2(hxlo, hxhi, in.xr, in.x, xlo, xhi, in.dxa, dx);
                         if (cW && s < N) {
                             Row A;
                             O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
                             const double gd = dxn - op.mv(A, dx);
-                            S((phase ? sm.WG : sm.WGA) + s) = gd;
+                            Sst((phase ? sm.WG : sm.WGA) + s, gd);
                             rows2(hwlo, hwhi, in.wr, in.ww, wlo, whi, in.wga, gd);
                         }
                         const int im = meas_of(s);
@@ -774,7 +791,7 @@ struct Solver {
                             Row Cm;
                             O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
                             const double gd = -op.mv(Cm, dx);
-                            S((phase ? sm.VG : sm.VGA) + im) = gd;
+                            Sst((phase ? sm.VG : sm.VGA) + im, gd);
                             rows2(hvlo, hvhi, in.vr, in.vv, vlo, vhi, in.vga, gd);
                         }
                         dxn = dx;
@@ -808,15 +825,15 @@ struct Solver {
                         row_dir(true, q.s0, q.l0, rp0, -gda, 0.0, delta, ds, dl);
                         const double e = ds * dl - smu;
                         row_dir(true, q.s0, q.l0, rp0, -gd, e, delta, ds, dl);
-                        S(slot + 0) = q.s0 + al * ds;
-                        S(slot + 1) = q.l0 + al * dl;
+                        Sst(slot + 0, q.s0 + al * ds);
+                        Sst(slot + 1, q.l0 + al * dl);
                     }
                     if (h1) {
                         row_dir(true, q.s1, q.l1, rp1, gda, 0.0, delta, ds, dl);
                         const double e = ds * dl - smu;
                         row_dir(true, q.s1, q.l1, rp1, gd, e, delta, ds, dl);
-                        S(slot + 2) = q.s1 + al * ds;
-                        S(slot + 3) = q.l1 + al * dl;
+                        Sst(slot + 2, q.s1 + al * ds);
+                        Sst(slot + 3, q.l1 + al * dl);
                     }
                 };
                 auto stage = [&](int s, StageIn& in) {
@@ -827,7 +844,7 @@ struct Solver {
                     if (cV && im >= 0) upd2(hvlo, hvhi, sm.VR + 4 * im, in.vr, in.vv, vlo, vhi, in.vga, in.vg);
                     zm_l = fmax(zm_l, fabs(xc));
                     dm_l = fmax(dm_l, fabs(al * dx));
-                    S(sm.X + s) = xc + al * dx;
+                    Sst(sm.X + s, xc + al * dx);
                 };
                 sweep<K_U, MPCQP_MHE_DEPTH_U>(true, stage);
                 const double dm = w.rmax(dm_l), zm = w.rmax(zm_l);
@@ -851,12 +868,12 @@ struct Solver {
         O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
         const bool bad = st == 2;
         // a failed solve keeps the open-loop window: x(0) = x̄, ŵ = 0 (the starting point)
-        double xc = bad ? xbar : S(sm.X + 0);
+        double xc = bad ? xbar : Sld(sm.X + 0);
         if (live && a.Zt && r < nx) a.Zt[(size_t)b * (nx + He * nx) + r] = xc;
         for (int s = 0; s < N; ++s) {
-            const double gs = S(sm.G + s);
+            const double gs = Sld(sm.G + s);
             const double ax = op.mv(A, xc) + gs;
-            const double xn = bad ? ax : S(sm.X + s + 1);
+            const double xn = bad ? ax : Sld(sm.X + s + 1);
             if (live && r < nx) {
                 if (a.Zt) a.Zt[(size_t)b * (nx + He * nx) + nx + s * nx + r] = xn - ax;
                 if (a.Xhat) a.Xhat[(size_t)b * He * nx + s * nx + r] = xn;
@@ -870,12 +887,12 @@ struct Solver {
         if (live && a.Zt && r < nx)
             for (int s = N; s < He; ++s) a.Zt[(size_t)b * (nx + He * nx) + nx + s * nx + r] = 0.0;
         if (a.Vhat) {
-            double xs = bad ? xbar : S(sm.X + 0);
+            double xs = bad ? xbar : Sld(sm.X + 0);
             for (int s = 0; s <= N; ++s) {
                 const int i = meas_of(s);
                 const double cx = op.mv(Cm, xs);
-                if (i >= 0 && live && r < nym) a.Vhat[(size_t)b * He * nym + i * nym + r] = S(sm.E + i) - cx;
-                if (s < N) xs = bad ? op.mv(A, xs) + S(sm.G + s) : S(sm.X + s + 1);
+                if (i >= 0 && live && r < nym) a.Vhat[(size_t)b * He * nym + i * nym + r] = Sld(sm.E + i) - cx;
+                if (s < N) xs = bad ? op.mv(A, xs) + Sld(sm.G + s) : Sld(sm.X + s + 1);
             }
         }
         if (live) {

@@ -21,6 +21,20 @@ struct MheDevWave : DevWave {
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return (T*)(((uint64_t)hi << 32) | lo);
     }
+    // raw buffer access to a wave-private array: scalar (slot) offset + one per-lane byte offset; a lane whose
+    // offset is BUF_OOB reads zero and its stores are dropped by the bounds check of the buffer resource
+    using Buf = __amdgpu_buffer_rsrc_t;
+    static constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
+    __device__ __forceinline__ Buf make_buf(double* base, size_t bytes) const {
+        return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+    }
+    __device__ __forceinline__ double bload(Buf b, unsigned voff, int soff) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b, voff, soff, 0));
+    }
+    __device__ __forceinline__ void bstore(Buf b, unsigned voff, int soff, double v) const {
+        using V = decltype(__builtin_amdgcn_raw_buffer_load_b64(b, 0u, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(V, v), b, voff, soff, 0);
+    }
     // acc += sum_i (x_i of lane L_i of this lane's row) * y_i: the broadcast is the DPP modifier of the
     // multiply-add itself.  One asm block per four terms: the hardware does not interlock a DPP read of a
     // VGPR that a VALU instruction wrote within the previous two wait states, and the compiler's hazard

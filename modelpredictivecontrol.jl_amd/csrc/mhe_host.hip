@@ -54,7 +54,7 @@ static int up(mpcqp_mhe h, double* dst, const double* src, size_t n) {
 static int ensure_scratch(mpcqp_mhe h) {
     const mhe::SlotMap sm = mhe::slot_map(h->d.NX, h->d.He, h->d.cls);
     h->d.nslot = sm.total;
-    const size_t need = (size_t)h->d.nwaves * sm.total * WAVE * sizeof(double);
+    const size_t need = (size_t)h->d.nwaves * mhe::wave_scratch_doubles(h->d.NX, sm.total) * sizeof(double);
     if (need <= h->scratch_bytes) return MPCQP_OK;
     void* p = nullptr;
     int rc = dalloc(h, &p, need);

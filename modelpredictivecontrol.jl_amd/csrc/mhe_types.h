@@ -32,7 +32,7 @@ struct Dims {
     int max_iter;
     double gap_tol, res_tol, dual_reg;
     int nwaves;        // wavefronts launched (each loops over groups of four estimators)
-    int nslot;         // 64-double slots of scratch per wavefront
+    int nslot;         // slots of scratch per wavefront (a slot = one double per active lane, 4 NX doubles)
     int cst_stride;    // doubles per estimator in the constant block
     uint32_t opt;      // experiment switches (MPCQP_MHE_OPT), 0 in production
 };
@@ -74,6 +74,9 @@ MPCQP_HD inline SlotMap slot_map(int NX, int He, uint32_t cls) {
     return m;
 }
 
+// doubles of scratch per wavefront: nslot packed slots (one double per active lane)
+MPCQP_HD inline size_t wave_scratch_doubles(int NX, int nslot) { return (size_t)nslot * GPW * NX + WAVE; }
+
 struct Raw {               // inputs of mpcqp_mhe_set_model (ABI layout: column-major inside an estimator)
     const double *Ahat, *Bu, *Cm, *Bd, *Ddm, *fx;    // [B][nx*nx] [B][nx*nu] [B][nym*nx] [B][nx*nd] [B][nym*nd] [B][nx] (fx may be null)
     const double *Q, *R;                             // [B][nx*nx] [B][nym*nym]
@@ -90,7 +93,7 @@ struct Args {
     double* Zt;                  // [B][nx + He nx]  out: [x̂0arr; Ŵ] (reference order, zero beyond Nk), may be null
     double *Vhat, *Xhat;         // optional outs: [B][He nym], [B][He nx]
     int32_t *status, *iters;
-    double* scratch;             // [nwaves][nslot][64]
+    double* scratch;             // [nwaves][wave_scratch_doubles(NX, nslot)]
 };
 
 }  // namespace mhe

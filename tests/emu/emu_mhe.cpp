@@ -40,6 +40,17 @@ struct EmuWave {
     double rowbc(double v) { return xchg(v)[(lane & ~(RL - 1)) + C]; }
     template <class T>
     T* uniform(T* p) const { return p; }
+    struct Buf { double* p; size_t bytes; };
+    static constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
+    Buf make_buf(double* base, size_t bytes) const { return Buf{base, bytes}; }
+    double bload(Buf b, unsigned voff, int soff) const {
+        const size_t o = (size_t)voff + (size_t)soff;
+        return (voff == BUF_OOB || o + 8 > b.bytes) ? 0.0 : *(const double*)((const char*)b.p + o);
+    }
+    void bstore(Buf b, unsigned voff, int soff, double v) const {
+        const size_t o = (size_t)voff + (size_t)soff;
+        if (voff != BUF_OOB && o + 8 <= b.bytes) *(double*)((char*)b.p + o) = v;
+    }
     template <int L0, int L1, int L2, int L3>
     void fmabc4(double& acc, double x0, double x1, double x2, double x3, double y0, double y1, double y2, double y3) {
         acc = fma(rowbc<L0>(x0), y0, acc); acc = fma(rowbc<L1>(x1), y1, acc);
