@@ -134,6 +134,15 @@ int mpcqp_set_flags(mpcqp_handle h, uint32_t flags);
  * couples different prediction steps is not supported (MPCQP_ERR_UNSUPPORTED on the host side).  */
 int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk);
 
+/* Dense (Hermitian) weight matrices, the reference's M_Hp=, N_Hc=, L_Hp= keywords in full generality
+ * (src/controller/construct.jl:45-93, 837-845; linmpc.jl:205-214): M_Hp (nY,nY,B) may couple different
+ * prediction steps, N_Hc (nDU,nDU,B) different moves, L_Hp (nU,nU,B) different inputs/steps.  Each replaces the
+ * corresponding diagonal of mpcqp_set_weights (NULL: keep the diagonal / block form); call after
+ * mpcqp_set_weights.  H~ is rebuilt (K2, runtime-dimension kernel).  With a dense M_Hp or L_Hp the step
+ * evaluates M (F - R^y) and L (Tu lastu0 - R^u) densely and runs on the runtime-dimension kernel; a dense N_Hc
+ * only changes H~ and keeps the specialised step kernels.                                           */
+int mpcqp_set_dense_weights(mpcqp_handle h, const double* M_Hp, const double* N_Hc, const double* L_Hp);
+
 /* Custom linear inequality constraints over k .. k+Hp (keywords Wy, Wu, Wd, Wr of LinMPC,
  * src/controller/construct.jl:666-694; relaxW :1086-1160; linconstraint_custom!,
  * src/controller/execute.jl:337-364):

@@ -35,7 +35,7 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_loop_device", "mpcqp_recondense_device",
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_last_predmat_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
-           "mpcqp_set_output_weight_blocks", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
+           "mpcqp_set_output_weight_blocks", "mpcqp_set_dense_weights", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
            "mpcqp_set_flags", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_row_groups", "mpcqp_prebuild",
            "mpcqp_last_build_error", "mpcqp_multi_create", "mpcqp_multi_destroy", "mpcqp_multi_ndev",
            "mpcqp_multi_handle", "mpcqp_multi_shard", "mpcqp_multi_set_model", "mpcqp_multi_set_weights",
@@ -95,6 +95,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_weights.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_set_bounds.argtypes = [C.c_void_p, C.POINTER(Bounds)]
     lib.mpcqp_set_output_weight_blocks.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpcqp_set_dense_weights.argtypes = [C.c_void_p] * 4
     lib.mpcqp_set_flags.argtypes = [C.c_void_p, C.c_uint32]
     lib.mpcqp_set_custom_constraints.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     lib.mpcqp_set_custom_bounds.argtypes = [C.c_void_p] + [C.c_void_p] * 4
@@ -201,6 +202,11 @@ class Handle:
         """Mblk (B, Hp, ny, ny), symmetric blocks, or None (back to the diagonal weight)."""
         a = None if Mblk is None else _f64(np.asarray(Mblk, float).transpose(0, 1, 3, 2))
         _chk(self.lib, self.lib.mpcqp_set_output_weight_blocks(self.h, _ptr(a)))
+
+    def set_dense_weights(self, M_Hp=None, N_Hc=None, L_Hp=None):
+        """Dense symmetric weights (B, n, n) or None; they replace the diagonals of set_weights."""
+        arrs = [None if a is None else colmajor(a) for a in (M_Hp, N_Hc, L_Hp)]
+        _chk(self.lib, self.lib.mpcqp_set_dense_weights(self.h, *[_ptr(a) for a in arrs]))
 
     def set_flags(self, flags):
         _chk(self.lib, self.lib.mpcqp_set_flags(self.h, int(flags)))
@@ -457,7 +463,7 @@ class BatchLinMPC:
     """
 
     def __init__(self, Ahat, Bhu, Chat, Bhd=None, Dhd=None, *, Hp, Hc=2, Mwt=None, Nwt=None,
-                 Lwt=None, M_Hp=None, Cwt=1e5, Wy=None, Wu=None, Wd=None, Wr=None, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
+                 Lwt=None, M_Hp=None, N_Hc=None, L_Hp=None, Cwt=1e5, Wy=None, Wu=None, Wd=None, Wr=None, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
                  cold_start=False, keep_qp=False, warm_dual=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
                  transcription="SingleShooting", lib=None):
         # `transcription` (LinMPC keyword, linmpc.jl:288-316).  For a LinModel the MultipleShooting QP
@@ -503,7 +509,7 @@ class BatchLinMPC:
         self.Uop, self.Yop, self.Dop = np.tile(self.uop, Hp), np.tile(self.yop, Hp), np.tile(self.dop, Hp)
         self.Cwt = cw
         self.setmodel(Ahat, Bhu, Chat, Bhd, Dhd)
-        self.setweights(Mwt, Nwt, Lwt, M_Hp=M_Hp)
+        self.setweights(Mwt, Nwt, Lwt, M_Hp=M_Hp, N_Hc=N_Hc, L_Hp=L_Hp)
         # custom linear constraints (validate_custom_lincon, src/controller/construct.jl:666-694)
         given = [np.asarray(W, float) for W in (Wy, Wu, Wd, Wr) if W is not None]
         self.nw = 0
@@ -555,10 +561,12 @@ class BatchLinMPC:
                           None if self.nd == 0 else colmajor(Dhd),
                           dopv if np.any(dopv != 0) else None)
 
-    def setweights(self, Mwt=None, Nwt=None, Lwt=None, M_Hp=None):
-        """Defaults of src/general.jl:3-6 (Mwt=1, Nwt=0.1, Lwt=0).  `M_Hp` (nY,nY) or (B,nY,nY) is the
-        reference's `M_Hp=` keyword (src/controller/linmpc.jl:205-214) for block-diagonal weights
-        blkdiag(M_1..M_Hp) with symmetric ny x ny blocks, e.g. a terminal cost; it overrides Mwt."""
+    def setweights(self, Mwt=None, Nwt=None, Lwt=None, M_Hp=None, N_Hc=None, L_Hp=None):
+        """Defaults of src/general.jl:3-6 (Mwt=1, Nwt=0.1, Lwt=0).  `M_Hp` (nY,nY), `N_Hc` (nΔU,nΔU), `L_Hp`
+        (nU,nU) -- each also (B,n,n) -- are the reference's full weight matrices (src/controller/linmpc.jl:205-214,
+        construct.jl:45-93); they override the per-channel vectors.  A block-diagonal M_Hp = blkdiag(M_1..M_Hp)
+        (e.g. a terminal cost) keeps the specialised step kernels; an M_Hp or L_Hp that couples different prediction
+        steps runs on the runtime-dimension kernel; a dense N_Hc only changes H̃."""
         B, Hp, Hc, ny = self.B, self.Hp, self.Hc, self.ny
         w = lambda v, n, dflt: (np.full((B, n), dflt) if v is None
                                 else np.broadcast_to(np.asarray(v, float), (B, n)).copy())
@@ -569,27 +577,40 @@ class BatchLinMPC:
         self.Mwt, self.Nwt, self.Lwt = M, N, L
         self.hd.set_weights(np.tile(M, Hp), np.tile(N, Hc), np.tile(L, Hp),
                             self.Cwt if self.neps else None)
-        self.Mblk = None
-        if M_Hp is not None:
-            Mf = np.asarray(M_Hp, float)
-            if Mf.shape == (self.nY, self.nY):
-                Mf = np.broadcast_to(Mf, (B, self.nY, self.nY))
-            if Mf.shape != (B, self.nY, self.nY):
-                raise ValueError(f"M_Hp size should be ({self.nY}, {self.nY})")
+
+        def full(Mx, n, name):
+            if Mx is None:
+                return None
+            Mf = np.asarray(Mx, float)
+            if Mf.shape == (n, n):
+                Mf = np.broadcast_to(Mf, (B, n, n))
+            if Mf.shape != (B, n, n):
+                raise ValueError(f"{name} size should be ({n}, {n})")
             if not np.allclose(Mf, Mf.transpose(0, 2, 1), rtol=0, atol=1e-12 * max(1.0, np.abs(Mf).max())):
-                raise ValueError("M_Hp should be Hermitian")
+                raise ValueError(f"{name} should be Hermitian")
+            return np.ascontiguousarray(Mf)
+
+        self.Mblk, self.Mfull = None, None
+        Mf, self.Ndense, self.Ldense = full(M_Hp, self.nY, "M_Hp"), full(N_Hc, self.nDU, "N_Hc"), full(L_Hp, self.nU, "L_Hp")
+        if Mf is not None:
             blk = np.stack([Mf[:, t * ny:(t + 1) * ny, t * ny:(t + 1) * ny] for t in range(Hp)], axis=1)
             off = Mf.copy()
             for t in range(Hp):
                 off[:, t * ny:(t + 1) * ny, t * ny:(t + 1) * ny] = 0.0
             if np.any(off != 0.0):
-                raise NotImplementedError("M_Hp coupling different prediction steps is not supported "
-                                          "(MPCQP_ERR_UNSUPPORTED): only blkdiag(M_1..M_Hp)")
-            self.Mblk = blk
-            self.hd.set_output_weight_blocks(blk)
+                self.Mfull = Mf                      # couples different prediction steps: dense path
+            else:
+                self.Mblk = blk
+        if self.Mblk is not None:
+            self.hd.set_output_weight_blocks(self.Mblk)
         elif getattr(self, "_had_blocks", False):
             self.hd.set_output_weight_blocks(None)
-        self._had_blocks = M_Hp is not None
+        self._had_blocks = self.Mblk is not None
+        dense = (self.Mfull, self.Ndense, self.Ldense)
+        if any(a is not None for a in dense) or getattr(self, "_had_dense", False):
+            self.hd.set_dense_weights(*dense)
+        self._had_dense = any(a is not None for a in dense)
+        self._prepared = False
 
     # -- constraints --------------------------------------------------------------------------
     def setconstraint(self, *, umin=None, umax=None, Δumin=None, Δumax=None, ymin=None, ymax=None,
@@ -854,13 +875,18 @@ class BatchLinMPC:
             info["Ŷ"] = self._Yhat0 + self.Yop
             # J = (Ŷ-R̂y)'M(Ŷ-R̂y) + ΔU'N ΔU + (U-R̂u)'L(U-R̂u) + C ϵ²   (obj_nonlinprog!, general.jl:107 with r)
             ey, eu = info["Ŷ"] - Rhaty, info["U"] - Rhatu
-            if self.Mblk is not None:
+            if getattr(self, "Mfull", None) is not None:
+                Jy = np.einsum("bi,bij,bj->b", ey, self.Mfull, ey)
+            elif self.Mblk is not None:
                 eyb = ey.reshape(self.B, Hp, ny)
                 Jy = np.einsum("bti,btij,btj->b", eyb, self.Mblk, eyb)
             else:
                 Jy = np.sum(np.tile(self.Mwt, Hp) * ey * ey, axis=1)
-            info["J"] = (Jy + np.sum(np.tile(self.Nwt, Hc) * DU * DU, axis=1) + np.sum(np.tile(self.Lwt, Hp) * eu * eu, axis=1)
-                         + (self.Cwt * eps * eps if self.neps else 0.0))
+            Jdu = (np.einsum("bi,bij,bj->b", DU, self.Ndense, DU) if getattr(self, "Ndense", None) is not None
+                   else np.sum(np.tile(self.Nwt, Hc) * DU * DU, axis=1))
+            Ju = (np.einsum("bi,bij,bj->b", eu, self.Ldense, eu) if getattr(self, "Ldense", None) is not None
+                  else np.sum(np.tile(self.Lwt, Hp) * eu * eu, axis=1))
+            info["J"] = Jy + Jdu + Ju + (self.Cwt * eps * eps if self.neps else 0.0)
             if self.nw > 0:       # W = Wy ŷe + Wu ue + Wd d̂e + Wr r̂e   (execute.jl:221, relaxW)
                 xhat0, Rhaty, d0, Dh0 = self._winfo
                 Hp, ny, nd = self.Hp, self.ny, self.nd

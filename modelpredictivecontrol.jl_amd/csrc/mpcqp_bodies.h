@@ -611,6 +611,37 @@ struct Qp {
         }
     }
 
+    // E[(t,a),(j,cc)] = Σ(t - j_j)[a,cc] for t >= j_j, else 0   (transcription.jl:134-139)
+    MPCQP_HD double Eat(int t, int a, int j, int cc) const {
+        const int t0 = jl(j);
+        return t >= t0 ? S[(t - t0) * sp + a * rs + cc] : 0.0;
+    }
+
+    // P[pk(i,i')] += scale * E[:,i]' M E[:,i'] for a DENSE symmetric M_Hp (nY x nY, column-major), one column
+    // i' at a time: v = M E[:,i'] into `tmp` (nY doubles of LDS), then the dot products with E[:,i], i >= i'.
+    // Set-up path only (K2): nΔU (nY² + nY nΔU) multiply-adds.
+    MPCQP_HD void EtMfullE_add(const double* Mf, double* tmp, double* P, double scale) {
+        const int ny = d.ny, nu = d.nu, nDU = d.nDU, nY = d.nY;
+        for (int ip = 0; ip < nDU; ++ip) {
+            const int j2 = ip / nu, c2 = ip - j2 * nu;
+            for (int r = w.lane; r < nY; r += WAVE) {
+                double acc = 0.0;
+                for (int t = jl(j2); t < d.Hp; ++t)
+                    for (int a = 0; a < ny; ++a) acc += Mf[r + (size_t)nY * (t * ny + a)] * Eat(t, a, j2, c2);
+                tmp[r] = acc;
+            }
+            w.sync();
+            for (int i = ip + w.lane; i < nDU; i += WAVE) {
+                const int j = i / nu, cc = i - j * nu;
+                double acc = 0.0;
+                for (int t = jl(j); t < d.Hp; ++t)
+                    for (int a = 0; a < ny; ++a) acc += Eat(t, a, j, cc) * tmp[t * ny + a];
+                P[pk(i, ip)] += scale * acc;
+            }
+            w.sync();
+        }
+    }
+
     // ex̂[i,(j,c)]
     MPCQP_HD double Xat(int i, int k) const {
         const int j = k / d.nu, cc = k - j * d.nu;
@@ -764,10 +795,11 @@ MPCQP_HD void hessian_body(W& w, const DM& d, const Model& m, int b, double* sm)
     double* P = qp.Phi;
     double* tY = sm + qp.c.tA[P_Y];
     for (int i = w.lane; i < d.npk; i += WAVE) P[i] = 0.0;
-    if (!m.Mblk)
+    if (!m.Mblk && !m.Mfull)
         for (int i = w.lane; i < d.nY; i += WAVE) tY[i] = m.Mdiag[(size_t)b * d.nY + i];
     w.sync();
-    if (m.Mblk) qp.EtMblkE_add(m.Mblk + (size_t)b * d.Hp * d.ny * d.ny, P, 2.0);
+    if (m.Mfull) qp.EtMfullE_add(m.Mfull + (size_t)b * d.nY * d.nY, tY, P, 2.0);
+    else if (m.Mblk) qp.EtMblkE_add(m.Mblk + (size_t)b * d.Hp * d.ny * d.ny, P, 2.0);
     else qp.EtDE_add(tY, P, 2.0);                               // 2 E'ME
     w.sync();
     const int nu = d.nu;
@@ -777,10 +809,26 @@ MPCQP_HD void hessian_body(W& w, const DM& d, const Model& m, int b, double* sm)
     const double* L = m.Ldiag + (size_t)b * d.nU;
     for (int i = w.lane; i < d.nDU; i += WAVE) {
         const int j = i / nu, cc = i - j * nu;
-        double suf = 0.0;
-        for (int t = qp.jl(j); t < d.Hp; ++t) suf += L[t * nu + cc];
-        for (int j2 = 0; j2 <= j; ++j2) P[pk(i, j2 * nu + cc)] += 2.0 * suf;
-        P[pk(i, i)] += 2.0 * m.Ndiag[(size_t)b * d.nDU + i];    // 2 N
+        if (m.Ldense) {        // dense L_Hp: entry ((j,c),(j',c')) = sum_{t >= j_j} sum_{t' >= j_j'} L[(t,c),(t',c')]
+            const double* Lf = m.Ldense + (size_t)b * d.nU * d.nU;
+            for (int ip = 0; ip <= i; ++ip) {
+                const int j2 = ip / nu, c2 = ip - j2 * nu;
+                double acc = 0.0;
+                for (int t = qp.jl(j); t < d.Hp; ++t)
+                    for (int t2 = qp.jl(j2); t2 < d.Hp; ++t2) acc += Lf[(t * nu + cc) + (size_t)d.nU * (t2 * nu + c2)];
+                P[pk(i, ip)] += 2.0 * acc;
+            }
+        } else {
+            double suf = 0.0;
+            for (int t = qp.jl(j); t < d.Hp; ++t) suf += L[t * nu + cc];
+            for (int j2 = 0; j2 <= j; ++j2) P[pk(i, j2 * nu + cc)] += 2.0 * suf;
+        }
+        if (m.Ndense) {        // dense N_Hc
+            const double* Nf = m.Ndense + (size_t)b * d.nDU * d.nDU;
+            for (int ip = 0; ip <= i; ++ip) P[pk(i, ip)] += 2.0 * Nf[i + (size_t)d.nDU * ip];
+        } else {
+            P[pk(i, i)] += 2.0 * m.Ndiag[(size_t)b * d.nDU + i];    // 2 N
+        }
     }
     if (d.neps && w.lane == 0) P[pk(d.nZ - 1, d.nZ - 1)] = 2.0 * m.Cwt[b];    // Ñ = blkdiag(N, C)
     w.sync();
@@ -1047,7 +1095,14 @@ struct Step {
         auto cy = [&](int r) {
             return F[r] - (rconst ? io.Ry[(size_t)b * ny + (r % ny)] : io.Ry[(size_t)b * nY + r]);
         };
-        if (m.Mblk) {          // block-diagonal M_Hp: (M Cy)[t,a] = sum_a' M_t[a,a'] Cy[t,a']
+        if (!DM::is_static && m.Mfull) {      // dense M_Hp: M (F - R̂y), column-major symmetric (coalesced over r)
+            const double* Mf = m.Mfull + (size_t)b * nY * nY;
+            for (int r = w.lane; r < nY; r += WAVE) {
+                double acc = 0.0;
+                for (int r2 = 0; r2 < nY; ++r2) acc += Mf[r + (size_t)nY * r2] * cy(r2);
+                tY[r] = acc;
+            }
+        } else if (m.Mblk) {          // block-diagonal M_Hp: (M Cy)[t,a] = sum_a' M_t[a,a'] Cy[t,a']
             const double* Mb = m.Mblk + (size_t)b * d.Hp * ny * ny;
             for (int r = w.lane; r < nY; r += WAVE) {
                 const int t = r / ny, a = r - t * ny;
@@ -1065,9 +1120,18 @@ struct Step {
         for (int k = w.lane; k < d.nDU; k += WAVE) {
             const int j = k / nu, cc = k - j * nu;
             double acc = 0.0;
-            for (int t = qp.jl(j); t < d.Hp; ++t) {
-                const double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cc] : 0.0;
-                acc += Ld[t * nu + cc] * (lu[cc] - ru);
+            if (!DM::is_static && m.Ldense) {    // dense L_Hp: (Pu' L (Tu lastu0 - R̂u))[k]
+                const double* Lf = m.Ldense + (size_t)b * d.nU * d.nU;
+                for (int t = qp.jl(j); t < d.Hp; ++t)
+                    for (int r2 = 0; r2 < d.nU; ++r2) {
+                        const double ru = io.Ru ? io.Ru[(size_t)b * d.nU + r2] : 0.0;
+                        acc += Lf[(t * nu + cc) + (size_t)d.nU * r2] * (lu[r2 % nu] - ru);
+                    }
+            } else {
+                for (int t = qp.jl(j); t < d.Hp; ++t) {
+                    const double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cc] : 0.0;
+                    acc += Ld[t * nu + cc] * (lu[cc] - ru);
+                }
             }
             q[k] += 2.0 * acc;       // same lane wrote q[k] in Et_apply_add
         }

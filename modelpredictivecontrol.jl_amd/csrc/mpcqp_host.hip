@@ -33,7 +33,7 @@ struct mpcqp_handle_s {
     std::vector<int> nb, jl, blk;
     std::vector<void*> owned;
     // model / weights / bounds storage
-    DBuf Ahat, Bu, C, Bd, Dd, dop, Mdiag, Ndiag, Ldiag, Cwt, Mblk;
+    DBuf Ahat, Bu, C, Bd, Dd, dop, Mdiag, Ndiag, Ldiag, Cwt, Mblk, Mfull, Ndense, Ldense;
     DBuf Wy, Wu, Wd, Wr, w_op, Wmin, Wmax, C_wmin, C_wmax, ry_now;
     DBuf bnd[16];
     // staging for the host-pointer step
@@ -319,6 +319,29 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
     if (h->have_model) {
         HIPCHK(launch_hessian(d, h->m, h->stream));
     }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+int mpcqp_set_dense_weights(mpcqp_handle h, const double* M_Hp, const double* N_Hc, const double* L_Hp) {
+    if (!h) return MPCQP_ERR_NULL;
+    Dims& d = h->d;
+    if (!h->have_weights) return MPCQP_ERR_ORDER;       // the diagonals and C come from mpcqp_set_weights
+    ON_DEVICE(h);
+    struct { const double* src; DBuf* buf; const double** dst; size_t n; } w[3] = {
+        {M_Hp, &h->Mfull, &h->m.Mfull, (size_t)d.nY}, {N_Hc, &h->Ndense, &h->m.Ndense, (size_t)d.nDU},
+        {L_Hp, &h->Ldense, &h->m.Ldense, (size_t)d.nU}};
+    for (auto& e : w) {
+        if (e.src) {
+            int rc = upload(h, *e.buf, e.src, (size_t)d.B * e.n * e.n * sizeof(double));
+            if (rc) return rc;
+            *e.dst = (const double*)e.buf->p;
+        } else {
+            *e.dst = nullptr;
+        }
+    }
+    d.dense_w = (h->m.Mfull || h->m.Ldense) ? 1 : 0;     // (a dense N_Hc only changes H̃: any step kernel serves it)
+    if (h->have_model) HIPCHK(launch_hessian(d, h->m, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }

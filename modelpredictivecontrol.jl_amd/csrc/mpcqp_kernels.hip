@@ -156,7 +156,7 @@ static bool jit_enabled() {
 }
 
 static bool spec_eligible(const Dims& d) {     // (custom linear constraints and nZ~ > 64 run on the runtime-dims kernel)
-    return d.nw == 0 && d.nZ <= WAVE;
+    return d.nw == 0 && d.nZ <= WAVE && !d.dense_w;
 }
 
 // run `argv` (argv[0] = binary), stdout+stderr appended to `log`; returns the exit status, -1 on failure to start
@@ -256,7 +256,7 @@ static bool aot_matches(const Dims& d) {
 // Which kernel a step of `d` runs on: 0 the runtime-dimension kernel, 1 an ahead-of-time
 // specialisation, 2 an on-demand one (already loaded or loadable from the cache).
 int step_kernel_kind(const Dims& d) {
-    if (force_generic()) return 0;
+    if (force_generic() || d.dense_w) return 0;
     if (aot_matches(d)) return 1;
     return find_spec(d, true) ? 2 : 0;
 }
@@ -264,7 +264,7 @@ int step_kernel_kind(const Dims& d) {
 // Make the specialised kernel of `d` available (compile if needed, load).  Returns the kernel kind
 // as step_kernel_kind(); `err` receives the reason when an eligible specialisation could not be built.
 int prepare_step(const Dims& d, std::string* err) {
-    if (force_generic()) return 0;
+    if (force_generic() || d.dense_w) return 0;
     if (aot_matches(d)) return 1;
     if (!jit_enabled() || !spec_eligible(d)) return 0;
     if (find_spec(d, true)) return 2;
@@ -312,7 +312,7 @@ hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, 
 
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
     // (a block-diagonal M_Hp takes the scalar contraction of the runtime-dims kernel: set-up path)
-    if (!force_generic() && !m.Mblk) {
+    if (!force_generic() && !m.Mblk && !m.Mfull && !m.Ndense && !m.Ldense) {
 #define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
         {                                                                           \
             using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                   \
@@ -330,7 +330,7 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
 }
 
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
-    if (!force_generic()) {
+    if (!force_generic() && !d.dense_w) {      // (dense M_Hp / L_Hp: runtime-dimension kernel, like custom constraints)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
         {                                                                           \
             using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                   \

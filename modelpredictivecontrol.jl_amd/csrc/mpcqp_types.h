@@ -62,6 +62,7 @@ struct Dims {
     int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
     int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh, nW
     int default_nb;          // 1 iff nb = [1,..,1,Hp-Hc+1]
+    int dense_w;             // 1 iff a dense M_Hp or L_Hp is set: the step runs on the runtime-dimension kernel
     int max_iter;
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
@@ -90,6 +91,10 @@ struct Model {
     // weights
     const double *Mdiag, *Ndiag, *Ldiag, *Cwt;
     const double* Mblk;   // optional [B][Hp][ny][ny]: block-diagonal M_Hp (symmetric blocks), replaces Mdiag
+    // optional dense (symmetric) weights, column-major per problem; they replace the diagonals (runtime-dimension kernels only)
+    const double* Mfull;  // [B][nY][nY]    M_Hp coupling different prediction steps
+    const double* Ndense; // [B][nDU][nDU]  N_Hc
+    const double* Ldense; // [B][nU][nU]    L_Hp
     // bounds + softness (null = group absent / default softness)
     const double *U0min, *U0max, *DUmin, *DUmax, *Y0min, *Y0max, *x0min, *x0max;
     const double *C_umin, *C_umax, *C_dumin, *C_dumax, *C_ymin, *C_ymax, *c_x0min, *c_x0max;

@@ -103,7 +103,7 @@ hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStrea
 }
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
     const char* fg = getenv("MPCQP_FORCE_GENERIC");
-    if (!(fg && fg[0] == '1')) {
+    if (!(fg && fg[0] == '1') && !m.Mfull && !m.Ndense && !m.Ldense) {
 #define XNB(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 0)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 1)
 #define XX(NU, NY, NXH, HP, HC, NEPS, GM, NB)                                                  \
@@ -126,7 +126,7 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
 }
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
     const char* fg = getenv("MPCQP_FORCE_GENERIC");
-    if (!(fg && fg[0] == '1')) {
+    if (!(fg && fg[0] == '1') && !d.dense_w) {
 #define XNB(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 0)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 1)
 #define XX(NU, NY, NXH, HP, HC, NEPS, GM, NB)                                                  \

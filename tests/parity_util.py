@@ -598,3 +598,44 @@ def multiple_shooting_known_answers(lib=None, B=2):
     mpc.setmodel(rep(kf2.Ah), rep(kf2.Bhu), rep(kf2.Ch))
     out["u4"] = mpc.moveinput(np.zeros((B, kf.nxh)), [40.0]).copy()
     return out
+
+
+def dense_weight_case(lib=None, B=3, which=("M", "N", "L"), seed=0):
+    """Full Hermitian weight matrices (M_Hp coupling prediction steps, N_Hc coupling moves, L_Hp coupling
+    inputs/steps: construct.jl:45-93, 837-845) against the oracle, with input bounds active and a soft output
+    bound, a time-varying R̂u, different plants per controller.  Returns (worst rel ΔU error, kernel kind)."""
+    cfg = synth.Config("dense-w", nx=3, nu=2, ny=2, Hp=7, Hc=3, umin=-0.7, umax=0.7, ymax=0.9)
+    bt = synth.make_batch(cfg, B, seed=30 + seed)
+    rng = np.random.default_rng(seed)
+    nY, nDU, nU = cfg.ny * cfg.Hp, cfg.nu * cfg.Hc, cfg.nu * cfg.Hp
+
+    def spd(n, scale, diag):
+        R = rng.standard_normal((n, n))
+        return scale * (R @ R.T) / n + np.diag(np.full(n, diag))
+
+    kw = {}
+    if "M" in which:
+        kw["M_Hp"] = spd(nY, 0.8, 0.5)
+    if "N" in which:
+        kw["N_Hc"] = spd(nDU, 0.2, 0.1)
+    if "L" in which:
+        kw["L_Hp"] = spd(nU, 0.1, 0.05)
+    mpc = mpcqp.BatchLinMPC(bt["Ahat"], bt["Bhu"], bt["Chat"], Hp=cfg.Hp, Hc=cfg.Hc, Cwt=cfg.Cwt, lib=lib, **kw)
+    mpc.setconstraint(**constraint_kwargs(cfg))
+    mpc.lastu0 = bt["lastu0"].copy()
+    Ru = 0.3 * rng.standard_normal((B, nU))
+    mpc.moveinput(bt["xhat0"], bt["ry"], Rhatu=Ru, want_info=True)
+    info = mpc.getinfo()
+    assert np.all(mpc.status == 0), mpc.status
+    worst = 0.0
+    for i in range(B):
+        m = cd.LinMPCOracle(bt["Ahat"][i], bt["Bhu"][i], bt["Chat"][i], Hp=cfg.Hp, Hc=cfg.Hc, Cwt=cfg.Cwt, **kw)
+        m.setconstraint(**constraint_kwargs(cfg, oracle=True))
+        m.initpred(bt["xhat0"][i], bt["lastu0"][i], bt["ry"][i], Rhatu=Ru[i])
+        m.linconstraint()
+        z, st, oinfo = qp.solve_qp(*m.qp_data(), m.warmstart(), return_info=True)
+        assert st == 0
+        worst = max(worst, np.abs(mpc.Z[i, :nDU] - z[:nDU]).max() / max(1.0, np.abs(z[:nDU]).max()))
+        Jo = 0.5 * z @ m.Ht @ z + m.qt @ z + m.r
+        assert abs(info["J"][i] - Jo) <= 1e-6 * max(1.0, abs(Jo)), (info["J"][i], Jo)
+    return worst, mpc.hd.kernel_kind()

@@ -336,3 +336,13 @@ def test_multiple_shooting_known_answers_on_cpu_emulator(emulib):
     assert np.allclose(r["yend"], 15.0, atol=1e-2) and r["defect"] <= 1e-9 and r["yerr"] <= 1e-8
     with pytest.raises(NotImplementedError, match="transcription"):
         mpcqp.BatchLinMPC(np.eye(2)[None], np.ones((1, 2, 1)), np.ones((1, 1, 2)), Hp=4, transcription="OrthogonalCollocation", lib=emulib)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("which", [("N",), ("M",), ("L",), ("M", "N", "L")], ids=["N_Hc", "M_Hp", "L_Hp", "all"])
+def test_dense_weight_matrices_on_cpu_emulator(emulib, which):
+    """Full Hermitian M_Hp / N_Hc / L_Hp (construct.jl:45-93, 837-845) vs the oracle; a dense N_Hc alone keeps the
+    handle eligible for a specialised step kernel, a dense M_Hp or L_Hp selects the runtime-dimension kernel."""
+    from tests.parity_util import dense_weight_case
+    worst, kind = dense_weight_case(lib=emulib, B=2, which=which)
+    assert worst <= 1e-6, worst

@@ -154,3 +154,53 @@ def test_config5_batch_constrained_full_size():
     assert np.abs(info["X̂"]).max() <= cfg.xabs + 1e-8 and np.abs(info["x̂arr"]).max() <= cfg.xabs + 1e-8
     frac_active = np.mean(np.abs(info["X̂"]).max(axis=1) >= cfg.xabs - 1e-6)
     assert frac_active > 0.05                               # the workload does exercise the constraints
+
+
+def test_closed_loop_mhe_feeds_linmpc():
+    """Both device paths in one loop, like `sim!` with a MovingHorizonEstimator inside a LinMPC
+    (src/plot_sim.jl, controller/execute.jl:59-80): plant -> ym -> BatchMHE.preparestate -> BatchLinMPC.moveinput ->
+    u -> BatchMHE.updatestate, against the same loop on oracle/mhe.py + oracle/condense.py, estimator by estimator."""
+    from oracle import condense as cd, qp
+    cfg = synth.MheConfig("loop", nx=3, nu=2, nym=2, nd=0, He=5, xabs=2.5)
+    B, Hp, Hc = 6, 8, 3
+    bt = synth.make_mhe_batch(cfg, B, seed=13)
+    rng = np.random.default_rng(5)
+    est = mhe_util.make_product(cfg, bt)
+    ors = mhe_util.make_oracles(cfg, bt, range(B))
+    mpc = mpcqp.BatchLinMPC(bt["Ahat"], bt["Bhu"], bt["Chm"], Hp=Hp, Hc=Hc, Mwt=[1.0, 1.0], Nwt=[0.1, 0.1], Cwt=1e5)
+    mpc.setconstraint(umin=[-0.8, -0.8], umax=[0.8, 0.8], ymax=[1.2, 1.2])
+    omp = []
+    for b in range(B):
+        m = cd.LinMPCOracle(bt["Ahat"][b], bt["Bhu"][b], bt["Chm"][b], Hp=Hp, Hc=Hc, Mwt=[1.0, 1.0], Nwt=[0.1, 0.1], Cwt=1e5)
+        m.setconstraint(umin=[-0.8, -0.8], umax=[0.8, 0.8], ymax=[1.2, 1.2])
+        omp.append(m)
+    xg = 0.3 * rng.standard_normal((B, cfg.nx))          # plant states driven by the PRODUCT's inputs
+    xo = xg.copy()                                       # ... and by the oracle loop's inputs
+    ry = np.array([0.6, -0.4])
+    lu_o = np.zeros((B, cfg.nu))
+    worst_x = worst_u = 0.0
+    for k in range(9):
+        v = cfg.sigmaR * rng.standard_normal((B, cfg.nym))
+        yg = np.einsum("bij,bj->bi", bt["C"], xg) + v
+        yo = np.einsum("bij,bj->bi", bt["C"], xo) + v
+        xhat = est.preparestate(yg)
+        assert np.all(est.status == 0)
+        ug = mpc.moveinput(xhat, ry)
+        assert np.all(mpc.status == 0)
+        est.updatestate(ug, yg)
+        uo = np.zeros_like(ug)
+        for b, (e, m) in enumerate(zip(ors, omp)):
+            xh = e.preparestate(yo[b])
+            m.initpred(xh, lu_o[b], ry)
+            m.linconstraint()
+            z, st, _ = qp.solve_qp(*m.qp_data(), m.warmstart(), return_info=True)
+            m.Zt = z
+            uo[b] = z[:cfg.nu] + lu_o[b]
+            e.updatestate(uo[b], yo[b])
+            worst_x = max(worst_x, np.abs(xhat[b] - xh).max() / max(1.0, np.abs(xh).max()))
+        worst_u = max(worst_u, np.abs(ug - uo).max())
+        lu_o = uo.copy()
+        w = cfg.sigmaQ * rng.standard_normal((B, cfg.nx))
+        xg = np.einsum("bij,bj->bi", bt["A"], xg) + np.einsum("bij,bj->bi", bt["Bu"], ug) + w
+        xo = np.einsum("bij,bj->bi", bt["A"], xo) + np.einsum("bij,bj->bi", bt["Bu"], uo) + w
+    assert worst_x <= 1e-5 and worst_u <= 1e-5, (worst_x, worst_u)

@@ -555,3 +555,12 @@ def test_rejected_specialisation_falls_back_to_generic_kernel(hiplib, tmp_path, 
     bt2 = synth.make_batch(cfg2, 4, seed=5)
     got2 = run_batch(cfg2, bt2)
     assert got2["mpc"].hd.kernel_kind() == mpcqp.api.KERNEL_ONDEMAND and any(f.endswith(".ok") for f in os.listdir(tmp_path))
+
+
+@pytest.mark.parametrize("which", [("N",), ("M",), ("L",), ("M", "N", "L")], ids=["N_Hc", "M_Hp", "L_Hp", "all"])
+def test_dense_weight_matrices_on_gpu(hiplib, which):
+    """Full Hermitian M_Hp (coupling prediction steps), N_Hc, L_Hp through the C-ABI vs the oracle (ΔU and J)."""
+    from tests.parity_util import dense_weight_case
+    worst, kind = dense_weight_case(B=5, which=which)
+    assert worst <= TOL, worst
+    assert kind == (mpcqp.api.KERNEL_ONDEMAND if which == ("N",) else mpcqp.api.KERNEL_GENERIC)
