@@ -15,8 +15,9 @@
  *
  * Supported: nx̂ <= 16, nym <= 16 (one estimator per 16-lane DPP row), any nu, nd, He; both forms
  * (direct = true/false); growing and moving windows; hard bounds on x̂ (arrival state and window), ŵ, v̂
- * given per channel; Cwt = Inf (the reference's default: no slack variable).  Soft constraints (finite
- * Cwt) and bounds that change along the window (X̂min / Ŵmin / V̂min vectors): MPCQP_ERR_UNSUPPORTED.
+ * given per channel, hard (Cwt = Inf, the reference's default) or relaxed by one slack variable ε (finite Cwt and
+ * softness c per channel, mpcqp_mhe_set_softness).  Bounds that change along the window (X̂min / Ŵmin / V̂min vectors):
+ * not supported.
  * There is no CPU fallback: every compute entry point needs a HIP device. */
 #ifndef MPCQP_MHE_H
 #define MPCQP_MHE_H
@@ -60,6 +61,13 @@ int mpcqp_mhe_set_model(mpcqp_mhe h, const double* Ahat, const double* Bhu, cons
 int mpcqp_mhe_set_bounds(mpcqp_mhe h, const double* xmin, const double* xmax, const double* wmin, const double* wmax,
                          const double* vmin, const double* vmax);
 
+/* Soft constraints (MovingHorizonEstimator(...; Cwt) + setconstraint!(estim; c_x̂min, ..., c_v̂max), construct.jl:858-1049,
+ * 1151-1288): Cwt (B) finite weights of ε² (NULL: Cwt = Inf, hard constraints only, the reference's default) and the
+ * softness c >= 0 of each channel's rows, (nx̂,B) / (nym,B) or NULL (= 0: hard).  A row reads  g'z - c ε <= h  with one
+ * slack ε >= 0 per estimator.  Softness without a finite Cwt: MPCQP_ERR_ARG (ArgumentError in the reference).      */
+int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin, const double* c_xmax, const double* c_wmin,
+                           const double* c_wmax, const double* c_vmin, const double* c_vmax);
+
 /* init_estimate_cov!: empties the data windows (Nk = 0), x̂0 <- xhat0 (nx̂,B; NULL: zeros), arrival
  * covariance P̄ <- P0 (nx̂,nx̂,B; required), d0(-1) <- d0_prev (nd,B; NULL: zeros), lastu0 (nu,B; NULL: zeros). */
 int mpcqp_mhe_init(mpcqp_mhe h, const double* xhat0, const double* P0, const double* d0_prev, const double* lastu0);
@@ -85,6 +93,7 @@ int mpcqp_mhe_sync(mpcqp_mhe h);
 #define MPCQP_MHE_PBAR     4   /* (nx̂,nx̂,B)       arrival covariance P̄                                  */
 #define MPCQP_MHE_VHAT     5   /* (He nym,B)       V̂ of the last solve  (MPCQP_MHE_KEEP_WINDOWS)          */
 #define MPCQP_MHE_XHATWIN  6   /* (He nx̂,B)        X̂0 of the last solve (MPCQP_MHE_KEEP_WINDOWS)          */
+#define MPCQP_MHE_EPSILON  7   /* (B)              slack ε of the last solve (after mpcqp_mhe_set_softness)     */
 int mpcqp_mhe_get(mpcqp_mhe h, int what, void* out);
 /* device address of one of the arrays above (NULL if not kept) */
 void* mpcqp_mhe_device_ptr(mpcqp_mhe h, int what);

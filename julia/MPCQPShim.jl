@@ -191,7 +191,6 @@ end
 
 function BatchMHE(estims::Vector{<:MovingHorizonEstimator}; device::Integer=0)
     e = estims[1]; B = length(estims); model = e.model
-    isinf(e.C) || error("finite Cwt (soft constraints) is not supported by libmpcqp's MHE path")
     d = MheDims(B, e.nx̂, model.nu, e.nym, model.nd, e.He, e.direct ? 1 : 0, device, 0, 0, 0.0, 0.0, 0.0)
     h = Ref{Ptr{Cvoid}}()
     check(ccall((:mpcqp_mhe_create, lib), Cint, (Ref{MheDims}, Ref{Ptr{Cvoid}}), d, h))
@@ -209,6 +208,12 @@ function BatchMHE(estims::Vector{<:MovingHorizonEstimator}; device::Integer=0)
           Ptr{Float64}, Ptr{Float64}), h[],
           cat2(c -> c.con.x̂0min), cat2(c -> c.con.x̂0max), cat2(c -> first(c.con.Ŵmin, nx̂)), cat2(c -> first(c.con.Ŵmax, nx̂)),
           cat2(c -> first(c.con.V̂min, nym)), cat2(c -> first(c.con.V̂max, nym))))
+    if !isinf(e.C)         # soft constraints: Cwt and the softness of each channel (first column block of the A_* matrices)
+        check(ccall((:mpcqp_mhe_set_softness, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+              Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], [c.C for c in estims],
+              cat2(c -> -c.con.A_x̂min[:, 1]), cat2(c -> -c.con.A_x̂max[:, 1]), cat2(c -> -Vector(c.con.A_Ŵmin[1:nx̂, 1])),
+              cat2(c -> -Vector(c.con.A_Ŵmax[1:nx̂, 1])), cat2(c -> -c.con.A_V̂min[1:nym, 1]), cat2(c -> -c.con.A_V̂max[1:nym, 1])))
+    end
     x̂0 = cat2(c -> c.x̂0)
     check(ccall((:mpcqp_mhe_init, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[],
           x̂0, cat3(c -> c.cov.P̂_0), nd > 0 ? cat2(c -> c.D0[1:nd]) : C_NULL, cat2(c -> c.lastu0)))

@@ -313,6 +313,8 @@ struct Solver {
     bool cX, cW, cV;
     double xlo, xhi, wlo, whi, vlo, vhi;
     bool hxlo, hxhi, hwlo, hwhi, hvlo, hvhi;
+    bool cS;                                   // a slack variable ε >= 0 relaxes the rows with softness c > 0
+    double cx0, cx1, cw0, cw1, cv0, cv1;       // softness of this lane's rows (0: hard)
 
     MPCQP_HD Solver(W& w_, const Dims& d_, const Args& a_, double* smem, int wave_id)
         : w(w_), d(d_), a(a_), op{w_}, lane(w_.lane), r(w_.lane & (RL - 1)), g(w_.lane >> 4),
@@ -324,6 +326,7 @@ struct Solver {
         N = d.N;
         p = d.direct ? 0 : 1;
         cX = (CM & CLS_X) && (d.cls & CLS_X); cW = (CM & CLS_W) && (d.cls & CLS_W); cV = (CM & CLS_V) && (d.cls & CLS_V);
+        cS = (CM & CLS_S) && (d.cls & CLS_S);
     }
     // Scratch accesses are raw buffer loads / stores: the slot offset is the instruction's scalar offset, the lane's
     // byte offset ONE register for the whole kernel, and the idle lanes carry an out-of-range offset -- the
@@ -422,29 +425,40 @@ struct Solver {
         double ww, wga, wg, wd;      // ŵ(s), affine / final direction of the ŵ rows, D̃w(s)
         double vv, vga, vg;          // v̂(im), directions of the v̂ rows
         double gs, es;               // g(s), e(im)
+        double phi, tp, psi;         // slack column φ(s) of the Newton matrix, its forward solve, ψ(s) = (Φxx⁻¹φ)(s)
         Row Si;
     };
-    enum { K_F0, K_F1, K_B0, K_B1, K_U };
+    enum { K_F0, K_F1, K_B0, K_B1, K_U, K_R0, K_R1 };      // K_R*: row pass of the soft variant
     MPCQP_HD void load_rows(int slot, RowIn& q) {
         q.s0 = Sld(slot + 0); q.l0 = Sld(slot + 1); q.s1 = Sld(slot + 2); q.l1 = Sld(slot + 3);
     }
     template <int K>
     MPCQP_HD void load_stage(int s, StageIn& in) {
-        constexpr bool fwd = K == K_F0 || K == K_F1, ph1 = K == K_F1 || K == K_B1;
+        constexpr bool fwd = K == K_F0 || K == K_F1, ph1 = K == K_F1 || K == K_B1 || K == K_R1;
+        constexpr bool rowpass = K == K_R0 || K == K_R1;
         const int im = meas_of(s);
         in.x = fwd ? (s < N ? Sld(sm.X + s + 1) : 0.0) : Sld(sm.X + s);
-        in.a0 = Sld((K == K_F0 ? sm.Q : K == K_F1 ? sm.RD : K == K_U ? sm.DX : sm.T) + s);
-        if (K == K_F1 || K == K_B1 || K == K_U) in.dxa = Sld(sm.DXA + s);
-        if (cX) load_rows(sm.XR + 4 * s, in.xr);
+        in.a0 = Sld((K == K_F0 ? sm.Q : K == K_F1 ? sm.RD : (K == K_U || K == K_R1) ? sm.DX : K == K_R0 ? sm.DXA : sm.T) + s);
+        if (K == K_F1 || K == K_B1 || K == K_U || K == K_R1) in.dxa = Sld(sm.DXA + s);
+        if (cS) {
+            if (K == K_B0 || K == K_B1) in.phi = Sld(sm.PHI + s);
+            if (K == K_B0) in.tp = Sld(sm.TP + s);
+            if (rowpass) in.psi = Sld(sm.PSI + s);
+        }
+        // (the backward solve sweeps of the soft variant do no row work: the rows wait for dε, see run())
+        const bool rows = !(cS && (K == K_B0 || K == K_B1));
+        if (cX && rows) load_rows(sm.XR + 4 * s, in.xr);
         if (cW && s < N) {
-            load_rows(sm.WR + 4 * s, in.wr);
-            if (K == K_F0) in.gs = Sld(sm.G + s);
-            else in.ww = Sld(sm.WW + s);
-            if (ph1 || K == K_U) in.wga = Sld(sm.WGA + s);
-            if (K == K_U) in.wg = Sld(sm.WG + s);
+            if (rows) {
+                load_rows(sm.WR + 4 * s, in.wr);
+                if (K == K_F0) in.gs = Sld(sm.G + s);
+                else in.ww = Sld(sm.WW + s);
+                if (ph1 || K == K_U) in.wga = Sld(sm.WGA + s);
+                if (K == K_U) in.wg = Sld(sm.WG + s);
+            }
             if (K == K_B0 || K == K_B1) in.wd = Sld(sm.WD + s);
         }
-        if (cV && im >= 0) {
+        if (cV && im >= 0 && rows) {
             load_rows(sm.VR + 4 * im, in.vr);
             if (K == K_F0) in.es = Sld(sm.E + im);
             else in.vv = Sld(sm.VV + im);
@@ -497,7 +511,14 @@ struct Solver {
         wlo = bnd(a.wmin, cW, nx, -BIG); whi = bnd(a.wmax, cW, nx, BIG);
         vlo = bnd(a.vmin, cV, nym, -BIG); vhi = bnd(a.vmax, cV, nym, BIG);
         hxlo = xlo > -BIG; hxhi = xhi < BIG; hwlo = wlo > -BIG; hwhi = whi < BIG; hvlo = vlo > -BIG; hvhi = vhi < BIG;
+        auto sft = [&](const double* p_, bool on, int n) { return (cS && on && p_ && r < n) ? p_[(size_t)b * RL + r] : 0.0; };
+        cx0 = sft(a.cxmin, cX, nx); cx1 = sft(a.cxmax, cX, nx); cw0 = sft(a.cwmin, cW, nx); cw1 = sft(a.cwmax, cW, nx);
+        cv0 = sft(a.cvmin, cV, nym); cv1 = sft(a.cvmax, cV, nym);
+        const double Cw = cS ? a.Cwt[b] : 0.0;
         const double lam0 = 10.0;
+        // the slack ε (starts at 0), the row ε >= 0 and the slack component of the Newton steps (group-uniform scalars)
+        double eps = 0.0, se = 1.0, le = lam0, dea = 0.0, de = 0.0, dsa_e = 0.0, dla_e = 0.0, ds_e = 0.0, dl_e = 0.0, ppsi = 0.0;
+        double sel_keep = 0.0, rd_e = 0.0;
         const double xbar = r < nx ? a.X0old[((size_t)b * d.He + yslot(0)) * nx + r] : 0.0;     // x̂0arr_old
 
         // ---- stage data: g, e, q, starting point (x(0) = x̄, ŵ = 0), slacks and multipliers
@@ -569,9 +590,13 @@ struct Solver {
             }
         }
         const double nh = w.rmax(nh_l);
-        const double mrows = w.rsum((double)m_l);
+        const double mrows = w.rsum((double)m_l) + (cS ? 1.0 : 0.0);
         const bool norows = !(mrows > 0.0);
         const double delta = d.dual_reg;
+        // ŵ rows couple neighbouring stages: an active one enters S(s+1) as D̃ - (D̃Â)(Â'D̃Â + ..)⁻¹(Â'D̃), a difference of
+        // D̃-sized terms.  Their multiplier steps are therefore regularised with δw = 1e-8 (D̃ <= 1e8: the cancellation
+        // costs 8 digits, not all 16); δ vanishes from the converged solution either way.
+        const double delta_w = fmax(delta, 1e-8);
 
         int st = 1, it = 0;
         bool done = false;
@@ -583,19 +608,27 @@ struct Solver {
             for (int phase = 0; phase < 2; ++phase) {
                 // ---------------- forward sweep: residuals (phase 0), right-hand side, factorisation (phase 0), t = S⁻¹ b̃
                 double rpn_l = 0.0, mu_l = 0.0, rdn_l = 0.0, ndd_l = 0.0;
+                double see_l = 0.0, sel_l = 0.0, sec_l = 0.0;      // slack column: Σ D̃c², Σ cλ, Σ c·c̃ over this lane's soft rows
                 {
                     Row Si, Oprev, Bs, U;
-                    double xm = 0.0, xc = Sld(sm.X + 0), tprev = 0.0;
-                    double dd_carry = 0.0, gl_carry = 0.0, cr_carry = 0.0;
+                    double xm = 0.0, xc = Sld(sm.X + 0), tprev = 0.0, tpprev = 0.0;
+                    double dd_carry = 0.0, gl_carry = 0.0, cr_carry = 0.0, ph_carry = 0.0;
                     auto stage = [&](int s, StageIn& in) {
                         const double xp = in.x;
-                        double gl = gl_carry, dd = dd_carry, cr = cr_carry;
-                        dd_carry = gl_carry = cr_carry = 0.0;
+                        double gl = gl_carry, dd = dd_carry, cr = cr_carry, ph = ph_carry;
+                        dd_carry = gl_carry = cr_carry = ph_carry = 0.0;
                         double Dtw = 0.0;
+                        // slack column of a row pair with softness (c0, c1): φ part f = D̃0 c0 - D̃1 c1 (in the pair's own space)
+                        auto soft = [&](const RowK& k0, const RowK& k1, double l0, double l1, bool h0, bool h1, double c0, double c1) {
+                            see_l += k0.Dt * c0 * c0 + k1.Dt * c1 * c1;
+                            sec_l += c0 * k0.c + c1 * k1.c;
+                            if (!phase) sel_l += (h0 ? c0 * l0 : 0.0) + (h1 ? c1 * l1 : 0.0);
+                            return k0.Dt * c0 - k1.Dt * c1;
+                        };
                         // phase 1: the rows' complementarity target carries the second-order term of the affine step
-                        auto extra = [&](bool has, double sv, double lv, double rp, double gda) {
+                        auto extra = [&](bool has, double sv, double lv, double rp, double gda, double dlt) {
                             double ds, dl;
-                            row_dir(has, sv, lv, rp, gda, 0.0, delta, ds, dl);
+                            row_dir(has, sv, lv, rp, gda, 0.0, dlt, ds, dl);
                             return ds * dl - smu;
                         };
                         auto tally = [&](bool has, double sv, double lv, double rp) {
@@ -603,13 +636,14 @@ struct Solver {
                         };
                         if (cX) {
                             const RowIn& q = in.xr;
-                            const double rp0 = -xc + q.s0 + xlo, rp1 = xc + q.s1 - xhi;
+                            const double rp0 = -xc + q.s0 + xlo - cx0 * eps, rp1 = xc + q.s1 - xhi - cx1 * eps;
                             double e0 = 0.0, e1 = 0.0;
-                            if (phase) { e0 = extra(hxlo, q.s0, q.l0, rp0, -in.dxa); e1 = extra(hxhi, q.s1, q.l1, rp1, in.dxa); }
+                            if (phase) { e0 = extra(hxlo, q.s0, q.l0, rp0, -in.dxa - cx0 * dea, delta); e1 = extra(hxhi, q.s1, q.l1, rp1, in.dxa - cx1 * dea, delta); }
                             const RowK k0 = row_rhs(hxlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hxhi, q.s1, q.l1, rp1, e1, delta);
                             gl += (hxhi ? q.l1 : 0.0) - (hxlo ? q.l0 : 0.0);
                             dd += k0.Dt + k1.Dt;
                             cr += k1.c - k0.c;
+                            if (cS) ph += soft(k0, k1, q.l0, q.l1, hxlo, hxhi, cx0, cx1);
                             if (!phase) { tally(hxlo, q.s0, q.l0, rp0); tally(hxhi, q.s1, q.l1, rp1); }
                         }
                         Row A;
@@ -619,10 +653,10 @@ struct Solver {
                             if (!phase) { wv = xp - op.mv(A, xc) - in.gs; Sst(sm.WW + s, wv); }
                             else wv = in.ww;
                             const RowIn& q = in.wr;
-                            const double rp0 = -wv + q.s0 + wlo, rp1 = wv + q.s1 - whi;
+                            const double rp0 = -wv + q.s0 + wlo - cw0 * eps, rp1 = wv + q.s1 - whi - cw1 * eps;
                             double e0 = 0.0, e1 = 0.0;
-                            if (phase) { e0 = extra(hwlo, q.s0, q.l0, rp0, -in.wga); e1 = extra(hwhi, q.s1, q.l1, rp1, in.wga); }
-                            const RowK k0 = row_rhs(hwlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hwhi, q.s1, q.l1, rp1, e1, delta);
+                            if (phase) { e0 = extra(hwlo, q.s0, q.l0, rp0, -in.wga - cw0 * dea, delta_w); e1 = extra(hwhi, q.s1, q.l1, rp1, in.wga - cw1 * dea, delta_w); }
+                            const RowK k0 = row_rhs(hwlo, q.s0, q.l0, rp0, e0, delta_w), k1 = row_rhs(hwhi, q.s1, q.l1, rp1, e1, delta_w);
                             const double lw = (hwhi ? q.l1 : 0.0) - (hwlo ? q.l0 : 0.0), cw = k1.c - k0.c;
                             Dtw = k0.Dt + k1.Dt;
                             if (!phase) Sst(sm.WD + s, Dtw);
@@ -631,6 +665,11 @@ struct Solver {
                             gl -= op.mv(At, lw);
                             cr -= op.mv(At, cw);
                             gl_carry = lw; cr_carry = cw; dd_carry = Dtw;
+                            if (cS) {      // ŵ = x(s+1) - Â x(s) - g: the column part f enters stage s+1 as is and stage s through -Â'
+                                const double f = soft(k0, k1, q.l0, q.l1, hwlo, hwhi, cw0, cw1);
+                                ph -= op.mv(At, f);
+                                ph_carry = f;
+                            }
                             if (!phase) { tally(hwlo, q.s0, q.l0, rp0); tally(hwhi, q.s1, q.l1, rp1); }
                         }
                         const int im = meas_of(s);
@@ -642,9 +681,9 @@ struct Solver {
                             if (!phase) { vv = in.es - op.mv(Cm, xc); Sst(sm.VV + im, vv); }
                             else vv = in.vv;
                             const RowIn& q = in.vr;
-                            const double rp0 = -vv + q.s0 + vlo, rp1 = vv + q.s1 - vhi;
+                            const double rp0 = -vv + q.s0 + vlo - cv0 * eps, rp1 = vv + q.s1 - vhi - cv1 * eps;
                             double e0 = 0.0, e1 = 0.0;
-                            if (phase) { e0 = extra(hvlo, q.s0, q.l0, rp0, -in.vga); e1 = extra(hvhi, q.s1, q.l1, rp1, in.vga); }
+                            if (phase) { e0 = extra(hvlo, q.s0, q.l0, rp0, -in.vga - cv0 * dea, delta); e1 = extra(hvhi, q.s1, q.l1, rp1, in.vga - cv1 * dea, delta); }
                             const RowK k0 = row_rhs(hvlo, q.s0, q.l0, rp0, e0, delta), k1 = row_rhs(hvhi, q.s1, q.l1, rp1, e1, delta);
                             const double lv = (hvhi ? q.l1 : 0.0) - (hvlo ? q.l0 : 0.0), cv = k1.c - k0.c;
                             Dtv = k0.Dt + k1.Dt;
@@ -653,6 +692,7 @@ struct Solver {
                             O::ldo(w.uniform(cbase + cm.Ct), coff, RL, Ct);
                             gl -= op.mv(Ct, lv);            // v̂ = e - Ĉm x: the rows' gradient is -Ĉm'
                             cr -= op.mv(Ct, cv);
+                            if (cS) ph -= op.mv(Ct, soft(k0, k1, q.l0, q.l1, hvlo, hvhi, cv0, cv1));
                             if (!phase) { tally(hvlo, q.s0, q.l0, rp0); tally(hvhi, q.s1, q.l1, rp1); }
                         }
                         double rd;
@@ -718,15 +758,40 @@ struct Solver {
                         const double t = op.mv(Si, rhs - otp);
                         Sst(sm.T + s, t);
                         tprev = t;
+                        if (cS && !phase) {        // the same forward recursion for the slack column φ
+                            const double otpp = s > 0 ? op.mv(Oprev, tpprev) : 0.0;
+                            const double tp = op.mv(Si, ph - otpp);
+                            Sst(sm.PHI + s, ph);
+                            Sst(sm.TP + s, tp);
+                            tpprev = tp;
+                        }
                         MPCQP_SCHED_FENCE();
                         xm = xc; xc = xp;
                     };
                     if (!phase) sweep<K_F0, MPCQP_MHE_DEPTH_F0>(true, stage); else sweep<K_F1, MPCQP_MHE_DEPTH>(true, stage);
                 }
+                // ---- slack variable: its row of the Newton system (group-uniform scalars)
+                double r_eps = 0.0, phi_ee = 1.0, rp_e = 0.0, ex_e = 0.0;
+                if (cS) {
+                    const double see = w.rsum(see_l), sec = w.rsum(sec_l);
+                    if (!phase) sel_keep = w.rsum(sel_l);
+                    rp_e = -eps + se;                                   // row -ε <= 0
+                    if (phase) ex_e = dsa_e * dla_e - smu;
+                    const RowK ke = row_rhs(true, se, le, rp_e, ex_e, delta);
+                    rd_e = 2.0 * Cw * eps - sel_keep - le;
+                    phi_ee = 2.0 * Cw + see + ke.Dt;
+                    r_eps = -rd_e - sec - ke.c;
+                }
                 if (!phase) {
                     rpn = w.rmax(rpn_l);
-                    const double rdn = w.rmax(rdn_l), ndd = w.rmax(ndd_l) + 1.0;
-                    const double musum = w.rsum(mu_l);
+                    double rdn = w.rmax(rdn_l), ndd = w.rmax(ndd_l) + 1.0;
+                    double musum = w.rsum(mu_l);
+                    if (cS) {
+                        rpn = fmax(rpn, fabs(rp_e));
+                        rdn = fmax(rdn, fabs(rd_e));
+                        ndd = fmax(ndd, fmax(fabs(2.0 * Cw * eps), fabs(sel_keep) + fabs(le)) + 1.0);
+                        musum += se * le;
+                    }
                     mu = norows ? 0.0 : musum / mrows;
 #ifdef MHE_DEBUG_PRINT
                     if (r == 0) printf("[b%d] pass %d mu %.3e rpn %.3e rdn %.3e ndd %.3e laststep %.3e ok %d done %d\n", b, pass, mu, rpn, rdn, ndd, laststep, (int)ok, (int)done);
@@ -745,58 +810,94 @@ struct Solver {
                     if (!w.any(!done)) break;
                 }
                 // ---------------- backward sweep: dx(s) = t(s) - Si(s) O(s)' dx(s+1); step ratios of the rows
-                double amin_l = 1e300, q1_l = 0.0, q2_l = 0.0;
+                // (soft variant: the sweep yields y = Φxx⁻¹ r_x and, in phase 0, ψ = Φxx⁻¹ φ; dε = (r_ε - φ'y)/(Φεε - φ'ψ),
+                //  dx = y - ψ dε, and the rows are visited by a pass of their own once dε is known)
+                double amin_l = 1e300, q1_l = 0.0, q2_l = 0.0, py_l = 0.0, ppsi_l = 0.0;
+                const int sDX = phase ? sm.DX : sm.DXA;
+                double dcur = 0.0;          // dε of the solve in progress
+                auto rows2 = [&](bool h0, bool h1, const RowIn& q, double val, double lo, double hi, double gda, double gd, double c0, double c1, double dlt) {
+                    // both rows of one bounded quantity `val` (lo <= val <= hi) with direction gd
+                    const double rp0 = -val + q.s0 + lo - c0 * eps, rp1 = val + q.s1 - hi - c1 * eps;
+                    double e0 = 0.0, e1 = 0.0, ds, dl;
+                    if (phase) {
+                        row_dir(h0, q.s0, q.l0, rp0, -gda - c0 * dea, 0.0, dlt, ds, dl); e0 = ds * dl - smu;
+                        row_dir(h1, q.s1, q.l1, rp1, gda - c1 * dea, 0.0, dlt, ds, dl); e1 = ds * dl - smu;
+                    }
+                    row_dir(h0, q.s0, q.l0, rp0, -gd - c0 * dcur, e0, dlt, ds, dl);
+                    amin_l = fmin(amin_l, fmin(ratio(q.s0, ds), ratio(q.l0, dl)));
+                    q1_l += q.s0 * dl + q.l0 * ds; q2_l += ds * dl;
+                    row_dir(h1, q.s1, q.l1, rp1, gd - c1 * dcur, e1, dlt, ds, dl);
+                    amin_l = fmin(amin_l, fmin(ratio(q.s1, ds), ratio(q.l1, dl)));
+                    q1_l += q.s1 * dl + q.l1 * ds; q2_l += ds * dl;
+                };
+                // rows of stage s for the direction dx(s) (dxn = dx(s+1)); stores the ŵ / v̂ row directions
+                auto rows_stage = [&](int s, StageIn& in, double dx, double dxn) {
+                    if (cX) rows2(hxlo, hxhi, in.xr, in.x, xlo, xhi, in.dxa, dx, cx0, cx1, delta);
+                    if (cW && s < N) {
+                        Row A;
+                        O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
+                        const double gd = dxn - op.mv(A, dx);
+                        Sst((phase ? sm.WG : sm.WGA) + s, gd);
+                        rows2(hwlo, hwhi, in.wr, in.ww, wlo, whi, in.wga, gd, cw0, cw1, delta_w);
+                    }
+                    const int im = meas_of(s);
+                    if (cV && im >= 0) {
+                        Row Cm;
+                        O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
+                        const double gd = -op.mv(Cm, dx);
+                        Sst((phase ? sm.VG : sm.VGA) + im, gd);
+                        rows2(hvlo, hvhi, in.vr, in.vv, vlo, vhi, in.vga, gd, cv0, cv1, delta);
+                    }
+                };
                 {
                     Row U;
-                    double dxn = 0.0;
-                    const int sDX = phase ? sm.DX : sm.DXA;
-                    auto rows2 = [&](bool h0, bool h1, const RowIn& q, double val, double lo, double hi, double gda, double gd) {
-                        // both rows of one bounded quantity `val` (lo <= val <= hi) with direction gd
-                        const double rp0 = -val + q.s0 + lo, rp1 = val + q.s1 - hi;
-                        double e0 = 0.0, e1 = 0.0, ds, dl;
-                        if (phase) {
-                            row_dir(h0, q.s0, q.l0, rp0, -gda, 0.0, delta, ds, dl); e0 = ds * dl - smu;
-                            row_dir(h1, q.s1, q.l1, rp1, gda, 0.0, delta, ds, dl); e1 = ds * dl - smu;
-                        }
-                        row_dir(h0, q.s0, q.l0, rp0, -gd, e0, delta, ds, dl);
-                        amin_l = fmin(amin_l, fmin(ratio(q.s0, ds), ratio(q.l0, dl)));
-                        q1_l += q.s0 * dl + q.l0 * ds; q2_l += ds * dl;
-                        row_dir(h1, q.s1, q.l1, rp1, gd, e1, delta, ds, dl);
-                        amin_l = fmin(amin_l, fmin(ratio(q.s1, ds), ratio(q.l1, dl)));
-                        q1_l += q.s1 * dl + q.l1 * ds; q2_l += ds * dl;
-                    };
+                    double dxn = 0.0, psn = 0.0;
                     auto stage = [&](int s, StageIn& in) {
-                        double dx = in.a0;
+                        double dx = in.a0, ps = cS && !phase ? in.tp : 0.0;
                         if (s < N) {
                             O::ld(L_OcT(), WAVE, U);
-                            double u = op.mv(U, dxn);
+                            double u = op.mv(U, dxn), up = cS && !phase ? op.mv(U, psn) : 0.0;
                             if (cW) {
                                 Row At;
                                 O::ldo(w.uniform(cbase + cm.At), coff, RL, At);
                                 u -= op.mv(At, in.wd * dxn);
+                                if (cS && !phase) up -= op.mv(At, in.wd * psn);
                             }
                             dx -= op.mv(in.Si, u);
+                            if (cS && !phase) ps -= op.mv(in.Si, up);
                         }
                         Sst(sDX + s, dx);
-                        if (cX) rows2(hxlo, hxhi, in.xr, in.x, xlo, xhi, in.dxa, dx);
-                        if (cW && s < N) {
-                            Row A;
-                            O::ldo(w.uniform(cbase + cm.A), coff, RL, A);
-                            const double gd = dxn - op.mv(A, dx);
-                            Sst((phase ? sm.WG : sm.WGA) + s, gd);
-                            rows2(hwlo, hwhi, in.wr, in.ww, wlo, whi, in.wga, gd);
+                        if (cS) {
+                            py_l += in.phi * dx;
+                            if (!phase) { Sst(sm.PSI + s, ps); ppsi_l += in.phi * ps; }
+                        } else {
+                            rows_stage(s, in, dx, dxn);
                         }
-                        const int im = meas_of(s);
-                        if (cV && im >= 0) {
-                            Row Cm;
-                            O::ldo(w.uniform(cbase + cm.Cm), coff, RL, Cm);
-                            const double gd = -op.mv(Cm, dx);
-                            Sst((phase ? sm.VG : sm.VGA) + im, gd);
-                            rows2(hvlo, hvhi, in.vr, in.vv, vlo, vhi, in.vga, gd);
-                        }
-                        dxn = dx;
+                        dxn = dx; psn = ps;
                     };
                     if (!phase) sweep<K_B0, MPCQP_MHE_DEPTH>(false, stage); else sweep<K_B1, MPCQP_MHE_DEPTH>(false, stage);
+                }
+                if (cS) {
+                    if (!phase) ppsi = w.rsum(ppsi_l);
+                    dcur = (r_eps - w.rsum(py_l)) / (phi_ee - ppsi);
+                    if (!phase) dea = dcur; else de = dcur;
+                    // row pass: dx = y - ψ dε, then the rows
+                    double dxn = 0.0;
+                    auto stage = [&](int s, StageIn& in) {
+                        const double dx = in.a0 - in.psi * dcur;
+                        Sst(sDX + s, dx);
+                        rows_stage(s, in, dx, dxn);
+                        dxn = dx;
+                    };
+                    if (!phase) sweep<K_R0, MPCQP_MHE_DEPTH>(false, stage); else sweep<K_R1, MPCQP_MHE_DEPTH>(false, stage);
+                    // the row -ε <= 0 itself
+                    double ds, dl;
+                    row_dir(true, se, le, rp_e, -dcur, ex_e, delta, ds, dl);
+                    if (r == 0) {          // (one lane of the group carries it through the reductions)
+                        amin_l = fmin(amin_l, fmin(ratio(se, ds), ratio(le, dl)));
+                        q1_l += se * dl + le * ds; q2_l += ds * dl;
+                    }
+                    if (!phase) { dsa_e = ds; dla_e = dl; } else { ds_e = ds; dl_e = dl; }
                 }
                 const double amin = w.rmin(amin_l);
                 const double q1 = w.rsum(q1_l), q2 = w.rsum(q2_l);
@@ -818,35 +919,36 @@ struct Solver {
             {
                 const double al = done ? 0.0 : alpha;
                 double zm_l = 1.0, dm_l = 0.0;
-                auto upd2 = [&](bool h0, bool h1, int slot, const RowIn& q, double val, double lo, double hi, double gda, double gd) {
-                    const double rp0 = -val + q.s0 + lo, rp1 = val + q.s1 - hi;
+                auto upd2 = [&](bool h0, bool h1, int slot, const RowIn& q, double val, double lo, double hi, double gda, double gd, double c0, double c1, double dlt) {
+                    const double rp0 = -val + q.s0 + lo - c0 * eps, rp1 = val + q.s1 - hi - c1 * eps;
                     double ds, dl;
                     if (h0) {
-                        row_dir(true, q.s0, q.l0, rp0, -gda, 0.0, delta, ds, dl);
+                        row_dir(true, q.s0, q.l0, rp0, -gda - c0 * dea, 0.0, dlt, ds, dl);
                         const double e = ds * dl - smu;
-                        row_dir(true, q.s0, q.l0, rp0, -gd, e, delta, ds, dl);
+                        row_dir(true, q.s0, q.l0, rp0, -gd - c0 * de, e, dlt, ds, dl);
                         Sst(slot + 0, q.s0 + al * ds);
                         Sst(slot + 1, q.l0 + al * dl);
                     }
                     if (h1) {
-                        row_dir(true, q.s1, q.l1, rp1, gda, 0.0, delta, ds, dl);
+                        row_dir(true, q.s1, q.l1, rp1, gda - c1 * dea, 0.0, dlt, ds, dl);
                         const double e = ds * dl - smu;
-                        row_dir(true, q.s1, q.l1, rp1, gd, e, delta, ds, dl);
+                        row_dir(true, q.s1, q.l1, rp1, gd - c1 * de, e, dlt, ds, dl);
                         Sst(slot + 2, q.s1 + al * ds);
                         Sst(slot + 3, q.l1 + al * dl);
                     }
                 };
                 auto stage = [&](int s, StageIn& in) {
                     const double xc = in.x, dx = in.a0;
-                    if (cX) upd2(hxlo, hxhi, sm.XR + 4 * s, in.xr, xc, xlo, xhi, in.dxa, dx);
-                    if (cW && s < N) upd2(hwlo, hwhi, sm.WR + 4 * s, in.wr, in.ww, wlo, whi, in.wga, in.wg);
+                    if (cX) upd2(hxlo, hxhi, sm.XR + 4 * s, in.xr, xc, xlo, xhi, in.dxa, dx, cx0, cx1, delta);
+                    if (cW && s < N) upd2(hwlo, hwhi, sm.WR + 4 * s, in.wr, in.ww, wlo, whi, in.wga, in.wg, cw0, cw1, delta_w);
                     const int im = meas_of(s);
-                    if (cV && im >= 0) upd2(hvlo, hvhi, sm.VR + 4 * im, in.vr, in.vv, vlo, vhi, in.vga, in.vg);
+                    if (cV && im >= 0) upd2(hvlo, hvhi, sm.VR + 4 * im, in.vr, in.vv, vlo, vhi, in.vga, in.vg, cv0, cv1, delta);
                     zm_l = fmax(zm_l, fabs(xc));
                     dm_l = fmax(dm_l, fabs(al * dx));
                     Sst(sm.X + s, xc + al * dx);
                 };
                 sweep<K_U, MPCQP_MHE_DEPTH_U>(true, stage);
+                if (cS) { eps += al * de; se += al * ds_e; le += al * dl_e; }
                 const double dm = w.rmax(dm_l), zm = w.rmax(zm_l);
                 if (!done) {
                     laststep = dm / zm;
@@ -857,6 +959,7 @@ struct Solver {
             if (!w.any(!done)) break;
         }
         if (st == 1 && !(rpn <= 1e-6 * nh)) st = 2;
+        if (live && cS && a.eps_out && r == 0) a.eps_out[b] = st == 2 ? 0.0 : eps;
         write_outputs(st, it, xbar);
     }
 

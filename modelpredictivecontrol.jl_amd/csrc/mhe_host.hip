@@ -29,6 +29,9 @@ struct mpcqp_mhe_s {
     // device arrays
     double *lastu = nullptr, *P0 = nullptr, *Pout = nullptr;
     double* bnd[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* sft[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* Cwt = nullptr;
+    bool soft = false;       // finite Cwt: a slack variable exists
     double *s_y = nullptr, *s_u = nullptr, *s_d = nullptr;      // staging of the host-pointer entry points
     size_t scratch_bytes = 0;
 };
@@ -222,7 +225,53 @@ int mpcqp_mhe_set_bounds(mpcqp_mhe h, const double* xmin, const double* xmax, co
             *dst[k] = nullptr;
         }
     }
-    d.cls = cls;
+    d.cls = cls | (d.cls & mhe::CLS_S);
+    return MPCQP_OK;
+}
+
+int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin, const double* c_xmax, const double* c_wmin,
+                           const double* c_wmax, const double* c_vmin, const double* c_vmax) {
+    if (!h) return MPCQP_ERR_NULL;
+    ON_DEVICE(h);
+    mhe::Dims& d = h->d;
+    const double* src[6] = {c_xmin, c_xmax, c_wmin, c_wmax, c_vmin, c_vmax};
+    const int n[6] = {d.nx, d.nx, d.nx, d.nx, d.nym, d.nym};
+    const double** dst[6] = {&h->a.cxmin, &h->a.cxmax, &h->a.cwmin, &h->a.cwmax, &h->a.cvmin, &h->a.cvmax};
+    bool any_c = false;
+    for (int k = 0; k < 6; ++k)
+        if (src[k])
+            for (size_t i = 0; i < (size_t)d.B * n[k]; ++i) {
+                if (!(src[k][i] >= 0.0) || std::isinf(src[k][i])) return MPCQP_ERR_ARG;      // softness is >= 0 and finite
+                any_c = any_c || src[k][i] > 0.0;
+            }
+    if (!Cwt) {                       // Cwt = Inf: hard constraints only
+        if (any_c) return MPCQP_ERR_ARG;     // (the reference: "Cwt must be finite to set softness parameters")
+        d.cls &= ~mhe::CLS_S;
+        h->soft = false;
+        for (int k = 0; k < 6; ++k) *dst[k] = nullptr;
+        return MPCQP_OK;
+    }
+    for (size_t b = 0; b < (size_t)d.B; ++b)
+        if (!(Cwt[b] >= 0.0) || std::isinf(Cwt[b])) return MPCQP_ERR_ARG;
+    if (!h->Cwt) { int rc = dalloc_t(h, &h->Cwt, (size_t)d.B); if (rc) return rc; }
+    int rc = up(h, h->Cwt, Cwt, (size_t)d.B);
+    if (rc) return rc;
+    h->a.Cwt = h->Cwt;
+    if (!h->a.eps_out) { rc = dalloc_t(h, &h->a.eps_out, (size_t)d.B); if (rc) return rc; }
+    std::vector<double> buf((size_t)d.B * mhe::RL);
+    for (int k = 0; k < 6; ++k) {
+        if (!src[k]) { *dst[k] = nullptr; continue; }
+        for (size_t b = 0; b < (size_t)d.B; ++b)
+            for (int r = 0; r < mhe::RL; ++r) buf[b * mhe::RL + r] = r < n[k] ? src[k][b * n[k] + r] : 0.0;
+        if (!h->sft[k]) { rc = dalloc_t(h, &h->sft[k], buf.size()); if (rc) return rc; }
+        rc = up(h, h->sft[k], buf.data(), buf.size());
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *dst[k] = h->sft[k];
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    d.cls |= mhe::CLS_S;
+    h->soft = true;
     return MPCQP_OK;
 }
 
@@ -347,6 +396,7 @@ int mpcqp_mhe_get(mpcqp_mhe h, int what, void* out) {
         case MPCQP_MHE_ITERS: src = h->a.iters; bytes = B * 4; break;
         case MPCQP_MHE_VHAT: src = h->a.Vhat; bytes = B * He * d.nym * 8; break;
         case MPCQP_MHE_XHATWIN: src = h->a.Xhat; bytes = B * He * nx * 8; break;
+        case MPCQP_MHE_EPSILON: src = h->a.eps_out; bytes = B * 8; break;
         case MPCQP_MHE_PBAR: {
             // the row-lane array back to (nx̂,nx̂,B): a covariance launch with no update writes the ABI copy
             HIPCHK(mhe::launch_cov(d, h->a, 0, nullptr, h->Pout, h->stream));

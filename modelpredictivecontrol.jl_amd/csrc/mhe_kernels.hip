@@ -52,6 +52,8 @@ hipError_t launch_step(const Dims& d, const Args& a, hipStream_t st) {
     const size_t lds = step_lds_doubles(d.NX) * sizeof(double);
     if ((d.cls & ~CLS_X) == 0) {
         MHE_DISPATCH(d.NX, hipLaunchKernelGGL((k_mhe_step<NX, 1u>), dim3(d.nwaves), dim3(WAVE), lds, st, d, a));
+    } else if (d.cls & CLS_S) {       // soft constraints: all classes + the slack variable
+        MHE_DISPATCH(d.NX, hipLaunchKernelGGL((k_mhe_step<NX, 15u>), dim3(d.nwaves), dim3(WAVE), lds, st, d, a));
     } else {
         MHE_DISPATCH(d.NX, hipLaunchKernelGGL((k_mhe_step<NX, 7u>), dim3(d.nwaves), dim3(WAVE), lds, st, d, a));
     }

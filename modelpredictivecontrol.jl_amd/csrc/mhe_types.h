@@ -19,7 +19,7 @@ namespace mhe {
 
 constexpr int RL = 16;    // lanes per estimator: one DPP row
 constexpr int GPW = 4;    // estimators per wavefront
-enum { CLS_X = 1u, CLS_W = 2u, CLS_V = 4u };
+enum { CLS_X = 1u, CLS_W = 2u, CLS_V = 4u, CLS_S = 8u };   // bound classes; CLS_S: a slack variable ε relaxes some rows
 
 struct Dims {
     int B, nx, nu, nym, nd, He;
@@ -56,7 +56,7 @@ MPCQP_HD inline CstMap cst_map(int NX, int nu, int nd) {
 
 // 64-double slots of one wavefront's scratch
 struct SlotMap {
-    int X, DX, DXA, RD, T, Q, G, E, SI, XR, WR, WW, WG, WGA, WD, VR, VV, VG, VGA, VD, total;
+    int X, DX, DXA, RD, T, Q, G, E, SI, XR, WR, WW, WG, WGA, WD, VR, VV, VG, VGA, VD, PHI, TP, PSI, total;
 };
 MPCQP_HD inline SlotMap slot_map(int NX, int He, uint32_t cls) {
     SlotMap m{};
@@ -70,6 +70,8 @@ MPCQP_HD inline SlotMap slot_map(int NX, int He, uint32_t cls) {
     const int nw = (cls & CLS_W) ? He : 0, nv = (cls & CLS_V) ? Hs : 0;
     m.WR = take(4 * nw); m.WW = take(nw); m.WG = take(nw); m.WGA = take(nw); m.WD = take(nw);
     m.VR = take(4 * nv); m.VV = take(nv); m.VG = take(nv); m.VGA = take(nv); m.VD = take(nv);
+    const int ns = (cls & CLS_S) ? Hs : 0;      // slack column of the Newton matrix: φ(s), its forward and backward solves
+    m.PHI = take(ns); m.TP = take(ns); m.PSI = take(ns);
     m.total = o;
     return m;
 }
@@ -87,6 +89,9 @@ struct Args {
     double* P;                   // [B][NX*RL]  arrival covariance P̄ (row-lane)
     double* Pi2;                 // [B][NX*RL]  2 P̄⁻¹
     const double *xmin, *xmax, *wmin, *wmax, *vmin, *vmax;   // [B][RL] per channel, |v| >= BIG: absent (null: class absent)
+    const double *cxmin, *cxmax, *cwmin, *cwmax, *cvmin, *cvmax;   // [B][RL] softness c >= 0 of the rows (null: hard), CLS_S
+    const double* Cwt;           // [B] weight of ε² (CLS_S)
+    double* eps_out;             // [B] optimal slack ε (CLS_S)
     double *Y0m, *U0, *D0, *X0old;   // data windows (rings): [B][He][nym], [B][He][nu], [B][He+1][nd], [B][He][nx]
     const double *y0m_new, *u0_new, *d0_new;   // [B][nym], [B][nu], [B][nd]: data of this period (pushed as window entry N-1)
     double* xhat0;               // [B][nx]  in: x̂0 before this period (pushed into X0old), out: new estimate

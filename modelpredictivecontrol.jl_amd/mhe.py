@@ -19,12 +19,12 @@ import numpy as np
 from . import api
 from .api import MpcqpError, _chk, _f64, _ptr, colmajor
 
-EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_init",
+EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_set_softness", "mpcqp_mhe_init",
            "mpcqp_mhe_prepare", "mpcqp_mhe_update", "mpcqp_mhe_prepare_device", "mpcqp_mhe_update_device",
            "mpcqp_mhe_sync", "mpcqp_mhe_get", "mpcqp_mhe_device_ptr", "mpcqp_mhe_nk", "mpcqp_mhe_last_ms",
            "mpcqp_mhe_register_columns")
 KEEP_WINDOWS = 1
-GET_XHAT0, GET_ZTILDE, GET_STATUS, GET_ITERS, GET_PBAR, GET_VHAT, GET_XHATWIN = range(7)
+GET_XHAT0, GET_ZTILDE, GET_STATUS, GET_ITERS, GET_PBAR, GET_VHAT, GET_XHATWIN, GET_EPSILON = range(8)
 
 
 class MheDims(C.Structure):
@@ -41,6 +41,7 @@ def _bind(lib):
     lib.mpcqp_mhe_destroy.argtypes = [C.c_void_p]
     lib.mpcqp_mhe_set_model.argtypes = [C.c_void_p] * 9
     lib.mpcqp_mhe_set_bounds.argtypes = [C.c_void_p] * 7
+    lib.mpcqp_mhe_set_softness.argtypes = [C.c_void_p] * 8
     lib.mpcqp_mhe_init.argtypes = [C.c_void_p] * 5
     lib.mpcqp_mhe_prepare.argtypes = [C.c_void_p] * 3
     lib.mpcqp_mhe_update.argtypes = [C.c_void_p] * 4
@@ -91,6 +92,11 @@ class MheHandle:
         arrs = [None if a is None else _f64(a) for a in (xmin, xmax, wmin, wmax, vmin, vmax)]
         _chk(self.lib, self.lib.mpcqp_mhe_set_bounds(self._h, *[_ptr(a) for a in arrs]))
 
+    def set_softness(self, Cwt=None, c_xmin=None, c_xmax=None, c_wmin=None, c_wmax=None, c_vmin=None, c_vmax=None):
+        """Cwt (B,) finite or None (= Inf, hard only); softness arrays (B, n) >= 0 or None."""
+        arrs = [None if a is None else _f64(a) for a in (Cwt, c_xmin, c_xmax, c_wmin, c_wmax, c_vmin, c_vmax)]
+        _chk(self.lib, self.lib.mpcqp_mhe_set_softness(self._h, *[_ptr(a) for a in arrs]))
+
     def init(self, xhat0, P0, d0_prev=None, lastu0=None):
         arrs = [None if xhat0 is None else _f64(xhat0), colmajor(P0), None if d0_prev is None else _f64(d0_prev),
                 None if lastu0 is None else _f64(lastu0)]
@@ -124,7 +130,8 @@ class MheHandle:
         B, nx, He, nym = self.B, self.nx, self.He, self.nym
         shape, dt = {GET_XHAT0: ((B, nx), np.float64), GET_ZTILDE: ((B, nx + He * nx), np.float64),
                      GET_STATUS: ((B,), np.int32), GET_ITERS: ((B,), np.int32), GET_PBAR: ((B, nx, nx), np.float64),
-                     GET_VHAT: ((B, He * nym), np.float64), GET_XHATWIN: ((B, He * nx), np.float64)}[what]
+                     GET_VHAT: ((B, He * nym), np.float64), GET_XHATWIN: ((B, He * nx), np.float64),
+                     GET_EPSILON: ((B,), np.float64)}[what]
         out = np.zeros(shape, dt)
         _chk(self.lib, self.lib.mpcqp_mhe_get(self._h, what, _ptr(out)))
         return out.transpose(0, 2, 1).copy() if what == GET_PBAR else out
@@ -182,10 +189,10 @@ class BatchMHE:
             raise ValueError("model matrices have inconsistent sizes")
         if not isinstance(He, (int, np.integer)) or He < 1:
             raise ValueError("Estimation horizon He should be ≥ 1")          # construct.jl:436
-        if not np.isinf(Cwt):
-            raise MpcqpError("finite Cwt (soft constraints) is not supported by this build")
         if Cwt < 0:
-            raise ValueError("Cwt weight should be ≥ 0")
+            raise ValueError("Cwt weight should be ≥ 0")                       # construct.jl:437
+        self.Cwt = float(Cwt)
+        self.nϵ = 0 if np.isinf(Cwt) else 1
         self.B, self.nx̂, self.nu, self.nym, self.nd, self.He, self.direct = B, nx, nu, nym, nd, int(He), bool(direct)
         self.Q̂ = np.asarray(Q̂, float) if Q̂ is not None else _diag_cov(np.ones(nx) if σQ is None else σQ, B, nx, "σQ")
         self.R̂ = np.asarray(R̂, float) if R̂ is not None else _diag_cov(np.ones(nym) if σR is None else σR, B, nym, "σR")
@@ -200,22 +207,24 @@ class BatchMHE:
                                 flags=KEEP_WINDOWS if keep_windows else 0, lib=lib, **solver)
         self.handle.set_model(Ahat, Bhu if nu else None, Chm, Bhd if nd else None, Dhdm if nd else None,
                               self.f̂op - self.x̂op, self.Q̂, self.R̂)
-        self._con = {}
+        self._con, self._soft = {}, {}
+        if self.nϵ:
+            self.handle.set_softness(np.full(B, self.Cwt))
         self.x̂0 = np.zeros((B, nx))
         self.handle.init(self.x̂0, self.P̂_0)
         self.status = np.zeros(B, np.int32)
 
     # -- setconstraint! (construct.jl:858-1049): per-channel hard bounds --------------------------------
-    def setconstraint(self, *, x̂min=None, x̂max=None, ŵmin=None, ŵmax=None, v̂min=None, v̂max=None, **other):
-        soft = [k for k in other if k.startswith(("c_", "C_"))]
-        if soft:
-            raise MpcqpError(f"softness parameters {soft} need a finite Cwt: not supported by this build")
-        full = [k for k in other if k in ("X̂min", "X̂max", "Ŵmin", "Ŵmax", "V̂min", "V̂max")]
+    def setconstraint(self, *, x̂min=None, x̂max=None, ŵmin=None, ŵmax=None, v̂min=None, v̂max=None, c_x̂min=None, c_x̂max=None,
+                      c_ŵmin=None, c_ŵmax=None, c_v̂min=None, c_v̂max=None, **other):
+        full = [k for k in other if k in ("X̂min", "X̂max", "Ŵmin", "Ŵmax", "V̂min", "V̂max", "C_x̂min", "C_x̂max", "C_ŵmin",
+                                          "C_ŵmax", "C_v̂min", "C_v̂max")]
         if full:
             raise MpcqpError(f"window-long bound vectors {full} are not supported by this build")
         if other:
             raise TypeError(f"unknown setconstraint keywords {sorted(other)}")
         B = self.B
+        con = dict(self._con)              # (validated before it replaces the current set)
         for key, val, n, shift in (("xmin", x̂min, self.nx̂, self.x̂op), ("xmax", x̂max, self.nx̂, self.x̂op),
                                    ("wmin", ŵmin, self.nx̂, None), ("wmax", ŵmax, self.nx̂, None),
                                    ("vmin", v̂min, self.nym, None), ("vmax", v̂max, self.nym, None)):
@@ -225,11 +234,27 @@ class BatchMHE:
             if v.shape not in ((n,), (B, n)):
                 raise ValueError(f"{key} size {v.shape} ≠ ({n},) or ({B}, {n})")       # DimensionMismatch
             v = np.broadcast_to(v, (B, n)).copy()
-            self._con[key] = v - shift if shift is not None else v
+            con[key] = v - shift if shift is not None else v
         for lo, hi in (("xmin", "xmax"), ("wmin", "wmax"), ("vmin", "vmax")):
-            if lo in self._con and hi in self._con and np.any(self._con[lo] > self._con[hi]):
+            if lo in con and hi in con and np.any(con[lo] > con[hi]):
                 raise ValueError(f"{lo} > {hi}: infeasible bounds")
+        self._con = con
         self.handle.set_bounds(**self._con)
+        # softness parameters (construct.jl:960-1020): nonnegative, and only with a finite Cwt
+        for key, val, n in (("c_xmin", c_x̂min, self.nx̂), ("c_xmax", c_x̂max, self.nx̂), ("c_wmin", c_ŵmin, self.nx̂),
+                            ("c_wmax", c_ŵmax, self.nx̂), ("c_vmin", c_v̂min, self.nym), ("c_vmax", c_v̂max, self.nym)):
+            if val is None:
+                continue
+            v = np.asarray(val, float)
+            if v.shape not in ((n,), (B, n)):
+                raise ValueError(f"{key} size {v.shape} ≠ ({n},) or ({B}, {n})")
+            if np.any(v < 0):
+                raise ValueError(f"{key} weights should be non-negative")
+            if not self.nϵ:
+                raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
+            self._soft[key] = np.broadcast_to(v, (B, n)).copy()
+        if self.nϵ:
+            self.handle.set_softness(np.full(B, self.Cwt), **self._soft)
         return self
 
     def setstate(self, x̂, P̂=None):
@@ -282,7 +307,8 @@ class BatchMHE:
         h = self.handle
         Nk, nx, He = h.Nk, self.nx̂, self.He
         Zt = h.get(GET_ZTILDE)
-        info = {"Nk": Nk, "Ŵ": Zt[:, nx:nx + Nk * nx], "x̂arr": Zt[:, :nx] + self.x̂op, "ϵ": np.zeros(self.B),
+        info = {"Nk": Nk, "Ŵ": Zt[:, nx:nx + Nk * nx], "x̂arr": Zt[:, :nx] + self.x̂op,
+                "ϵ": h.get(GET_EPSILON) if self.nϵ else np.zeros(self.B),
                 "status": h.get(GET_STATUS), "iters": h.get(GET_ITERS), "P̄": h.get(GET_PBAR)}
         if h.flags & KEEP_WINDOWS:
             info["V̂"] = h.get(GET_VHAT)[:, :Nk * self.nym]

@@ -134,6 +134,7 @@ class MheConfig:
     xabs: float = np.inf       # |x̂0| <= xabs on every state (arrival and window)
     wabs: float = np.inf       # |ŵ| <= wabs
     vabs: float = np.inf       # |v̂| <= vabs
+    Cwt: float = np.inf        # weight of the slack ε (Inf: hard constraints only)
 
     @property
     def nxh(self):

@@ -133,7 +133,7 @@ hipError_t launch_cov(const Dims& d, const Args& a, int mode, const double* P0, 
     return hipSuccess;
 }
 hipError_t launch_step(const Dims& d, const Args& a, hipStream_t) {
-    MHE_DISPATCH(d.NX, run_waves(d.nwaves, step_lds_doubles(d.NX), [&](EmuWave& w, int wv, double* sm) { step_body<EmuWave, NX>(w, d, a, wv, sm); }));
+    MHE_DISPATCH(d.NX, run_waves(d.nwaves, step_lds_doubles(d.NX), [&](EmuWave& w, int wv, double* sm) { step_body<EmuWave, NX, 15u>(w, d, a, wv, sm); }));
     return hipSuccess;
 }
 int waves_for(int, int B, int) {

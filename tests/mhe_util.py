@@ -21,13 +21,15 @@ def bounds_of(cfg):
 
 
 PRODUCT_KEYS = {"xhatmin": "x̂min", "xhatmax": "x̂max", "whatmin": "ŵmin", "whatmax": "ŵmax", "vhatmin": "v̂min",
-                "vhatmax": "v̂max"}
+                "vhatmax": "v̂max", "c_xhatmin": "c_x̂min", "c_xhatmax": "c_x̂max", "c_whatmin": "c_ŵmin", "c_whatmax": "c_ŵmax",
+                "c_vhatmin": "c_v̂min", "c_vhatmax": "c_v̂max"}
 
 
 def make_product(cfg, bt, lib=None, bounds=None, **kw):
     nd = cfg.nd
     bm = pm.BatchMHE(bt["Ahat"], bt["Bhu"], bt["Chm"], bt["Bhd"] if nd else None, bt["Dhdm"] if nd else None,
-                     He=cfg.He, Q̂=bt["Qhat"], R̂=bt["Rhat"], P̂_0=bt["P0"], direct=cfg.direct, lib=lib, **kw)
+                     He=cfg.He, Q̂=bt["Qhat"], R̂=bt["Rhat"], P̂_0=bt["P0"], direct=cfg.direct, Cwt=getattr(cfg, "Cwt", np.inf),
+                     lib=lib, **kw)
     bounds = bounds_of(cfg) if bounds is None else bounds
     if bounds:
         bm.setconstraint(**{PRODUCT_KEYS[k]: v for k, v in bounds.items()})
@@ -41,7 +43,7 @@ def make_oracles(cfg, bt, members, bounds=None):
     for b in members:
         model = es.LinModelOracle(bt["A"][b], bt["Bu"][b], bt["C"][b], bt["Bd"][b] if cfg.nd else None,
                                   np.zeros((cfg.nym, cfg.nd)) if cfg.nd else None)
-        e = om.MHEOracle(model, He=cfg.He, direct=cfg.direct, sigmaQ=np.full(cfg.nx, cfg.sigmaQ),
+        e = om.MHEOracle(model, He=cfg.He, direct=cfg.direct, Cwt=getattr(cfg, "Cwt", np.inf), sigmaQ=np.full(cfg.nx, cfg.sigmaQ),
                          sigmaR=np.full(cfg.nym, cfg.sigmaR), sigmaQint_ym=np.full(cfg.nym, cfg.sigmaQint),
                          sigmaP_0=np.full(cfg.nx, cfg.sigmaP0), sigmaPint_ym_0=np.full(cfg.nym, cfg.sigmaP0),
                          nint_ym=[1] * cfg.nym)
@@ -69,7 +71,7 @@ def run_periods(cfg, bt, nper, members, lib=None, seed=0, bounds=None):
             xo = np.array([e.updatestate(u[b], y[b], d[b] if cfg.nd else ()) for e, b in zip(ors, members)])
         info = bm.getinfo()
         Nk = info["Nk"]
-        Wo = np.array([e.Zt[nxh:nxh + Nk * nxh] for e in ors])
+        Wo = np.array([e.Zt[e.neps + nxh:e.neps + nxh + Nk * nxh] for e in ors])
         ex = np.abs(xg[members] - xo).max()
         ew = np.abs(info["Ŵ"][members] - Wo).max()
         scale = max(1.0, np.abs(xo).max())
@@ -79,6 +81,8 @@ def run_periods(cfg, bt, nper, members, lib=None, seed=0, bounds=None):
                 e.updatestate(u[b], y[b], d[b] if cfg.nd else ())
         Po = np.array([e.Parr_old for e in ors])
         ep = np.abs(bm.handle.get(pm.GET_PBAR)[members] - Po).max() / max(1.0, np.abs(Po).max())
-        rows.append(dict(k=k, Nk=Nk, ex=ex / scale, ew=ew / scale, ep=ep, status=info["status"].copy(),
+        eo = np.array([e.Zt[0] if e.neps else 0.0 for e in ors])
+        rows.append(dict(k=k, Nk=Nk, ex=ex / scale, ew=ew / scale, ep=ep, ee=np.abs(info["ϵ"][members] - eo).max(), eps=eo,
+                         status=info["status"].copy(),
                          iters=info["iters"].copy(), ostatus=[e.status for e in ors]))
     return rows, bm

@@ -204,3 +204,25 @@ def test_closed_loop_mhe_feeds_linmpc():
         xg = np.einsum("bij,bj->bi", bt["A"], xg) + np.einsum("bij,bj->bi", bt["Bu"], ug) + w
         xo = np.einsum("bij,bj->bi", bt["A"], xo) + np.einsum("bij,bj->bi", bt["Bu"], uo) + w
     assert worst_x <= 1e-5 and worst_u <= 1e-5, (worst_x, worst_u)
+
+
+@pytest.mark.parametrize("kw, soft", [
+    (dict(nx=2, nu=2, nym=2, nd=0, He=5, xabs=0.5, vabs=0.2, Cwt=1e3),
+     dict(c_xhatmax=[1.0, 0.5, 0.0, 0.0], c_xhatmin=[0.0, 1.0, 0.0, 0.0], c_vhatmin=[1.0, 1.0], c_vhatmax=[0.5, 1.0])),
+    (dict(nx=4, nu=2, nym=3, nd=1, He=8, xabs=0.8, wabs=0.15, Cwt=1e4),
+     dict(c_xhatmin=[1.0] * 7, c_xhatmax=[1.0] * 7, c_whatmin=[0.5] * 7, c_whatmax=[0.0] * 7)),
+    (dict(nx=8, nu=4, nym=4, nd=0, He=10, xabs=0.6, Cwt=1e5, direct=False), dict(c_xhatmin=[1.0] * 12, c_xhatmax=[1.0] * 12)),
+], ids=["xhat+vhat", "xhat+what+d", "NX12 predictor"])
+def test_soft_constraints_match_oracle(kw, soft):
+    """Finite Cwt and softness parameters: the slack ε, the estimates and Ŵ equal the oracle's (which solves the
+    reference's condensed QP with ε first in Z̃)."""
+    cfg = synth.MheConfig("soft", **kw)
+    B = 9
+    bt = synth.make_mhe_batch(cfg, B, seed=17)
+    bounds = mhe_util.bounds_of(cfg)
+    bounds.update({k: np.asarray(v, float) for k, v in soft.items()})
+    rows, bm = mhe_util.run_periods(cfg, bt, cfg.He + 2, [0, 4, 8], bounds=bounds)
+    for r in rows:
+        assert all(s == 0 for s in r["ostatus"]) and np.all(r["status"] == 0), r
+        assert r["ex"] <= TOL and r["ew"] <= TOL and r["ee"] <= TOL * max(1.0, r["eps"].max()), r
+    assert max(r["eps"].max() for r in rows) > 1e-3

@@ -59,8 +59,8 @@ def test_batchmhe_argument_checks(emulib):
     args = (bt["Ahat"], bt["Bhu"], bt["Chm"])
     with pytest.raises(ValueError, match="He"):
         pm.BatchMHE(*args, He=0, lib=emulib)
-    with pytest.raises(mpcqp.MpcqpError, match="Cwt"):
-        pm.BatchMHE(*args, He=3, Cwt=1e5, lib=emulib)
+    with pytest.raises(ValueError, match="Cwt"):
+        pm.BatchMHE(*args, He=3, Cwt=-1.0, lib=emulib)
     with pytest.raises(ValueError, match="inconsistent"):
         pm.BatchMHE(bt["Ahat"], bt["Bhu"][:, :3], bt["Chm"], He=3, lib=emulib)
     bm = pm.BatchMHE(*args, He=3, lib=emulib)
@@ -68,8 +68,10 @@ def test_batchmhe_argument_checks(emulib):
         bm.setconstraint(x̂min=[0.0, 0.0])                       # nx̂ = 4
     with pytest.raises(ValueError, match="infeasible"):
         bm.setconstraint(x̂min=np.ones(4), x̂max=np.zeros(4))
-    with pytest.raises(mpcqp.MpcqpError, match="soft"):
+    with pytest.raises(ValueError, match="Cwt must be finite"):        # construct.jl: softness needs a slack variable
         bm.setconstraint(c_x̂min=np.ones(4))
+    with pytest.raises(ValueError, match="non-negative"):
+        pm.BatchMHE(*args, He=3, Cwt=1e3, lib=emulib).setconstraint(c_v̂max=[-1.0, 0.0])
     with pytest.raises(mpcqp.MpcqpError, match="window-long"):
         bm.setconstraint(X̂min=np.zeros(16))
     with pytest.raises(ValueError, match="ym size"):
@@ -115,3 +117,19 @@ def test_constrained_mhe_on_emulator_matches_oracle(emulib, kw):
         assert np.abs(info["Ŵ"]).max() <= cfg.wabs + tol
     if np.isfinite(cfg.vabs):
         assert np.abs(info["V̂"]).max() <= cfg.vabs + tol
+
+
+@pytest.mark.slow
+def test_soft_constraints_on_emulator_match_oracle(emulib):
+    """Finite Cwt: one slack ε relaxes the rows with softness c > 0 (relaxX̂ / relaxV̂, construct.jl:1151-1288; the
+    slack is an arrow border of the block-tridiagonal Newton matrix).  Hard and soft rows mixed, ε ends > 0."""
+    cfg = _tiny(xabs=0.5, vabs=0.2, Cwt=1e3)
+    bt = synth.make_mhe_batch(cfg, 4, seed=4)
+    bounds = mhe_util.bounds_of(cfg)
+    bounds.update(c_xhatmax=np.array([1.0, 0.5, 0.0, 0.0]), c_xhatmin=np.array([0.0, 1.0, 0.0, 0.0]),
+                  c_vhatmin=np.array([1.0, 1.0]), c_vhatmax=np.array([0.5, 1.0]))
+    rows, bm = mhe_util.run_periods(cfg, bt, 4, [0, 1, 3], lib=emulib, bounds=bounds)
+    for r in rows:
+        assert r["ostatus"] == [0, 0, 0] and np.all(r["status"] == 0)
+        assert r["ex"] <= 2e-6 and r["ew"] <= 2e-6 and r["ee"] <= 2e-6, r
+    assert rows[-1]["eps"].max() > 0.05                     # the constraints are being relaxed
