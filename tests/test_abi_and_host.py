@@ -97,9 +97,12 @@ def test_T6_terminal_cost_is_lqr_on_cpu_emulator(emulib):
     X_mpc, X_lqr = run_lqr_terminal_cost(lib=emulib, B=2)
     assert np.abs(X_mpc - X_lqr).max() < 1e-10
     A, Bu, C, K, M_Hp = __import__("tests.parity_util", fromlist=["x"]).lqr_terminal_cost_case()
-    bad = M_Hp.copy(); bad[0, 5] = bad[5, 0] = 0.1            # couples steps 1 and 3
+    cpl = M_Hp.copy(); cpl[0, 5] = cpl[5, 0] = 0.1            # couples steps 1 and 3: the dense-weight path
     rep = lambda a: np.broadcast_to(a, (2,) + a.shape).copy()
-    with pytest.raises(NotImplementedError):
+    m = mpcqp.BatchLinMPC(rep(A), rep(Bu), rep(C), Hp=3, Hc=3, M_Hp=cpl, lib=emulib)
+    assert m.Mfull is not None and m.Mblk is None
+    bad = M_Hp.copy(); bad[0, 5] = 0.1                        # not Hermitian
+    with pytest.raises(ValueError, match="Hermitian"):
         mpcqp.BatchLinMPC(rep(A), rep(Bu), rep(C), Hp=3, Hc=3, M_Hp=bad, lib=emulib)
 
 
