@@ -99,6 +99,9 @@ class Shard:
                             stream=self.stream.cuda_stream)
 
 
+COLL_DEVICE = [None]      # device of the collectives when it is not the shard's GPU (MPCQP_BENCH_ONE_GPU)
+
+
 def timed_run(sh, steps, warmup, dist):
     """W untimed + K timed steps bracketed by barrier + synchronize; returns (wall seconds, max over the
     ranks; per-step kernel ms from events on the launch stream)."""
@@ -122,7 +125,7 @@ def timed_run(sh, steps, warmup, dist):
     elapsed = time.perf_counter() - t0
     kern_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=sh.dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=COLL_DEVICE[0] or sh.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, kern_ms
@@ -149,6 +152,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MPCQP_BENCH_ONE_GPU=1 (tests only): every rank uses device 0 and the collectives run over gloo on the host -- the
+    # N > 1 code path (sharding, strong + weak runs, gather, reductions) exercised on a box with a single GPU
+    one_gpu = os.environ.get("MPCQP_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
@@ -158,7 +166,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    args.coll_device = torch.device("cpu") if one_gpu else torch.device("cuda", local)
+    COLL_DEVICE[0] = torch.device("cpu") if one_gpu else None
 
     if args.config in synth.MHE_CONFIGS or args.config.startswith("mhe:"):
         # the linear MovingHorizonEstimator (BASELINE configs[4]) -- bench_mhe.py
@@ -188,7 +201,7 @@ def main():
     iters = sh.t_it.cpu().numpy()
     n_opt, it_sum = int((status == 0).sum()), float(iters.sum())
     if dist is not None:
-        agg = torch.tensor([n_opt, it_sum], dtype=torch.float64, device=sh.dev)
+        agg = torch.tensor([n_opt, it_sum], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(agg)
         n_opt, it_sum = int(agg[0].item()), float(agg[1].item())
     mean_it = it_sum / Bglobal
@@ -198,8 +211,8 @@ def main():
     if dist is not None:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        st_all = sharding.gather(sh.t_st, Bglobal, dist)
-        u_all = sharding.gather(sh.t_u0, Bglobal, dist)
+        st_all = sharding.gather(sh.t_st, Bglobal, dist, device=args.coll_device)
+        u_all = sharding.gather(sh.t_u0, Bglobal, dist, device=args.coll_device)
         torch.cuda.synchronize()
         gather = {"ms": (time.perf_counter() - t0) * 1e3, "bytes_per_rank": int(B * (4 + 8 * cfg.nu)),
                   "optimal_fraction": float((st_all == 0).double().mean().item()),

@@ -94,7 +94,7 @@ def run(args, rank, world, local, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=sh.dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     status, iters = sh.h.get(pm.GET_STATUS), sh.h.get(pm.GET_ITERS)
@@ -106,7 +106,7 @@ def run(args, rank, world, local, dist):
         sh.step(record=True)
     n_opt, it_sum = int((status == 0).sum()), float(iters.sum())
     if dist is not None:
-        agg = torch.tensor([n_opt, it_sum], dtype=torch.float64, device=sh.dev)
+        agg = torch.tensor([n_opt, it_sum], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(agg)
         n_opt, it_sum = int(agg[0].item()), float(agg[1].item())
     if rank != 0:
