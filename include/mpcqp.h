@@ -224,6 +224,8 @@ int mpcqp_recondense_device(mpcqp_handle h, void* stream);
 #define MPCQP_GET_BVEC      4
 #define MPCQP_GET_QTILDE    5
 #define MPCQP_GET_FVEC      6
+#define MPCQP_GET_AUDIT     7   /* (4,B) of the last step: final complementarity gap mu, dual residual / its scale, primal
+                                 * residual / its scale, 1.0 if the returned point passed the active-set polish's KKT check */
 int mpcqp_get(mpcqp_handle h, int which, double* out);
 
 /* ---- next row: the SteadyKalmanFilter steps on both sides of moveinput! --------

@@ -29,7 +29,7 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libmpcqp.so")
 FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL, FLAG_NO_POLISH = 1, 2, 4, 8, 16
 KERNEL_GENERIC, KERNEL_AOT, KERNEL_ONDEMAND = 0, 1, 2
 STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
-GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC = 1, 2, 3, 4, 5, 6
+GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC, GET_AUDIT = 1, 2, 3, 4, 5, 6, 7
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
            "mpcqp_destroy", "mpcqp_get_sizes", "mpcqp_set_model", "mpcqp_set_weights",
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_loop_device", "mpcqp_recondense_device",
@@ -297,10 +297,16 @@ class Handle:
     def get(self, which):
         shape = {GET_HESSIAN: (self.B, self.nZ, self.nZ), GET_STEPRESP: (self.B, self.Hp, self.nu, self.ny),
                  GET_KMAT: (self.B, self.nxhat, self.nY), GET_BVEC: (self.B, self.nY),
-                 GET_QTILDE: (self.B, self.nZ), GET_FVEC: (self.B, self.nY)}[which]
+                 GET_QTILDE: (self.B, self.nZ), GET_FVEC: (self.B, self.nY), GET_AUDIT: (self.B, 4)}[which]
         out = np.empty(shape)
         _chk(self.lib, self.lib.mpcqp_get(self.h, which, _ptr(out)))
         return out
+
+    def audit(self):
+        """What the convergence test of the last step saw: dict of (B,) arrays -- complementarity gap `mu`, relative
+        dual / primal residuals `rd`, `rp`, and `polished` (the returned point passed the KKT check of the polish)."""
+        a = self.get(GET_AUDIT)
+        return {"mu": a[:, 0], "rd": a[:, 1], "rp": a[:, 2], "polished": a[:, 3] > 0.5}
 
     def last_step_ms(self):
         return self.lib.mpcqp_last_step_ms(self.h)

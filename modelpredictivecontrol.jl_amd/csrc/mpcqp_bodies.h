@@ -2153,6 +2153,10 @@ struct Step {
             for (int k = w.lane; k < n; k += WAVE) z[k] = dz[k];
             w.sync();
             iters_out = 0;
+            if (io.audit && w.lane == 0) {      // closed form: exact up to the Cholesky solve
+                double* au = io.audit + (size_t)b * 4;
+                au[0] = 0.0; au[1] = 0.0; au[2] = 0.0; au[3] = 1.0;
+            }
             return ST_OPTIMAL;
         }
         // warm start kept in a register for the error path (nZ <= 64: one entry per lane; larger
@@ -2354,6 +2358,10 @@ struct Step {
             for_rows([&](int g, int k, Row& r) { lo[d.rowoff(g) + k] = (good && fin(r)) ? (polished ? fmax(r.pp, 0.0) : r.lam) : 0.0; });
         }
         iters_out = it + npolish;      // factorisations: interior-point iterations + polish attempts
+        if (io.audit && w.lane == 0) {      // what the convergence test saw last (callers can audit an OPTIMAL)
+            double* au = io.audit + (size_t)b * 4;
+            au[0] = mu; au[1] = rdn / ndd; au[2] = rpn / nh; au[3] = polished ? 1.0 : 0.0;
+        }
         return status;
     }
 

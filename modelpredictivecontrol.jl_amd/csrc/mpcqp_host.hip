@@ -38,7 +38,7 @@ struct mpcqp_handle_s {
     DBuf bnd[16];
     // staging for the host-pointer step
     DBuf s_x, s_lu, s_ry, s_ru, s_d0, s_dh, s_Z, s_u0, s_st, s_it, s_yh;
-    DBuf keep_q, keep_F, prof, lam;
+    DBuf keep_q, keep_F, prof, lam, audit;
     bool lam_valid = false;     // lam holds the multipliers of the previous step (MPCQP_FLAG_WARM_DUAL)
     // SteadyKalmanFilter
     DBuf kf_K, kf_iym, kf_x, kf_y, kf_u, kf_d;
@@ -519,6 +519,11 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
         io.kf_K = h->kf.Khat; io.kf_iym = h->kf.i_ym; io.kf_nym = h->kf.nym;
         io.kf_y0m = y0m; io.xhat0_out = xhat0_out; io.kf_predict = predict;
     }
+    {       // what the convergence test of every solve saw last (mpcqp_get MPCQP_GET_AUDIT)
+        int rc = dev_alloc(h, h->audit, (size_t)d.B * 4 * sizeof(double));
+        if (rc) return rc;
+        io.audit = (double*)h->audit.p;
+    }
     if (d.flags & MPCQP_FLAG_KEEP_QP) {
         int rc = dev_alloc(h, h->keep_q, (size_t)d.B * d.nZ * sizeof(double));
         if (!rc) rc = dev_alloc(h, h->keep_F, (size_t)d.B * d.nY * sizeof(double));
@@ -657,6 +662,10 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
         case MPCQP_GET_FVEC:
             if (!h->keep_F.p) return MPCQP_ERR_ORDER;
             HIPCHK(hipMemcpy(out, h->keep_F.p, B * d.nY * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        case MPCQP_GET_AUDIT:
+            if (!h->audit.p) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->audit.p, B * 4 * sizeof(double), hipMemcpyDeviceToHost));
             return MPCQP_OK;
 #ifdef MPCQP_PROFILE
         case 99:     /* per-phase cycle counters of profiling builds (-DMPCQP_PROFILE): (16,B) */

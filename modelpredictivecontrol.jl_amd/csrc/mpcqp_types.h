@@ -42,7 +42,7 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 5
+#define MPCQP_KERNEL_REV 6
 
 namespace mpcqp {
 
@@ -123,6 +123,8 @@ struct StepIO {
     const double* lam_prev;    // optional [B][nrows]: multipliers of the previous period (MPCQP_FLAG_WARM_DUAL)
     double* lam_out;           // optional [B][nrows]: multipliers of this period
     double *prof;              // optional [B][16] per-phase cycle counts (-DMPCQP_PROFILE builds only)
+    double *audit;             // optional [B][4]: final gap mu, dual residual / its scale, primal residual / its scale, 1 if the
+                               // returned point is an accepted active-set polish (KKT conditions of the QP checked)
     // optional: the SteadyKalmanFilter steps on both sides of moveinput! inside the same launch
     // (mpcqp_loop_device): kf_y0m != null => preparestate! first, x̂0 += K̂ (y0m - Ĉm x̂0 - D̂dm d0);
     // kf_predict != 0 => updatestate! last, x̂0 <- Â x̂0 + B̂u u0 + B̂d d0 + (f̂op - x̂op); both write xhat0_out

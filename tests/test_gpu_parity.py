@@ -564,3 +564,17 @@ def test_dense_weight_matrices_on_gpu(hiplib, which):
     worst, kind = dense_weight_case(B=5, which=which)
     assert worst <= TOL, worst
     assert kind == (mpcqp.api.KERNEL_ONDEMAND if which == ("N",) else mpcqp.api.KERNEL_GENERIC)
+
+
+def test_audit_of_the_convergence_test(hiplib):
+    """mpcqp_get(MPCQP_GET_AUDIT): the residuals behind every OPTIMAL are visible to the caller."""
+    cfg = synth.C3
+    bt = synth.make_batch(cfg, 256, seed=2)
+    got = run_batch(cfg, bt)
+    au = got["mpc"].hd.audit()
+    assert np.all(got["status"] == 0)
+    pol = au["polished"]
+    assert pol.mean() > 0.8                                        # most C3 instances end in an accepted polish
+    ipm = ~pol                                                     # the others ended on the interior-point criterion
+    assert np.all(au["mu"][ipm] <= 1e-12) and np.all(au["rp"][ipm] <= 1e-9)
+    assert np.all(np.isfinite(au["rd"])) and np.all(au["rd"] <= 1e-6)
