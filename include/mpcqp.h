@@ -277,6 +277,8 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
 #define MPCQP_KERNEL_AOT       1
 #define MPCQP_KERNEL_ONDEMAND  2
 int mpcqp_prepare(mpcqp_handle h);
+/* LDS bytes one problem needs in the step kernel (160 KB per CU: the number of problems resident per CU follows). */
+int mpcqp_lds_bytes(mpcqp_handle h);
 int mpcqp_kernel_kind(mpcqp_handle h);
 int mpcqp_row_groups(mpcqp_handle h, uint32_t* row_groups);
 int mpcqp_prebuild(const mpcqp_dims* dims, uint32_t row_groups);

@@ -36,7 +36,7 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_last_predmat_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
            "mpcqp_set_output_weight_blocks", "mpcqp_set_dense_weights", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
-           "mpcqp_set_flags", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_row_groups", "mpcqp_prebuild",
+           "mpcqp_set_flags", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_lds_bytes", "mpcqp_row_groups", "mpcqp_prebuild",
            "mpcqp_last_build_error", "mpcqp_multi_create", "mpcqp_multi_destroy", "mpcqp_multi_ndev",
            "mpcqp_multi_handle", "mpcqp_multi_shard", "mpcqp_multi_set_model", "mpcqp_multi_set_weights",
            "mpcqp_multi_set_bounds", "mpcqp_multi_prepare", "mpcqp_multi_step", "mpcqp_multi_gather_device")
@@ -118,6 +118,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_current_setpoint.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpcqp_prepare.argtypes = [C.c_void_p]
     lib.mpcqp_kernel_kind.argtypes = [C.c_void_p]
+    lib.mpcqp_lds_bytes.argtypes = [C.c_void_p]
     lib.mpcqp_row_groups.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     lib.mpcqp_prebuild.argtypes = [C.POINTER(Dims), C.c_uint32]
     lib.mpcqp_last_build_error.restype = C.c_char_p
@@ -228,6 +229,9 @@ class Handle:
                 warnings.warn(f"mpcqp: specialised kernel not available, using the runtime-dimension "
                               f"kernel ({msg})", RuntimeWarning)
         return k
+
+    def lds_bytes(self):
+        return self.lib.mpcqp_lds_bytes(self.h)
 
     def kernel_kind(self):
         return self.lib.mpcqp_kernel_kind(self.h)

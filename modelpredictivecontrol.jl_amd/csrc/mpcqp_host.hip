@@ -826,6 +826,11 @@ int mpcqp_prepare(mpcqp_handle h) {
     return kind;
 }
 
+int mpcqp_lds_bytes(mpcqp_handle h) {
+    if (!h) return MPCQP_ERR_NULL;
+    return (int)step_lds_bytes(h->d);
+}
+
 int mpcqp_kernel_kind(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
     return step_kernel_kind(h->d);
