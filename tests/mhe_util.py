@@ -86,3 +86,33 @@ def run_periods(cfg, bt, nper, members, lib=None, seed=0, bounds=None):
                          status=info["status"].copy(),
                          iters=info["iters"].copy(), ostatus=[e.status for e in ors]))
     return rows, bm
+
+
+def reference_known_answers(lib=None, B=2, forms=(True, False)):
+    """"MHE estimation and getinfo (LinModel)" of the reference (test/2_test_state_estim.jl:1034-1075) through the
+    PRODUCT: the estimator of the reference's `sys` plant (He = 2, both forms, default integrators) stays at the
+    operating point, and its estimated outputs follow a step of the measurements to 1e-3 / 1e-2 after 40 periods."""
+    from tests.test_oracle_mhe import _plant
+    out = {}
+    for direct in forms:
+        model = _plant().setop(uop=[10, 50], yop=[50, 30], dop=[5])
+        e = om.MHEOracle(model, He=2, direct=direct, sigmaQ=[0.25, 0.25], sigmaP_0=[0.25, 0.25])
+        rep = lambda M: np.repeat(np.asarray(M, float)[None], B, 0)
+        bm = pm.BatchMHE(rep(e.Ah), rep(e.Bhu), rep(e.Chm), rep(e.Bhd), rep(e.Dhdm), He=2, Q̂=rep(e.Q), R̂=rep(e.R),
+                         P̂_0=rep(e.cov.P0), direct=direct, uop=model.uop, yop_m=model.yop[e.i_ym], dop=model.dop,
+                         x̂op=e.xhop, f̂op=e.fhop, lib=lib)
+        yhat = lambda: np.einsum("ij,bj->bi", e.Ch, bm.x̂0) + model.yop          # evaloutput (D̂d = 0 for this plant)
+        bm.preparestate([50, 30], [5])
+        x = bm.updatestate([10, 50], [50, 30], [5])
+        res = {"x_at_op": np.abs(x - e.xhop).max()}
+        for _ in range(40):
+            bm.preparestate([50, 30], [5]); bm.updatestate([11, 52], [50, 30], [5])
+        bm.preparestate([50, 30], [5])
+        res["y_hold"] = np.abs(yhat() - [50, 30]).max()
+        for _ in range(40):
+            bm.preparestate([51, 32], [5]); bm.updatestate([10, 50], [51, 32], [5])
+        bm.preparestate([51, 32], [5])
+        res["y_step"] = np.abs(yhat() - [51, 32]).max()
+        res["tol"] = 1e-3 if direct else 1e-2
+        out[direct] = res
+    return out

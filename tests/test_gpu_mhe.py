@@ -226,3 +226,9 @@ def test_soft_constraints_match_oracle(kw, soft):
         assert all(s == 0 for s in r["ostatus"]) and np.all(r["status"] == 0), r
         assert r["ex"] <= TOL and r["ew"] <= TOL and r["ee"] <= TOL * max(1.0, r["eps"].max()), r
     assert max(r["eps"].max() for r in rows) > 1e-3
+
+
+def test_reference_known_answers_through_the_product():
+    """test/2_test_state_estim.jl:1034-1075 driven through BatchMHE on the GPU (both forms)."""
+    for direct, r in mhe_util.reference_known_answers(B=3).items():
+        assert r["x_at_op"] <= 1e-9 and r["y_hold"] <= r["tol"] and r["y_step"] <= r["tol"], (direct, r)

@@ -133,3 +133,18 @@ def test_soft_constraints_on_emulator_match_oracle(emulib):
         assert r["ostatus"] == [0, 0, 0] and np.all(r["status"] == 0)
         assert r["ex"] <= 2e-6 and r["ew"] <= 2e-6 and r["ee"] <= 2e-6, r
     assert rows[-1]["eps"].max() > 0.05                     # the constraints are being relaxed
+
+
+@pytest.mark.slow
+def test_reference_known_answers_through_the_product_on_emulator(emulib):
+    for direct, r in mhe_util.reference_known_answers(lib=emulib, B=1, forms=(True,)).items():      # (both forms: GPU suite)
+        assert r["x_at_op"] <= 1e-9 and r["y_hold"] <= r["tol"] and r["y_step"] <= r["tol"], (direct, r)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("kw", [dict(nx=1, nu=1, nym=1, nd=0, He=1, xabs=0.7), dict(nx=2, nu=1, nym=1, nd=1, He=1, vabs=0.3, direct=False)],
+                         ids=["He1", "He1 predictor"])
+def test_horizon_of_one_on_emulator(emulib, kw):
+    cfg = synth.MheConfig("he1", **kw)
+    rows, _ = mhe_util.run_periods(cfg, synth.make_mhe_batch(cfg, 4, seed=3), 4, [0, 1, 3], lib=emulib)
+    assert all(np.all(r["status"] == 0) and max(r["ex"], r["ew"]) <= 2e-6 and r["ep"] <= 1e-13 for r in rows)
