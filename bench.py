@@ -299,7 +299,8 @@ def main():
                        "nx": cfg.nx, "nxhat": cfg.nxh, "nu": cfg.nu, "ny": cfg.ny, "Hp": cfg.Hp, "Hc": cfg.Hc,
                        "nZ": hd.nZ, "rows": int(rows_u + rows_y + neps), "cold_start": True,
                        "ipm_mean_iters": mean_it, "optimal_fraction": n_opt / Bglobal,
-                       "kernel": {0: "runtime-dimension", 1: "ahead-of-time specialisation", 2: "on-demand specialisation"}[sh.kernel],
+                       "kernel": {0: "runtime-dimension", 1: "ahead-of-time specialisation", 2: "on-demand specialisation",
+                                  3: "small-problem kernel (four controllers per wavefront)"}[sh.kernel],
                        "value_from_median_step": Bglobal / (kmed * 1e-3) if world == 1 else None,
                        "median_kernel_ms": kmed,
                        "recondense_ms": recond_ms, "recondense_K1_ms": k1_ms, "recondense_K2_ms": recond_ms - k1_ms,

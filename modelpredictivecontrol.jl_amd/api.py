@@ -27,7 +27,7 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libmpcqp.so")
 
 # flags / codes of include/mpcqp.h
 FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL, FLAG_NO_POLISH = 1, 2, 4, 8, 16
-KERNEL_GENERIC, KERNEL_AOT, KERNEL_ONDEMAND = 0, 1, 2
+KERNEL_GENERIC, KERNEL_AOT, KERNEL_ONDEMAND, KERNEL_SMALL = 0, 1, 2, 3
 STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
 GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC, GET_AUDIT = 1, 2, 3, 4, 5, 6, 7
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",

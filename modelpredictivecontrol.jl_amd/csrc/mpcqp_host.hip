@@ -759,6 +759,8 @@ static int self_test_spec(mpcqp_handle h, double* worst) {
     d.flags = (d.flags | MPCQP_FLAG_COLD_START) & ~(uint32_t)(MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL);
     const size_t n = d.B, nry = (d.flags & MPCQP_FLAG_RY_CONSTANT) ? d.ny : d.nY;
     const size_t cnt[] = {n * d.nxh, n * d.nu, n * nry, n * (d.nd ? d.nd : 1), n * (d.nD ? d.nD : 1), n * d.nZ, n * d.nZ, n * d.nu, n * d.nu};
+    DBuf yh;                      // (asking for Ŷ keeps the step off the small-problem kernel: the specialisation is what is tested)
+    { int rcy = dev_alloc(h, yh, n * d.nY * sizeof(double)); if (rcy) return rcy; }
     std::vector<double> host(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4], 0.0);
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     auto rnd = [&] { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
@@ -779,6 +781,7 @@ static int self_test_spec(mpcqp_handle h, double* worst) {
     io.xhat0 = pin; io.lastu0 = pin + cnt[0]; io.Ry = pin + cnt[0] + cnt[1];
     if (d.nd) { io.d0 = pin + cnt[0] + cnt[1] + cnt[2]; io.Dhat0 = io.d0 + cnt[3]; }
     io.Z = pout; io.u0 = pout + cnt[5] + cnt[6]; io.status = pst; io.iters = pst + n;
+    io.Yhat0 = (double*)yh.p;
     HIPCHK(launch_step(d, h->m, io, h->stream));
     io.Z = pout + cnt[5]; io.u0 = pout + cnt[5] + cnt[6] + cnt[7]; io.status = pst + 2 * n; io.iters = pst + 3 * n;
     HIPCHK(launch_step_generic(d, h->m, io, h->stream));
@@ -805,7 +808,8 @@ int mpcqp_prepare(mpcqp_handle h) {
     int kind = prepare_step(h->d, &g_build_err);
     // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
     // it with the runtime-dimension kernel once; needs the model and weights (BatchLinMPC prepares before its first step)
-    if (kind == MPCQP_KERNEL_ONDEMAND && !spec_verified(h->d) && h->have_model && h->have_weights &&
+    const bool ondemand = kind == MPCQP_KERNEL_ONDEMAND || (kind == MPCQP_KERNEL_SMALL && step_kernel_kind_other(h->d) == MPCQP_KERNEL_ONDEMAND);
+    if (ondemand && !spec_verified(h->d) && h->have_model && h->have_weights &&
         step_lds_bytes(h->d) <= 160 * 1024) {
         ON_DEVICE(h);
         double worst = 0.0;
@@ -820,7 +824,7 @@ int mpcqp_prepare(mpcqp_handle h) {
             g_build_err = "the on-demand specialisation disagrees with the runtime-dimension kernel (relative difference " +
                           std::to_string(worst) + "): rejected, the runtime-dimension kernel is used";
             fprintf(stderr, "[mpcqp] %s\n", g_build_err.c_str());
-            kind = MPCQP_KERNEL_GENERIC;
+            if (kind != MPCQP_KERNEL_SMALL) kind = MPCQP_KERNEL_GENERIC;
         }
     }
     return kind;

@@ -256,6 +256,12 @@ static bool aot_matches(const Dims& d) {
 // Which kernel a step of `d` runs on: 0 the runtime-dimension kernel, 1 an ahead-of-time
 // specialisation, 2 an on-demand one (already loaded or loadable from the cache).
 int step_kernel_kind(const Dims& d) {
+    if (!force_generic() && small_eligible(d, Model{}, StepIO{})) return 3;
+    return step_kernel_kind_other(d);
+}
+
+// the kernel of the steps the small-problem kernel does not take (Ŷ requested, fused Kalman steps)
+int step_kernel_kind_other(const Dims& d) {
     if (force_generic() || d.dense_w) return 0;
     if (aot_matches(d)) return 1;
     return find_spec(d, true) ? 2 : 0;
@@ -263,7 +269,7 @@ int step_kernel_kind(const Dims& d) {
 
 // Make the specialised kernel of `d` available (compile if needed, load).  Returns the kernel kind
 // as step_kernel_kind(); `err` receives the reason when an eligible specialisation could not be built.
-int prepare_step(const Dims& d, std::string* err) {
+static int prepare_step_other(const Dims& d, std::string* err) {
     if (force_generic() || d.dense_w) return 0;
     if (aot_matches(d)) return 1;
     if (!jit_enabled() || !spec_eligible(d)) return 0;
@@ -276,6 +282,12 @@ int prepare_step(const Dims& d, std::string* err) {
     if (find_spec(d, true)) return 2;
     if (err) *err = "the specialisation was built but could not be loaded";
     return 0;
+}
+
+int prepare_step(const Dims& d, std::string* err) {
+    // (the kernel behind the small one is prepared as well: steps that ask for Ŷ or fuse the Kalman steps run on it)
+    const int other = prepare_step_other(d, err);
+    return (!force_generic() && small_eligible(d, Model{}, StepIO{})) ? 3 : other;
 }
 
 // compile only (no device, no load): for build pipelines
@@ -330,6 +342,7 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
 }
 
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
+    if (!force_generic() && small_eligible(d, m, io)) return launch_step_small(d, m, io, st);
     if (!force_generic() && !d.dense_w) {      // (dense M_Hp / L_Hp: runtime-dimension kernel, like custom constraints)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
         {                                                                           \

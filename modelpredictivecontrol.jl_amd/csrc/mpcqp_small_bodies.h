@@ -1,0 +1,285 @@
+// mpcqp_small_bodies.h -- the LinMPC step for SMALL problems (nZ̃ <= 16): four controllers per wavefront, one per
+// 16-lane DPP row, with the row-per-lane register algebra of the MovingHorizonEstimator kernel (mhe_bodies.h: Ops).
+//
+// One QP per wavefront leaves most of the wave idle when nZ̃ is small (BASELINE configs[1], "C2": nZ̃ = 11 -> 11 of 64
+// lanes busy in the factorisation).  Here lane r of a row owns variable r, row r of H̃ / Φ (nZ̃ registers), its two
+// variable bounds and the merged input-bound rows of its (move-blocking interval, channel); Φ⁻¹ comes from the
+// in-register Gauss-Jordan sweep, G v / Gᵀw are mat-vecs with the lane's rows of the input-bound matrices.
+//
+// Same step as Step::build / Step::run of mpcqp_bodies.h (initpred!, linconstraint!, optim_objective!, getinput!:
+// src/controller/execute.jl:247-277, 466-505, 536-546; transcription.jl:811-848, 997-1007) for the handles that
+// qualify (small_eligible() in mpcqp_kernels.hip): constraint groups box (hard ΔU bounds, ϵ >= 0) and U (hard or soft
+// input bounds, one merged row per interval and channel with its multiplicity as barrier weight), diagonal weights, no
+// output / terminal / custom rows.  Dual-regularised Mehrotra predictor-corrector as everywhere else, without the
+// active-set polish.
+#pragma once
+#include <math.h>
+
+#include "mhe_bodies.h"
+#include "mpcqp_types.h"
+
+namespace mpcqp {
+
+constexpr int SMALL_GPW = 4, SMALL_RL = 16;
+
+MPCQP_HD inline size_t small_lds_doubles(const Dims& d) { return (size_t)SMALL_GPW * d.nY; }
+
+template <class W, int NX>
+MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO& io, int wg, double* smem) {
+    using O = mhe::Ops<W, NX>;
+    using Row = typename O::Row;
+    O op{w};
+    const int lane = w.lane, l = lane & (SMALL_RL - 1), g = lane >> 4;
+    const int bq = wg * SMALL_GPW + g;
+    const bool live = bq < d.B;
+    const int b = live ? bq : d.B - 1;
+    const int nx = d.nxh, nu = d.nu, ny = d.ny, nd = d.nd, nY = d.nY, nDU = d.nDU, nZ = d.nZ, Hp = d.Hp, Hc = d.Hc;
+    const int e = nDU;                         // index of ϵ (when neps)
+    const bool isvar = l < nZ, isdu = l < nDU, iseps = d.neps && l == e;
+    double* cyv = smem + (size_t)g * nY;
+    const double* x0 = io.xhat0 + (size_t)b * nx;
+    const double* lu = io.lastu0 + (size_t)b * nu;
+    const double* Stab = m.Stab + (size_t)b * Hp * ny * nu;          // Σ_t [Hp][ny][nu]
+    auto jl = [&](int j) { return m.jl[j]; };
+
+    // ---- F = B + K x̂0 + V lastu0 (+ G d0 + J D̂0), cy = M (F - R̂y)             execute.jl:249-275
+    {
+        const double* K = m.Ktab + (size_t)b * nx * nY;
+        const double* Bv = m.Bvec + (size_t)b * nY;
+        const double* Md = m.Mdiag + (size_t)b * nY;
+        const bool rconst = d.flags & 1u;
+        for (int r = l; r < nY; r += SMALL_RL) {
+            const int t = r / ny, a = r - t * ny;
+            double acc = Bv[r];
+            for (int k = 0; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
+            for (int cc = 0; cc < nu; ++cc) acc += Stab[(t * ny + a) * nu + cc] * lu[cc];
+            if (nd > 0) {
+                const double* Gd = m.Gdtab + (size_t)b * Hp * ny * nd;
+                const double* dd0 = io.d0 + (size_t)b * nd;
+                const double* Dh = io.Dhat0 + (size_t)b * d.nD;
+                const double* Dd = m.Dd + (size_t)b * ny * nd;
+                for (int q = 0; q < nd; ++q) {
+                    acc += Gd[(t * ny + a) * nd + q] * dd0[q];
+                    acc += Dd[a + ny * q] * Dh[t * nd + q];
+                    for (int j = 0; j < t; ++j) acc += Gd[((t - j - 1) * ny + a) * nd + q] * Dh[j * nd + q];
+                }
+            }
+            const double ry = rconst ? io.Ry[(size_t)b * ny + a] : io.Ry[(size_t)b * nY + r];
+            cyv[r] = Md[r] * (acc - ry);
+        }
+    }
+    w.sync();
+    // ---- q̃ = 2[(M Ẽ)'(F - R̂y) + (L P̃u)'(Tu lastu0 - R̂u)]
+    const int jme = isdu ? l / nu : 0, cme = isdu ? l - jme * nu : 0;
+    double qv = 0.0;
+    if (isdu) {
+        const int t0 = jl(jme);
+        double acc = 0.0;
+        for (int t = t0; t < Hp; ++t)
+            for (int a = 0; a < ny; ++a) acc += Stab[((t - t0) * ny + a) * nu + cme] * cyv[t * ny + a];
+        const double* Ld = m.Ldiag + (size_t)b * d.nU;
+        for (int t = t0; t < Hp; ++t) {
+            const double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cme] : 0.0;
+            acc += Ld[t * nu + cme] * (lu[cme] - ru);
+        }
+        qv = 2.0 * acc;
+    }
+    // ---- H̃ (row l), the input-bound matrices: rows of the lower / upper merged rows and of their transposes
+    Row H, Glo, Ghi, GloT, GhiT;
+    const double* Hpk = m.Hpk + (size_t)b * d.npk;
+    // softness of this lane's merged rows: the one of the interval's first step (Step::soft_init)
+    double cs0 = 0.0, cs1 = 0.0;
+    if (isdu && d.neps) {
+        if (m.C_umin) cs0 = m.C_umin[(size_t)b * d.nU + jl(jme) * nu + cme];
+        if (m.C_umax) cs1 = m.C_umax[(size_t)b * d.nU + jl(jme) * nu + cme];
+    }
+    mhe::sfor<NX>([&](auto ic) {
+        constexpr int c = decltype(ic)::v;
+        const bool in = isvar && c < nZ;
+        H[c] = in ? (c <= l ? Hpk[pk(l, c)] : Hpk[pk(c, l)]) : (l == c ? 1.0 : 0.0);
+        const int jc = c / nu, cc = c - jc * nu;
+        const bool same = isdu && c < nDU && cc == cme;
+        const double gu = (same && jc <= jme) ? 1.0 : 0.0;           // P̃u row of (interval, channel) l: held cumulative sum
+        const double gut = (same && jc >= jme) ? 1.0 : 0.0;
+        Glo[c] = -gu; Ghi[c] = gu; GloT[c] = -gut; GhiT[c] = gut;
+    });
+    if (d.neps) {       // the ϵ column of the rows (-softness) and, for lane ϵ, the softness of every row
+        mhe::sfor<NX>([&](auto ic) {
+            constexpr int c = decltype(ic)::v;
+            if (c == e) { Glo[c] = isdu ? -cs0 : 0.0; Ghi[c] = isdu ? -cs1 : 0.0; }
+            const double s0c = w.template rowbc<c>(cs0), s1c = w.template rowbc<c>(cs1);
+            if (iseps) { GloT[c] = c < nDU ? -s0c : 0.0; GhiT[c] = c < nDU ? -s1c : 0.0; }
+        });
+    }
+    // ---- rows of this lane: 0 box lower, 1 box upper, 2 merged Umin, 3 merged Umax          (i_b: finite only)
+    double h0 = 2.0 * BIG, h1 = 2.0 * BIG, h2 = 2.0 * BIG, h3 = 2.0 * BIG, wt = 1.0;
+    if (isdu) {
+        const size_t o = (size_t)b * nDU + l;
+        if (m.DUmin && (!d.neps || !m.C_dumin || m.C_dumin[o] == 0.0)) h0 = -m.DUmin[o];
+        if (m.DUmax && (!d.neps || !m.C_dumax || m.C_dumax[o] == 0.0)) h1 = m.DUmax[o];
+        const int t0 = jl(jme), t1 = (jme + 1 < Hc) ? jl(jme + 1) : Hp;
+        wt = (double)(t1 - t0);                   // multiplicity of the merged row (barrier weight)
+        if (m.U0min) {
+            double v = -INFINITY;
+            for (int t = t0; t < t1; ++t) v = fmax(v, m.U0min[(size_t)b * d.nU + t * nu + cme]);
+            h2 = -v + lu[cme];
+        }
+        if (m.U0max) {
+            double v = INFINITY;
+            for (int t = t0; t < t1; ++t) v = fmin(v, m.U0max[(size_t)b * d.nU + t * nu + cme]);
+            h3 = v - lu[cme];
+        }
+    } else if (iseps) {
+        h0 = 0.0;                                 // ϵ >= 0
+    }
+    auto fin = [](double h) { return fabs(h) < BIG && h == h; };
+    const bool p0 = fin(h0), p1 = fin(h1), p2 = fin(h2), p3 = fin(h3);
+    const double w0 = 1.0, w1 = 1.0, w2 = wt, w3 = wt;
+    const double wsum = w.rsum((p0 ? w0 : 0.0) + (p1 ? w1 : 0.0) + (p2 ? w2 : 0.0) + (p3 ? w3 : 0.0));
+    const bool norows = !(wsum > 0.0);
+    const double nh = 1.0 + w.rmax(fmax(fmax(p0 ? fabs(h0) : 0.0, p1 ? fabs(h1) : 0.0), fmax(p2 ? fabs(h2) : 0.0, p3 ? fabs(h3) : 0.0)));
+
+    // ---- warm start  Z̃s = [Z̃prev[nu+1:nΔU]; 0; ϵprev]                             transcription.jl:1001-1004
+    const double* Zg = io.Z + (size_t)b * nZ;
+    const bool cold = d.flags & 2u;
+    double z = 0.0;
+    if (isvar && !cold) z = (l < nDU - nu) ? Zg[l + nu] : (l >= nDU ? Zg[l] : 0.0);
+    const double zws = z;
+    // starting point: s = max(h - G z, 1), λ = 10 w / s
+    double s0, s1, s2, s3, l0, l1, l2, l3;
+    {
+        const double g2 = op.mv(Glo, z), g3 = op.mv(Ghi, z);
+        s0 = fmax(h0 + z, 1.0); s1 = fmax(h1 - z, 1.0); s2 = fmax(h2 - g2, 1.0); s3 = fmax(h3 - g3, 1.0);
+        if (!p0) s0 = 1.0; if (!p1) s1 = 1.0; if (!p2) s2 = 1.0; if (!p3) s3 = 1.0;
+        l0 = p0 ? 10.0 * w0 / s0 : 0.0; l1 = p1 ? 10.0 * w1 / s1 : 0.0; l2 = p2 ? 10.0 * w2 / s2 : 0.0; l3 = p3 ? 10.0 * w3 / s3 : 0.0;
+    }
+    const double delta = d.dual_reg;
+    int st = 1, it = 0;
+    bool done = false;
+    double laststep = 1e300, rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0, rpn = 0.0;
+    struct RowD { double Dt, wv; };
+    auto rowd = [&](bool has, double sv, double lv) {
+        RowD r;
+        const double D = lv / sv;
+        r.wv = 1.0 / (1.0 + delta * D);
+        r.Dt = has ? D * r.wv : 0.0;
+        return r;
+    };
+    for (int pass = 0; pass < d.max_iter; ++pass) {
+        // ---- residuals
+        const double g2 = op.mv(Glo, z), g3 = op.mv(Ghi, z);
+        const double rp0 = -z + s0 - h0, rp1 = z + s1 - h1, rp2 = g2 + s2 - h2, rp3 = g3 + s3 - h3;
+        const double hz = op.mv(H, z);
+        const double gl = (p1 ? l1 : 0.0) - (p0 ? l0 : 0.0) + op.mv(GloT, p2 ? l2 : 0.0) + op.mv(GhiT, p3 ? l3 : 0.0);
+        const double rd = isvar ? hz + qv + gl : 0.0;
+        rpn = w.rmax(fmax(fmax(p0 ? fabs(rp0) : 0.0, p1 ? fabs(rp1) : 0.0), fmax(p2 ? fabs(rp2) : 0.0, p3 ? fabs(rp3) : 0.0)));
+        const double rdn = w.rmax(fabs(rd));
+        const double ndd = w.rmax(isvar ? fmax(fabs(qv), fmax(fabs(hz), fabs(gl))) : 0.0) + 1.0;
+        const double musum = w.rsum((p0 ? s0 * l0 : 0.0) + (p1 ? s1 * l1 : 0.0) + (p2 ? s2 * l2 : 0.0) + (p3 ? s3 * l3 : 0.0));
+        const double mu = norows ? 0.0 : musum / wsum;
+#ifdef MHE_DEBUG_PRINT
+        if (l == 0) printf("[b%d] pass %d mu %.3e rpn %.3e rdn %.3e ndd %.3e laststep %.3e lastscale %.3e done %d\n", b, pass, mu, rpn, rdn, ndd, laststep, lastscale, (int)done);
+#endif
+        if (!done) {
+            it = pass;
+            if (!(mu == mu) || !(rdn == rdn)) { st = 2; done = true; }
+            const bool stalled = rdn >= 0.5 * rdn_prev && lastscale <= 0.1;
+            rdn_prev = rdn;
+            const bool pstalled = rpn >= 0.5 * rpn_prev && lastscale <= 0.1 && rpn <= 1e-9 * nh;
+            rpn_prev = rpn;
+            if (!done && mu <= d.gap_tol && (rdn <= d.res_tol * ndd || stalled) && (rpn <= 10.0 * d.res_tol * nh || pstalled) &&
+                laststep <= 1e-6) { st = 0; done = true; }
+        }
+        if (!w.any(!done)) break;
+        // ---- Φ = H̃ + Gᵀ D̃ G, Φ⁻¹
+        const RowD d0 = rowd(p0, s0, l0), d1 = rowd(p1, s1, l1), d2 = rowd(p2, s2, l2), d3 = rowd(p3, s3, l3);
+        Row Phi, T, U;
+        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = H[c]; T[c] = d2.Dt * Glo[c]; });
+        O::add_diag(Phi, l, d0.Dt + d1.Dt);
+        op.mm(GloT, T, U);
+        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += U[c]; T[c] = d3.Dt * Ghi[c]; });
+        op.mm(GhiT, T, U);
+        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += U[c]; });
+        const bool ok = op.gj(Phi, l);
+        if (!done && !ok) { st = 2; done = true; }
+        // ---- predictor, corrector
+        double smu = 0.0, alpha = 1.0, dz = 0.0;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;            // Δs Δλ of the affine step
+        double ds0 = 0, ds1 = 0, ds2 = 0, ds3 = 0, dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0;
+        for (int phase = 0; phase < 2; ++phase) {
+            auto cof = [&](bool has, const RowD& rr, double sv, double lv, double rp, double ex) {
+                return has ? rr.wv * (sv * lv + ex) / sv - rr.Dt * rp : 0.0;
+            };
+            const double e0 = phase ? a0 - w0 * smu : 0.0, e1 = phase ? a1 - w1 * smu : 0.0;
+            const double e2 = phase ? a2 - w2 * smu : 0.0, e3 = phase ? a3 - w3 * smu : 0.0;
+            const double c0 = cof(p0, d0, s0, l0, rp0, e0), c1 = cof(p1, d1, s1, l1, rp1, e1);
+            const double c2 = cof(p2, d2, s2, l2, rp2, e2), c3 = cof(p3, d3, s3, l3, rp3, e3);
+            const double gtc = op.mv(GloT, c2) + op.mv(GhiT, c3);       // (every lane takes part in the mat-vecs)
+            const double rhs = isvar ? -rd + (c1 - c0) + gtc : 0.0;
+            dz = op.mv(Phi, rhs);
+            const double gd2 = op.mv(Glo, dz), gd3 = op.mv(Ghi, dz);
+            auto dir = [&](bool has, const RowD& rr, double sv, double lv, double rp, double gd, double ex, double& ds, double& dl) {
+                const double rc = sv * lv + ex;
+                dl = has ? -rr.wv * rc / sv + rr.Dt * (rp + gd) : 0.0;
+                ds = has ? -rr.wv * ((rp + gd) + delta * rc / sv) : 0.0;
+            };
+            dir(p0, d0, s0, l0, rp0, -dz, e0, ds0, dl0); dir(p1, d1, s1, l1, rp1, dz, e1, ds1, dl1);
+            dir(p2, d2, s2, l2, rp2, gd2, e2, ds2, dl2); dir(p3, d3, s3, l3, rp3, gd3, e3, ds3, dl3);
+            double am = 1e300;
+            am = fmin(am, fmin(fmin(mhe::ratio(s0, ds0), mhe::ratio(l0, dl0)), fmin(mhe::ratio(s1, ds1), mhe::ratio(l1, dl1))));
+            am = fmin(am, fmin(fmin(mhe::ratio(s2, ds2), mhe::ratio(l2, dl2)), fmin(mhe::ratio(s3, ds3), mhe::ratio(l3, dl3))));
+            const double amin = w.rmin(am);
+            if (!phase) {
+                const double aaff = fmin(1.0, amin);
+                const double mas = w.rsum((s0 + aaff * ds0) * (l0 + aaff * dl0) * (p0 ? 1.0 : 0.0) + (s1 + aaff * ds1) * (l1 + aaff * dl1) * (p1 ? 1.0 : 0.0) +
+                                          (s2 + aaff * ds2) * (l2 + aaff * dl2) * (p2 ? 1.0 : 0.0) + (s3 + aaff * ds3) * (l3 + aaff * dl3) * (p3 ? 1.0 : 0.0));
+                const double sig = (mas / wsum) / mu;
+                smu = sig * sig * sig * mu;
+                a0 = ds0 * dl0; a1 = ds1 * dl1; a2 = ds2 * dl2; a3 = ds3 * dl3;
+            } else {
+                // fraction to the boundary: 0.9999 if the iterate it leads to stays in the wide neighbourhood
+                // min s_i λ_i / w_i >= 0.01 μ, else 0.99 (an unguarded 0.9999 jams about one instance in 50000 into a
+                // cycle; all the row state is in registers here, so the test costs two reductions)
+                alpha = fmin(1.0, 0.9999 * amin);
+                auto pr = [&](bool has, double sv, double ds, double lv, double dl) { return has ? (sv + alpha * ds) * (lv + alpha * dl) : 0.0; };
+                const double q0 = pr(p0, s0, ds0, l0, dl0), q1 = pr(p1, s1, ds1, l1, dl1), q2 = pr(p2, s2, ds2, l2, dl2), q3 = pr(p3, s3, ds3, l3, dl3);
+                const double psum = w.rsum(q0 + q1 + q2 + q3);
+                const double pmin = w.rmin(fmin(fmin(p0 ? q0 / w0 : 1e300, p1 ? q1 / w1 : 1e300), fmin(p2 ? q2 / w2 : 1e300, p3 ? q3 / w3 : 1e300)));
+                if (!(pmin * wsum >= 0.01 * psum)) alpha = fmin(1.0, 0.99 * amin);
+            }
+        }
+        // ---- update (a finished controller of the wavefront keeps its iterate)
+        {
+            const double al = done ? 0.0 : alpha;
+            if (p0) { s0 += al * ds0; l0 += al * dl0; }
+            if (p1) { s1 += al * ds1; l1 += al * dl1; }
+            if (p2) { s2 += al * ds2; l2 += al * dl2; }
+            if (p3) { s3 += al * ds3; l3 += al * dl3; }
+            const double zm = w.rmax(isdu ? fmax(1.0, fabs(z)) : 1.0), dm = w.rmax(isdu ? fabs(al * dz) : 0.0);
+            if (isvar && !done) z += al * dz;
+            if (!done) {
+                laststep = dm / zm;
+                lastscale = 1.0 - alpha;
+                if (norows) { st = 0; done = true; it = 0; }
+            }
+        }
+        if (!w.any(!done)) break;
+    }
+    // never primal-feasible (or NaN) => the reference's error branch (execute.jl:484-489): the shifted warm start
+    if (st == 1 && !(rpn <= 1e-6 * nh)) st = 2;
+    if (st == 2) z = zws;
+    if (live) {
+        if (isvar) io.Z[(size_t)b * nZ + l] = z;
+        if (l < nu) io.u0[(size_t)b * nu + l] = z + lu[l];          // getinput!: u0 = lastu0 + ΔU[1:nu]
+        if (l == 0) {
+            io.status[b] = st;
+            if (io.iters) io.iters[b] = it;                          // factorisations (0: closed form, no finite row)
+            if (io.audit) {
+                double* au = io.audit + (size_t)b * 4;
+                au[0] = 0.0; au[1] = 0.0; au[2] = rpn / nh; au[3] = 0.0;
+            }
+        }
+    }
+}
+
+}  // namespace mpcqp

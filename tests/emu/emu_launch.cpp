@@ -124,8 +124,9 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
     run_waves(d.B, make_carve(d).total, [&](EmuWave& w, int b, double* sm) { hessian_body(w, d, m, b, sm); });
     return hipSuccess;
 }
-hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
+hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
     const char* fg = getenv("MPCQP_FORCE_GENERIC");
+    if (!(fg && fg[0] == '1') && small_eligible(d, m, io)) return launch_step_small(d, m, io, st);
     if (!(fg && fg[0] == '1') && !d.dense_w) {
 #define XNB(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 0)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 1)
@@ -162,8 +163,9 @@ hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const
     return hipSuccess;
 }
 // (the emulator has no on-demand kernels: every shape it was not compiled for runs the runtime-dims body)
-int step_kernel_kind(const Dims&) { return 0; }
-int prepare_step(const Dims&, std::string*) { return 0; }
+int step_kernel_kind(const Dims& d) { return small_eligible(d, Model{}, StepIO{}) ? 3 : 0; }
+int step_kernel_kind_other(const Dims&) { return 0; }
+int prepare_step(const Dims& d, std::string*) { return small_eligible(d, Model{}, StepIO{}) ? 3 : 0; }
 int prebuild_step(const Dims&, std::string*) { return 0; }
 bool spec_verified(const Dims&) { return true; }
 void mark_spec_verified(const Dims&) {}

@@ -11,6 +11,8 @@
 
 #include "mhe_bodies.h"
 #include "mhe_launch.h"
+#include "mpcqp_launch.h"
+#include "mpcqp_small_bodies.h"
 
 namespace mpcqp {
 namespace mhe {
@@ -136,6 +138,17 @@ hipError_t launch_step(const Dims& d, const Args& a, hipStream_t) {
     MHE_DISPATCH(d.NX, run_waves(d.nwaves, step_lds_doubles(d.NX), [&](EmuWave& w, int wv, double* sm) { step_body<EmuWave, NX, 15u>(w, d, a, wv, sm); }));
     return hipSuccess;
 }
+}  // namespace mhe
+
+hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
+    using namespace mhe;
+    const int grid = (d.B + SMALL_GPW - 1) / SMALL_GPW, NXv = 4 * ((d.nZ + 3) / 4);
+    MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX>(w, d, m, io, wv, sm); }));
+    return hipSuccess;
+}
+
+namespace mhe {
+
 int waves_for(int, int B, int) {
     const int groups = (B + GPW - 1) / GPW;
     return groups < 2 ? groups : 2;       // two "persistent" wavefronts: the grid-stride loop is exercised

@@ -639,3 +639,52 @@ def dense_weight_case(lib=None, B=3, which=("M", "N", "L"), seed=0):
         Jo = 0.5 * z @ m.Ht @ z + m.qt @ z + m.r
         assert abs(info["J"][i] - Jo) <= 1e-6 * max(1.0, abs(Jo)), (info["J"][i], Jo)
     return worst, mpc.hd.kernel_kind()
+
+
+def small_kernel_cases(lib=None, B=6):
+    """The small-problem step kernel (nZ̃ <= 16, box + input-bound rows, four controllers per wavefront:
+    csrc/mpcqp_small_bodies.h) against the oracle, member by member, over two periods (cold, then warm started):
+    hard u / Δu box (C2), soft input bounds with an active ϵ, measured disturbances with a D̂ preview, a non-default
+    move-blocking vector with time-varying R̂u, and a controller without any finite bound (ExplicitMPC closed form).
+    Returns the worst relative ΔU error and the kernel kinds."""
+    rng = np.random.default_rng(0)
+    worst, kinds = 0.0, []
+    cases = [
+        dict(cfg=synth.C2, kw={}, con=constraint_kwargs(synth.C2)),
+        dict(cfg=synth.Config("soft-u", nx=3, nu=2, ny=2, Hp=12, Hc=4, Cwt=1e3), kw={},
+             con=dict(umin=[-0.25, -0.3], umax=[0.25, 0.3], c_umin=[1.0, 0.5], c_umax=[0.5, 1.0], Δumax=[0.2, 0.2])),
+        dict(cfg=synth.Config("nb", nx=3, nu=2, ny=2, Hp=9, Hc=[2, 1, 3, 3], Cwt=np.inf), kw={}, con=dict(umin=[-0.5, -0.4], umax=[0.5, 0.6])),
+        dict(cfg=synth.Config("free", nx=3, nu=3, ny=2, Hp=8, Hc=4, Cwt=np.inf), kw={}, con={}),
+    ]
+    for case in cases:
+        cfg, con = case["cfg"], case["con"]
+        Hc = cfg.Hc
+        bt = synth.make_batch(synth.Config(cfg.name, nx=cfg.nx, nu=cfg.nu, ny=cfg.ny, Hp=cfg.Hp, Hc=len(Hc) if isinstance(Hc, list) else Hc), B, seed=41)
+        mk = dict(Hp=cfg.Hp, Hc=Hc, Cwt=cfg.Cwt, Mwt=np.full(cfg.ny, cfg.Mwt), Nwt=np.full(cfg.nu, cfg.Nwt), Lwt=np.full(cfg.nu, 0.05))
+        mpc = mpcqp.BatchLinMPC(bt["Ahat"], bt["Bhu"], bt["Chat"], lib=lib, **mk)
+        mpc.setconstraint(**con)
+        ors = []
+        for i in range(B):
+            m = cd.LinMPCOracle(bt["Ahat"][i], bt["Bhu"][i], bt["Chat"][i], **mk)
+            m.setconstraint(**{k.replace("Δ", "d"): v for k, v in con.items()})
+            ors.append(m)
+        lu = bt["lastu0"].copy()
+        mpc.lastu0 = lu.copy()
+        nDU = mpc.nDU
+        for period in range(2):
+            x0 = bt["xhat0"] * (1.0 - 0.2 * period)
+            Ru = 0.2 * rng.standard_normal((B, mpc.nU))
+            mpc.moveinput(x0, bt["ry"], Rhatu=Ru)
+            assert np.all(mpc.status == 0), (cfg.name, mpc.status)
+            for i, m in enumerate(ors):
+                m.initpred(x0[i], lu[i], bt["ry"][i], Rhatu=Ru[i])
+                m.linconstraint()
+                z, st, _ = qp.solve_qp(*m.qp_data(), m.warmstart(), return_info=True)
+                assert st == 0
+                m.Zt = z
+                worst = max(worst, np.abs(mpc.Z[i, :nDU] - z[:nDU]).max() / max(1.0, np.abs(z[:nDU]).max()))
+                if mpc.neps:
+                    worst = max(worst, abs(mpc.Z[i, -1] - z[-1]) / max(1.0, abs(z[-1])))
+            lu = mpc.lastu0.copy()
+        kinds.append(mpc.hd.kernel_kind())
+    return worst, kinds

@@ -118,7 +118,9 @@ def test_c_client_runs_steps_on_gpu(tmp_path, hiplib):
         fx = str(tmp_path / f"{name}.bin")
         write_c_fixture(fx, name, 16)
         out = subprocess.run([exe, "run", fx], capture_output=True, text=True)
-        assert out.returncode == 0 and "run ok" in out.stdout and "kernel kind 1" in out.stdout, out.stdout + out.stderr
+        # (C2 qualifies for the small-problem kernel, kind 3; C3 runs its ahead-of-time specialisation, kind 1)
+        want = "kernel kind 3" if name == "C2" else "kernel kind 1"
+        assert out.returncode == 0 and "run ok" in out.stdout and want in out.stdout, out.stdout + out.stderr
 
 
 def test_multi_device_entry_points_on_gpu(hiplib):
@@ -578,3 +580,33 @@ def test_audit_of_the_convergence_test(hiplib):
     ipm = ~pol                                                     # the others ended on the interior-point criterion
     assert np.all(au["mu"][ipm] <= 1e-12) and np.all(au["rp"][ipm] <= 1e-9)
     assert np.all(np.isfinite(au["rd"])) and np.all(au["rd"] <= 1e-6)
+
+
+def test_small_problem_kernel_on_gpu(hiplib):
+    """Four controllers per wavefront (nZ̃ <= 16, box + input-bound rows): C2, soft input bounds, move blocking with R̂u,
+    no bounds at all -- every member vs the oracle over a cold and a warm-started period."""
+    from tests.parity_util import small_kernel_cases
+    worst, kinds = small_kernel_cases(B=9)
+    assert worst <= TOL, worst
+    assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
+
+
+def test_small_problem_kernel_full_batch_C2(hiplib):
+    """65536 C2 controllers on the small-problem kernel: all optimal (the wide-neighbourhood safeguard of the step
+    length matters: instance 10539 cycles without it), bounds respected, first 64 against the oracle."""
+    cfg = synth.C2
+    B = 65536
+    bt = synth.make_batch(cfg, B, seed=0)
+    mpc = make_controller(cfg, bt)
+    assert mpc.hd.kernel_kind() == mpcqp.api.KERNEL_SMALL
+    mpc.lastu0 = bt["lastu0"].copy()
+    u = mpc.moveinput(bt["xhat0"], bt["ry"])
+    assert np.all(mpc.status == 0) and mpc.iters.max() <= 40
+    nDU = cfg.nu * cfg.Hc
+    DU = mpc.Z[:, :nDU]
+    assert DU.max() <= cfg.dumax + 1e-9 and DU.min() >= cfg.dumin - 1e-9
+    U = np.cumsum(DU.reshape(B, cfg.Hc, cfg.nu), axis=1) + bt["lastu0"][:, None, :]
+    assert U.max() <= cfg.umax + 1e-9 and U.min() >= cfg.umin - 1e-9
+    sub = {k: (v[:64] if isinstance(v, np.ndarray) else v) for k, v in bt.items()}
+    ref = oracle_batch(cfg, sub)
+    assert rel_err(mpc.Z[:64], ref["Z"], nDU).max() <= TOL
