@@ -909,9 +909,11 @@ struct Solver {
                     const double sig = (mas / mrows) / mu;
                     smu = sig * sig * sig * mu;
                 } else {
-                    // fraction to the boundary 0.9999 (the wide-neighbourhood safeguard of the LinMPC kernel costs a
-                    // pass over the rows per iteration and did not lower the iteration count on MHE problems)
-                    alpha = fmin(1.0, 0.9999 * amin);
+                    // fraction to the boundary 0.9999 (the wide-neighbourhood safeguard of the LinMPC kernels costs a
+                    // pass over the rows per iteration here and did not lower the iteration count on MHE problems).
+                    // An unguarded 0.9999 can jam a rare instance into a cycle (seen once in 65536 C2 controllers,
+                    // mpcqp_small_bodies.h): a solve still running after 20 iterations continues with 0.99.
+                    alpha = fmin(1.0, (pass >= 20 ? 0.99 : 0.9999) * amin);
                 }
             }
             if (!w.any(!done)) break;
