@@ -170,7 +170,8 @@ class BatchMHE:
     Ahat (B,nx̂,nx̂), Bhu (B,nx̂,nu), Chm (B,nym,nx̂) [rows i_ym of Ĉ], Bhd (B,nx̂,nd), Dhdm (B,nym,nd): the
     augmented model of `augment_model` (src/estimator/construct.jl).  Covariances as in the reference:
     `σP_0`, `σQ`, `σR` standard deviations of the AUGMENTED state / measured outputs (vectors, shared or
-    (B,n)), or full matrices `P̂_0`, `Q̂`, `R̂` ((B,n,n)).  `Cwt` must stay Inf (hard constraints only)."""
+    (B,n)), or full matrices `P̂_0`, `Q̂`, `R̂` ((B,n,n)).  `Cwt` = Inf (default): hard constraints only; a finite
+    `Cwt` adds the slack ε and enables the softness keywords `c_x̂min … c_v̂max` of `setconstraint`."""
 
     def __init__(self, Ahat, Bhu, Chm, Bhd=None, Dhdm=None, *, He, σP_0=None, σQ=None, σR=None, P̂_0=None, Q̂=None,
                  R̂=None, Cwt=np.inf, direct=True, uop=None, yop_m=None, dop=None, x̂op=None, f̂op=None, device=0,
