@@ -277,7 +277,7 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
 #define MPCQP_KERNEL_AOT       1
 #define MPCQP_KERNEL_ONDEMAND  2
 #define MPCQP_KERNEL_SMALL     3   /* nZ~ <= 16 with box and input-bound rows only: four controllers per wavefront
-                                    * (csrc/mpcqp_small_bodies.h); a step that also asks for Y^ or fuses the Kalman steps
+                                    * (csrc/mpcqp_small_bodies.h); a step that fuses the Kalman steps (mpcqp_loop_device)
                                     * runs on the kernel the other rules select */
 int mpcqp_prepare(mpcqp_handle h);
 /* LDS bytes one problem needs in the step kernel (160 KB per CU: the number of problems resident per CU follows). */

@@ -759,7 +759,7 @@ static int self_test_spec(mpcqp_handle h, double* worst) {
     d.flags = (d.flags | MPCQP_FLAG_COLD_START) & ~(uint32_t)(MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL);
     const size_t n = d.B, nry = (d.flags & MPCQP_FLAG_RY_CONSTANT) ? d.ny : d.nY;
     const size_t cnt[] = {n * d.nxh, n * d.nu, n * nry, n * (d.nd ? d.nd : 1), n * (d.nD ? d.nD : 1), n * d.nZ, n * d.nZ, n * d.nu, n * d.nu};
-    DBuf yh;                      // (asking for Ŷ keeps the step off the small-problem kernel: the specialisation is what is tested)
+    DBuf yh;                      // (Ŷ as well: the specialisation's predict! path is part of what is tested)
     { int rcy = dev_alloc(h, yh, n * d.nY * sizeof(double)); if (rcy) return rcy; }
     std::vector<double> host(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4], 0.0);
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
@@ -782,7 +782,8 @@ static int self_test_spec(mpcqp_handle h, double* worst) {
     if (d.nd) { io.d0 = pin + cnt[0] + cnt[1] + cnt[2]; io.Dhat0 = io.d0 + cnt[3]; }
     io.Z = pout; io.u0 = pout + cnt[5] + cnt[6]; io.status = pst; io.iters = pst + n;
     io.Yhat0 = (double*)yh.p;
-    HIPCHK(launch_step(d, h->m, io, h->stream));
+    io.kf_predict = 0;
+    HIPCHK(launch_step_spec_or_aot(d, h->m, io, h->stream));
     io.Z = pout + cnt[5]; io.u0 = pout + cnt[5] + cnt[6] + cnt[7]; io.status = pst + 2 * n; io.iters = pst + 3 * n;
     HIPCHK(launch_step_generic(d, h->m, io, h->stream));
     std::vector<double> z(cnt[5] + cnt[6]);

@@ -343,6 +343,11 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
 
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
     if (!force_generic() && small_eligible(d, m, io)) return launch_step_small(d, m, io, st);
+    return launch_step_spec_or_aot(d, m, io, st);
+}
+
+// the one-QP-per-wavefront kernels: ahead-of-time specialisation, on-demand specialisation, runtime dimensions
+hipError_t launch_step_spec_or_aot(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
     if (!force_generic() && !d.dense_w) {      // (dense M_Hp / L_Hp: runtime-dimension kernel, like custom constraints)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
         {                                                                           \

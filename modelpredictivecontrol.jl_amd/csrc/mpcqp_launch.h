@@ -11,6 +11,7 @@ namespace mpcqp {
 hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStream_t st);
 hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st);
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
+hipError_t launch_step_spec_or_aot(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);   // never the small-problem kernel
 size_t step_lds_bytes(const Dims& d);
 // kernel a step runs on: 0 runtime-dimension kernel, 1 ahead-of-time specialisation, 2 on-demand specialisation
 int step_kernel_kind(const Dims& d);
@@ -27,8 +28,8 @@ hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hi
 inline bool small_eligible(const Dims& d, const Model& m, const StepIO& io) {
     static const bool on = [] { const char* e = getenv("MPCQP_SMALL"); return !(e && e[0] == '0'); }();
     return on && d.nZ <= 16 && (d.gmask & ~0xFu) == 0 && d.nw == 0 && !d.dense_w && !m.Mblk && !m.Mfull &&
-           !(d.flags & (4u | 8u)) && !io.Yhat0 && !io.kf_y0m && !io.kf_predict && !io.q_keep && !io.lam_out &&
-           (size_t)d.nY * 4 * sizeof(double) <= 64 * 1024;
+           !(d.flags & (4u | 8u)) && !io.kf_y0m && !io.kf_predict && !io.q_keep && !io.lam_out &&
+           (size_t)(2 * d.nY + 16) * 4 * sizeof(double) <= 64 * 1024;
 }
 hipError_t launch_kf_correct(const Dims& d, const Model& m, const KfParams& kf, double* xhat0,
                              const double* y0m, const double* d0, hipStream_t st);

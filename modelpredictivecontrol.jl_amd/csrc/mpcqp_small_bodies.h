@@ -22,7 +22,8 @@ namespace mpcqp {
 
 constexpr int SMALL_GPW = 4, SMALL_RL = 16;
 
-MPCQP_HD inline size_t small_lds_doubles(const Dims& d) { return (size_t)SMALL_GPW * d.nY; }
+// per group: M(F - R̂y) and F (nY each) and the optimum (16) for the optional Ŷ output
+MPCQP_HD inline size_t small_lds_doubles(const Dims& d) { return (size_t)SMALL_GPW * (2 * d.nY + SMALL_RL); }
 
 template <class W, int NX>
 MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO& io, int wg, double* smem) {
@@ -36,7 +37,9 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     const int nx = d.nxh, nu = d.nu, ny = d.ny, nd = d.nd, nY = d.nY, nDU = d.nDU, nZ = d.nZ, Hp = d.Hp, Hc = d.Hc;
     const int e = nDU;                         // index of ϵ (when neps)
     const bool isvar = l < nZ, isdu = l < nDU, iseps = d.neps && l == e;
-    double* cyv = smem + (size_t)g * nY;
+    double* cyv = smem + (size_t)g * (2 * nY + SMALL_RL);
+    double* Fv = cyv + nY;          // F, kept for the optional Ŷ output
+    double* zv = Fv + nY;           // the optimum, for the same
     const double* x0 = io.xhat0 + (size_t)b * nx;
     const double* lu = io.lastu0 + (size_t)b * nu;
     const double* Stab = m.Stab + (size_t)b * Hp * ny * nu;          // Σ_t [Hp][ny][nu]
@@ -66,6 +69,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             }
             const double ry = rconst ? io.Ry[(size_t)b * ny + a] : io.Ry[(size_t)b * nY + r];
             cyv[r] = Md[r] * (acc - ry);
+            Fv[r] = acc;
         }
     }
     w.sync();
@@ -268,6 +272,17 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     // never primal-feasible (or NaN) => the reference's error branch (execute.jl:484-489): the shifted warm start
     if (st == 1 && !(rpn <= 1e-6 * nh)) st = 2;
     if (st == 2) z = zws;
+    if (io.Yhat0) {          // predict! (transcription.jl:1136-1145): Ŷ0 = Ẽ Z̃ + F
+        zv[l] = isdu ? z : 0.0;
+        w.sync();
+        for (int r = l; r < nY; r += SMALL_RL) {
+            const int t = r / ny, a = r - t * ny;
+            double acc = Fv[r];
+            for (int j = 0; j < Hc && jl(j) <= t; ++j)
+                for (int cc = 0; cc < nu; ++cc) acc += Stab[((t - jl(j)) * ny + a) * nu + cc] * zv[j * nu + cc];
+            if (live) io.Yhat0[(size_t)b * nY + r] = acc;
+        }
+    }
     if (live) {
         if (isvar) io.Z[(size_t)b * nZ + l] = z;
         if (l < nu) io.u0[(size_t)b * nu + l] = z + lu[l];          // getinput!: u0 = lastu0 + ΔU[1:nu]

@@ -127,6 +127,10 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t) {
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
     const char* fg = getenv("MPCQP_FORCE_GENERIC");
     if (!(fg && fg[0] == '1') && small_eligible(d, m, io)) return launch_step_small(d, m, io, st);
+    return launch_step_spec_or_aot(d, m, io, st);
+}
+hipError_t launch_step_spec_or_aot(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
+    const char* fg = getenv("MPCQP_FORCE_GENERIC");
     if (!(fg && fg[0] == '1') && !d.dense_w) {
 #define XNB(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 0)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM) XX(NU, NY, NXH, HP, HC, NEPS, GM, 1)
