@@ -355,6 +355,6 @@ def test_dense_weight_matrices_on_cpu_emulator(emulib, which):
 def test_small_problem_kernel_on_cpu_emulator(emulib):
     """csrc/mpcqp_small_bodies.h (four controllers per wavefront for nZ̃ <= 16) vs the oracle."""
     from tests.parity_util import small_kernel_cases
-    worst, kinds = small_kernel_cases(lib=emulib, B=5)
+    worst, kinds = small_kernel_cases(lib=emulib, B=4)          # one wavefront per case
     assert worst <= 1e-6, worst
     assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
