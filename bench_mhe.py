@@ -146,7 +146,7 @@ def run(args, rank, world, local, dist):
                      "flops_per_solve": flops,
                      "note": "FP64 vector peak (v_fma_f64; the kernel's blocks are 12 x 12, below the 16 x 16 x 4 MFMA "
                              "tile, and run on v_fma_f64 + DPP row broadcasts); flops = setup + I W_iter, block "
-                             "tridiagonal count, I = mean factorisations per solve; the window state of a wavefront (257 KB) "
+                             "tridiagonal count, I = mean factorisations per solve; the window state of a wavefront (~190 KB) "
                              "streams through HBM: traffic / kernel_ms is the measured HBM rate (peak 8000 GB/s), the "
                              "limiter of this kernel next to its dependent sweeps"},
     }
