@@ -116,3 +116,62 @@ def reference_known_answers(lib=None, B=2, forms=(True, False)):
         res["tol"] = 1e-3 if direct else 1e-2
         out[direct] = res
     return out
+
+
+def random_family(seed, lib=None, B=5):
+    """One randomised MovingHorizonEstimator family (dimensions, form, horizon, bound classes, hard / soft) driven
+    through He + 3 periods on the product and on oracle/mhe.py, every member compared.  Returns (worst relative
+    error over the periods where the oracle's QP was solved, number of compared solves, failures seen)."""
+    rng = np.random.default_rng(1000 + seed)
+    nx, nym = int(rng.integers(1, 9)), int(rng.integers(1, 5))
+    kw = dict(nx=nx, nu=int(rng.integers(0, 4)), nym=nym, nd=int(rng.integers(0, 3)), He=int(rng.integers(1, 11)),
+              direct=bool(rng.integers(0, 2)))
+    cls = int(rng.integers(0, 6))           # 0 none, 1 x̂, 2 ŵ, 3 v̂, 4 x̂ + v̂, 5 ŵ + v̂
+    if cls in (1, 4):
+        kw["xabs"] = float(rng.uniform(0.6, 2.0))
+    if cls in (2, 5):
+        kw["wabs"] = float(rng.uniform(0.1, 0.4))
+    if cls in (3, 4, 5):
+        kw["vabs"] = float(rng.uniform(0.3, 0.8))
+    soft = cls != 0 and rng.random() < 0.4
+    if soft:
+        kw["Cwt"] = float(10.0 ** rng.uniform(2, 5))
+    cfg = synth.MheConfig(f"fam{seed}", **kw)
+    bt = synth.make_mhe_batch(cfg, B, seed=seed)
+    bounds = bounds_of(cfg)
+    if soft:
+        nxh = cfg.nxh
+        for key, n in (("xhat", nxh), ("what", nxh), ("vhat", cfg.nym)):
+            if key + "min" in bounds:
+                bounds["c_" + key + "min"] = np.where(rng.random(n) < 0.6, rng.uniform(0.2, 1.5, n), 0.0)
+                bounds["c_" + key + "max"] = np.where(rng.random(n) < 0.6, rng.uniform(0.2, 1.5, n), 0.0)
+    nper = cfg.He + 3
+    Y, U, D = synth.make_mhe_data(cfg, bt, nper, seed=seed)
+    bm = make_product(cfg, bt, lib=lib, bounds=bounds)
+    ors = make_oracles(cfg, bt, range(B), bounds=bounds)
+    clean = np.ones(B, bool)
+    worst, ncmp, nfail = 0.0, 0, 0
+    for k in range(nper):
+        y, u, d = Y[k], U[k], (D[k] if cfg.nd else None)
+        xg = bm.preparestate(y, d)
+        if not cfg.direct:
+            xg = bm.updatestate(u, y, d)
+        for b, e in enumerate(ors):
+            xo = e.preparestate(y[b], d[b] if cfg.nd else ())
+            if not cfg.direct:
+                xo = e.updatestate(u[b], y[b], d[b] if cfg.nd else ())
+            if not clean[b]:
+                continue
+            if e.status != 0:                  # infeasible window (x̂ + v̂ or ŵ + v̂ bounds can contradict the data)
+                assert bm.status[b] != 0, (seed, k, b, "the oracle failed, the product reports success")
+                clean[b] = False
+                nfail += 1
+                continue
+            assert bm.status[b] == 0, (seed, k, b, "the product failed on a window the oracle solved", kw)
+            worst = max(worst, np.abs(xg[b] - xo).max() / max(1.0, np.abs(xo).max()))
+            ncmp += 1
+        if cfg.direct:
+            bm.updatestate(u, y, d)
+            for b, e in enumerate(ors):
+                e.updatestate(u[b], y[b], d[b] if cfg.nd else ())
+    return worst, ncmp, nfail
