@@ -89,7 +89,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         qv = 2.0 * acc;
     }
     // ---- H̃ (row l), the input-bound matrices: rows of the lower / upper merged rows and of their transposes
-    Row H, Glo, Ghi, GloT, GhiT;
+    Row H, GU, GUt;          // P̃u (held cumulative sum) row of this lane's (interval, channel) and the row of its transpose
     const double* Hpk = m.Hpk + (size_t)b * d.npk;
     // softness of this lane's merged rows: the one of the interval's first step (Step::soft_init)
     double cs0 = 0.0, cs1 = 0.0;
@@ -105,16 +105,22 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         const bool same = isdu && c < nDU && cc == cme;
         const double gu = (same && jc <= jme) ? 1.0 : 0.0;           // P̃u row of (interval, channel) l: held cumulative sum
         const double gut = (same && jc >= jme) ? 1.0 : 0.0;
-        Glo[c] = -gu; Ghi[c] = gu; GloT[c] = -gut; GhiT[c] = gut;
+        GU[c] = gu; GUt[c] = gut;
     });
-    if (d.neps) {       // the ϵ column of the rows (-softness) and, for lane ϵ, the softness of every row
-        mhe::sfor<NX>([&](auto ic) {
-            constexpr int c = decltype(ic)::v;
-            if (c == e) { Glo[c] = isdu ? -cs0 : 0.0; Ghi[c] = isdu ? -cs1 : 0.0; }
-            const double s0c = w.template rowbc<c>(cs0), s1c = w.template rowbc<c>(cs1);
-            if (iseps) { GloT[c] = c < nDU ? -s0c : 0.0; GhiT[c] = c < nDU ? -s1c : 0.0; }
-        });
-    }
+    // The merged rows are  -P̃u z - cs0 ϵ <= h2  and  P̃u z - cs1 ϵ <= h3: their ΔU part shares P̃u, the ϵ part is the
+    // lane's softness -- applied by hand (gmul / gtmul below) instead of carrying four register rows.
+    auto epsof = [&](double v) { return d.neps ? w.rsum(iseps ? v : 0.0) : 0.0; };            // component ϵ of a vector
+    // G v for the two merged rows of this lane
+    auto gmul = [&](double v, double& glo, double& ghi) {
+        const double pu = op.mv(GU, v), ve = epsof(v);
+        glo = -pu - cs0 * ve; ghi = pu - cs1 * ve;
+    };
+    // (Gu' w)[l] for multipliers / coefficients w2 (lower rows), w3 (upper rows) of every lane
+    auto gtmul = [&](double w2, double w3) {
+        const double x = op.mv(GUt, w3 - w2);
+        const double se_ = d.neps ? w.rsum(cs0 * w2 + cs1 * w3) : 0.0;
+        return iseps ? -se_ : x;
+    };
     // ---- rows of this lane: 0 box lower, 1 box upper, 2 merged Umin, 3 merged Umax          (i_b: finite only)
     double h0 = 2.0 * BIG, h1 = 2.0 * BIG, h2 = 2.0 * BIG, h3 = 2.0 * BIG, wt = 1.0;
     if (isdu) {
@@ -152,7 +158,8 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     // starting point: s = max(h - G z, 1), λ = 10 w / s
     double s0, s1, s2, s3, l0, l1, l2, l3;
     {
-        const double g2 = op.mv(Glo, z), g3 = op.mv(Ghi, z);
+        double g2, g3;
+        gmul(z, g2, g3);
         s0 = fmax(h0 + z, 1.0); s1 = fmax(h1 - z, 1.0); s2 = fmax(h2 - g2, 1.0); s3 = fmax(h3 - g3, 1.0);
         if (!p0) s0 = 1.0; if (!p1) s1 = 1.0; if (!p2) s2 = 1.0; if (!p3) s3 = 1.0;
         l0 = p0 ? 10.0 * w0 / s0 : 0.0; l1 = p1 ? 10.0 * w1 / s1 : 0.0; l2 = p2 ? 10.0 * w2 / s2 : 0.0; l3 = p3 ? 10.0 * w3 / s3 : 0.0;
@@ -171,10 +178,11 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     };
     for (int pass = 0; pass < d.max_iter; ++pass) {
         // ---- residuals
-        const double g2 = op.mv(Glo, z), g3 = op.mv(Ghi, z);
+        double g2, g3;
+        gmul(z, g2, g3);
         const double rp0 = -z + s0 - h0, rp1 = z + s1 - h1, rp2 = g2 + s2 - h2, rp3 = g3 + s3 - h3;
         const double hz = op.mv(H, z);
-        const double gl = (p1 ? l1 : 0.0) - (p0 ? l0 : 0.0) + op.mv(GloT, p2 ? l2 : 0.0) + op.mv(GhiT, p3 ? l3 : 0.0);
+        const double gl = (p1 ? l1 : 0.0) - (p0 ? l0 : 0.0) + gtmul(p2 ? l2 : 0.0, p3 ? l3 : 0.0);
         const double rd = isvar ? hz + qv + gl : 0.0;
         rpn = w.rmax(fmax(fmax(p0 ? fabs(rp0) : 0.0, p1 ? fabs(rp1) : 0.0), fmax(p2 ? fabs(rp2) : 0.0, p3 ? fabs(rp3) : 0.0)));
         const double rdn = w.rmax(fabs(rd));
@@ -198,12 +206,19 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         // ---- Φ = H̃ + Gᵀ D̃ G, Φ⁻¹
         const RowD d0 = rowd(p0, s0, l0), d1 = rowd(p1, s1, l1), d2 = rowd(p2, s2, l2), d3 = rowd(p3, s3, l3);
         Row Phi, T, U;
-        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = H[c]; T[c] = d2.Dt * Glo[c]; });
+        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = H[c]; T[c] = (d2.Dt + d3.Dt) * GU[c]; });
         O::add_diag(Phi, l, d0.Dt + d1.Dt);
-        op.mm(GloT, T, U);
-        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += U[c]; T[c] = d3.Dt * Ghi[c]; });
-        op.mm(GhiT, T, U);
+        op.mm(GUt, T, U);                              // P̃u' (D̃2 + D̃3) P̃u
         mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += U[c]; });
+        if (d.neps) {      // ϵ column / row: Φ[k][ϵ] = sum_j P̃u[j][k] (D̃2 cs0 - D̃3 cs1)_j,  Φ[ϵ][ϵ] += sum_j D̃2 cs0² + D̃3 cs1²
+            const double col = op.mv(GUt, d2.Dt * cs0 - d3.Dt * cs1);
+            const double dee = w.rsum(d2.Dt * cs0 * cs0 + d3.Dt * cs1 * cs1);
+            mhe::sfor<NX>([&](auto ic) {
+                constexpr int c = decltype(ic)::v;
+                const double rowv = w.template rowbc<c>(col);          // Φ[ϵ][c] = Φ[c][ϵ]
+                Phi[c] += iseps ? (c == e ? dee : (c < nDU ? rowv : 0.0)) : ((c == e && isdu) ? col : 0.0);
+            });
+        }
         const bool ok = op.gj(Phi, l);
         if (!done && !ok) { st = 2; done = true; }
         // ---- predictor, corrector
@@ -218,10 +233,11 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             const double e2 = phase ? a2 - w2 * smu : 0.0, e3 = phase ? a3 - w3 * smu : 0.0;
             const double c0 = cof(p0, d0, s0, l0, rp0, e0), c1 = cof(p1, d1, s1, l1, rp1, e1);
             const double c2 = cof(p2, d2, s2, l2, rp2, e2), c3 = cof(p3, d3, s3, l3, rp3, e3);
-            const double gtc = op.mv(GloT, c2) + op.mv(GhiT, c3);       // (every lane takes part in the mat-vecs)
+            const double gtc = gtmul(c2, c3);                           // (every lane takes part in the mat-vecs)
             const double rhs = isvar ? -rd + (c1 - c0) + gtc : 0.0;
             dz = op.mv(Phi, rhs);
-            const double gd2 = op.mv(Glo, dz), gd3 = op.mv(Ghi, dz);
+            double gd2, gd3;
+            gmul(dz, gd2, gd3);
             auto dir = [&](bool has, const RowD& rr, double sv, double lv, double rp, double gd, double ex, double& ds, double& dl) {
                 const double rc = sv * lv + ex;
                 dl = has ? -rr.wv * rc / sv + rr.Dt * (rp + gd) : 0.0;
