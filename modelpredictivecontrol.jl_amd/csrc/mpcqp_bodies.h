@@ -61,6 +61,47 @@ MPCQP_HD inline double rcp(double x) {
 #endif
 }
 
+// v_rcp_f64 alone (4.6e-8 relative): the ratio tests of the step length, where a fraction-to-the-boundary factor of
+// 0.99 .. 0.9999 makes that precision irrelevant.
+MPCQP_HD inline double rcp_fast(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    return 1.0 / x;
+#endif
+}
+
+// min / max without the operand canonicalisation (v_max_f64 x, x, x in front of every llvm.maxnum in IEEE mode):
+// NaN handling is the instruction's own (a NaN operand loses), which is what fmin / fmax specify as well.
+MPCQP_HD inline double fmx(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fmax(a, b);
+#endif
+}
+MPCQP_HD inline double fmn(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fmin(a, b);
+#endif
+}
+// max(a, |b|)
+MPCQP_HD inline double fmx_abs(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fmax(a, fabs(b));
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // Compile-time dimensions: same member names as the runtime `Dims`, so the bodies below are
 // written once against a dims policy DM.  Specialised kernels (mpcqp_dispatch.h) give the
@@ -293,6 +334,24 @@ struct Qp {
     // of lane-dependent length: lane k = (j, c) holds x[k] (0 on lanes >= nDU), log2(Hc) steps of
     // "fetch the value s blocks away and add".  One value per lane: nDU <= 64.  All lanes call.
     MPCQP_HD double block_prefix(double x) {            // sum_{jj <= j} x[(jj, c)]
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) {
+            if constexpr (DM::nu == 4 && DM::nDU <= WAVE) {
+                // four blocks per 16-lane row: inclusive scan inside the row by two row shifts (zero fill), then the
+                // totals of the rows before (their last block) in ONE round of independent fetches
+                x += W::template dpp<0x114>(x);          // row_shr:4
+                x += W::template dpp<0x118>(x);          // row_shr:8
+                const int row = w.lane >> 4, cc = w.lane & 3;
+                double carry = 0.0;
+                MPCQP_UNROLL
+                for (int rr = 1; rr <= (DM::Hc - 1) / 4; ++rr) {
+                    const double y = w.fetch(x, ((row - rr) << 4) + 12 + cc);
+                    carry += row >= rr ? y : 0.0;
+                }
+                return x + carry;
+            }
+        }
+#endif
         const int nu = d.nu, j = w.lane / nu;
         for (int s_ = 1; s_ < d.Hc; s_ <<= 1) {
             const double y = w.fetch(x, w.lane - s_ * nu);
@@ -301,6 +360,22 @@ struct Qp {
         return x;
     }
     MPCQP_HD double block_suffix(double x) {            // sum_{jj >= j} x[(jj, c)]
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) {
+            if constexpr (DM::nu == 4 && DM::nDU <= WAVE) {
+                x += W::template dpp<0x104>(x);          // row_shl:4
+                x += W::template dpp<0x108>(x);          // row_shl:8
+                const int row = w.lane >> 4, cc = w.lane & 3;
+                double carry = 0.0;
+                MPCQP_UNROLL
+                for (int rr = 1; rr <= (DM::Hc - 1) / 4; ++rr) {
+                    const double y = w.fetch(x, ((row + rr) << 4) + cc);      // lanes >= nDU hold zeros
+                    carry += row + rr < 4 ? y : 0.0;
+                }
+                return x + carry;
+            }
+        }
+#endif
         const int nu = d.nu, j = w.lane / nu;
         for (int s_ = 1; s_ < d.Hc; s_ <<= 1) {
             const double y = w.fetch(x, w.lane + s_ * nu);
@@ -420,8 +495,12 @@ struct Qp {
     // time; the 16-wide tiles run over the ΔU index; E is never formed -- operands come straight
     // from the block-Toeplitz table, and tiles whose block columns start after step t are skipped.
     typedef double v4d __attribute__((ext_vector_type(4)));
-    // returns the first step t whose rows the ϵ row (tb) has been accumulated for (-1: no ϵ row)
-    __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb) {
+    // returns the first step t whose rows the ϵ row (tb) has been accumulated for (-1: no ϵ row).
+    // Hg != nullptr: P is OVERWRITTEN with Hg (packed H̃ in global memory) + scale * E'DE on the whole stored
+    // triangle (ϵ row and its diagonal included) instead of being updated in place -- no staging of H̃ in LDS and
+    // no read-modify-write of the tiles; the H̃ entries are fetched in the accumulator layout before the K loop.
+    __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb,
+                                                 const double* Hg = nullptr) {
         MPCQP_RELANE(2);
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp, RS = DM::rs;
         constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
@@ -458,6 +537,34 @@ struct Qp {
             // ϵ row (index NDU, when present): row NDU of Phi is sum_r tb[r] E[r,:], i.e. the same
             // contraction with A operand tb instead of E*dd -- rides in its tile row for free
             const bool erow = DM::neps && tb != nullptr && IE >= I0 && IE <= I1;
+            // entry (reg) of tile (I, J) held by this lane: row i = 16 I + 4 reg + lk, column ip = 16 J + li; with
+            // G = 4 I + reg the packed index pk(i, ip) = 8 G (G + 1) + 16 J + 4 (G + 1) lk + li is linear in the lane's
+            // (lk, li) with compile-time coefficients
+            auto entry_ok = [&](int I, int J, int reg) {
+                const bool eI = erow && I == IE;
+                const int il = 4 * reg + lk;                           // row inside the tile
+                const bool rowok = 16 * I + 15 < NDU || 16 * I + il < NDU;
+                const bool colok = 16 * J + 15 < NDU || 16 * J + li < NDU;
+                const bool low = J < I || li <= il;
+                return colok && ((rowok && low) || (eI && il == LE));
+            };
+            auto entry_idx = [&](int I, int J, int reg) {
+                const int G = 4 * I + reg;
+                return 8 * G * (G + 1) + 16 * J + 4 * (G + 1) * lk + li;
+            };
+            // H̃ in the accumulator layout, requested now and consumed by the write-back
+            double hreg[2][MAXT][4];
+            if (Hg) {
+                MPCQP_UNROLL
+                for (int I = I0; I <= I1; ++I) {
+                    MPCQP_UNROLL
+                    for (int J = 0; J <= I; ++J) {
+                        MPCQP_UNROLL
+                        for (int reg = 0; reg < 4; ++reg)
+                            hreg[I - I0][J][reg] = Hg[entry_ok(I, J, reg) ? (unsigned)entry_idx(I, J, reg) : 0u];
+                    }
+                }
+            }
             // First K step at which tile row I sees a block column that has started (t >= j_l of
             // its first column); the ϵ row needs every step.  The K loop is split at these points
             // so that its bodies are branch-free (accumulators stay in place across iterations).
@@ -474,43 +581,72 @@ struct Qp {
             // One K step: operands straight from the Σ table.  A lane whose block column has not
             // started at step t reads the zero slot (no select on the value).  With ny a multiple
             // of 4 the step t of the four K rows is wave-uniform and every row exists.
+            // The operands of step kk + 1 are requested before the matrix-core instructions of step kk are issued
+            // (software pipeline: a lone wave otherwise sits out one LDS round trip per K step).
             const int zoff = (int)((sm + c.zero) - S);       // the zero slot as an index from block 0 of the table
-            auto kstep = [&](int kk, bool row0, bool row1) {
-                double dv, tbv = 0.0, e[NT];
+            struct Ops { double dv, tbv, e[NT]; };
+            auto kload = [&](int kk, Ops& o) {
+                o.tbv = 0.0;
                 if constexpr (NY % 4 == 0) {
                     const int t = (4 * kk) / NY, a0 = 4 * kk - t * NY;         // uniform
                     const int base = t * SP + a0 * RS;
-                    dv = dd[4 * kk + lkp];
-                    if (erow) tbv = tb[4 * kk + lkp];
+                    o.dv = dd[4 * kk + lkp];
+                    if (erow) o.tbv = tb[4 * kk + lkp];
                     MPCQP_UNROLL
-                    for (int J = 0; J <= I1; ++J) e[J] = S[(DM::zpad || t >= jI[J]) ? base + offL[J] : zoff];
+                    for (int J = 0; J <= I1; ++J) o.e[J] = S[(DM::zpad || t >= jI[J]) ? base + offL[J] : zoff];
                 } else {
                     const int r = 4 * kk + lk;
                     const bool rok = r < NYR;
                     const int rr = rok ? r : 0;
                     const int t = rr / NY, a = rr - t * NY;
-                    dv = rok ? dd[rr] : 0.0;
-                    if (erow) tbv = rok ? tb[rr] : 0.0;
+                    o.dv = rok ? dd[rr] : 0.0;
+                    if (erow) o.tbv = rok ? tb[rr] : 0.0;
                     const int base = t * SP + a * RS;
                     MPCQP_UNROLL
-                    for (int J = 0; J <= I1; ++J) e[J] = S[(rok && (DM::zpad || t >= jI[J])) ? base + offI[J] : zoff];
+                    for (int J = 0; J <= I1; ++J) o.e[J] = S[(rok && (DM::zpad || t >= jI[J])) ? base + offI[J] : zoff];
                 }
+            };
+            auto kcomp = [&](const Ops& o, bool row0, bool row1) {
                 MPCQP_UNROLL
                 for (int I = I0; I <= I1; ++I) {
                     if (I == I0 ? !row0 : !row1) continue;
                     const bool eI = erow && I == IE;
-                    double ad = e[I] * dv;
-                    if (eI && li == LE) ad = tbv;
+                    double ad = o.e[I] * o.dv;
+                    if (eI && li == LE) ad = o.tbv;
                     MPCQP_UNROLL
                     for (int J = 0; J <= I; ++J)
-                        acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, e[J], acc[I - I0][J], 0, 0, 0);
+                        acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, o.e[J], acc[I - I0][J], 0, 0, 0);
                 }
             };
+            // (the request one step past the end reads whatever follows in LDS and is never used)
+            constexpr bool PIPE = (NY % 4 == 0) && DM::zpad > 0;
+            Ops cur, nxt;
+            if (PIPE) kload(kA, cur);
             _Pragma("unroll 2")
-            for (int kk = kA; kk < kB; ++kk) kstep(kk, true, false);
+            for (int kk = kA; kk < kB; ++kk) {
+                if (PIPE) { kload(kk + 1, nxt); MPCQP_SCHED_FENCE(); kcomp(cur, true, false); MPCQP_SCHED_FENCE(); cur = nxt; }
+                else { kload(kk, cur); kcomp(cur, true, false); }
+            }
             if (I1 > I0) {
                 _Pragma("unroll 2")
-                for (int kk = kB; kk < NK; ++kk) kstep(kk, true, true);
+                for (int kk = kB; kk < NK; ++kk) {
+                    if (PIPE) { kload(kk + 1, nxt); MPCQP_SCHED_FENCE(); kcomp(cur, true, true); MPCQP_SCHED_FENCE(); cur = nxt; }
+                    else { kload(kk, cur); kcomp(cur, true, true); }
+                }
+            }
+            if (Hg) {
+                // plain stores of H̃ + scale acc on the stored triangle
+                MPCQP_UNROLL
+                for (int I = I0; I <= I1; ++I) {
+                    MPCQP_UNROLL
+                    for (int J = 0; J <= I; ++J) {
+                        MPCQP_UNROLL
+                        for (int reg = 0; reg < 4; ++reg)
+                            if (entry_ok(I, J, reg))
+                                P[entry_idx(I, J, reg)] = fma(scale, acc[I - I0][J][reg], hreg[I - I0][J][reg]);
+                    }
+                }
+                continue;
             }
             // write-back: every lane does an unconditional read-modify-write; entries outside the
             // stored triangle go to the trash slot (no exec-masked region per entry, so the reads of
@@ -518,16 +654,13 @@ struct Qp {
             double* const trash = sm + c.zero + 4;
             MPCQP_UNROLL
             for (int I = I0; I <= I1; ++I) {
-                const bool eI = erow && I == IE;
                 MPCQP_UNROLL
                 for (int J = 0; J <= I; ++J) {
                     double* pp_[4];
                     double old_[4];
                     MPCQP_UNROLL
                     for (int reg = 0; reg < 4; ++reg) {
-                        const int i = 16 * I + lk + 4 * reg, ip = 16 * J + li;
-                        const bool ok = ip < NDU && ((i < NDU && ip <= i) || (eI && i == NDU));
-                        pp_[reg] = ok ? P + pk(i, ip) : trash;
+                        pp_[reg] = entry_ok(I, J, reg) ? P + entry_idx(I, J, reg) : trash;
                         old_[reg] = *pp_[reg];
                     }
                     MPCQP_UNROLL
@@ -535,6 +668,7 @@ struct Qp {
                 }
             }
         }
+        if (Hg && DM::neps && w.lane == 0) P[pk(NDU, NDU)] = Hg[pk(NDU, NDU)];     // Ñ's slack weight (construct.jl:842)
         return eps_t0;
     }
 #endif
@@ -542,9 +676,10 @@ struct Qp {
     // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU).  When `tb` is given
     // and the matrix-core path runs, the ϵ row P[pk(nDU, i')] += sum_r tb[r] E[r,i'] is added for the
     // rows of the steps t >= the returned value; the caller adds the rest (Et_apply_add; -1: all of it).
-    MPCQP_HD int EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr) {
+    MPCQP_HD int EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr,
+                          const double* Hg = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (DM::is_static) return EtDE_add_mfma(dd, P, scale, tb);
+        if constexpr (DM::is_static) return EtDE_add_mfma(dd, P, scale, tb, Hg);
 #endif
         // Strips of four: the packed layout (pk) stores row i as (i/4 + 1) aligned chunks of four
         // columns, chunk s of the whole triangle at P[4s..4s+3].  A lane takes a strip (i, ip0..ip0+3):
@@ -845,6 +980,7 @@ struct Row {
     double &h, &s, &lam, &rp, &gd, &pp;
     double cs;       // softness of the row (stored with runtime dims, re-derived otherwise)
     double wt = 1.0; // multiplicity of the row in the barrier (re-derived on every pass, see rowweight())
+    double* wic = nullptr;   // compile-time dims: register that keeps 1 / (s + δ lam) of the current iterate (row_wi_cached)
 };
 
 template <class DM, bool STATIC = DM::is_static>
@@ -878,10 +1014,11 @@ struct RowStore<DM, true> {
     }
     static constexpr int NSLOT = slotoff(NGROUP) > 0 ? slotoff(NGROUP) : 1;
     double a[NROWARR - 1][NSLOT];
+    double wi_[NSLOT];
     MPCQP_HD RowStore(const DM&, double*, const Carve&, int) {}
     MPCQP_HD Row at(int g, int q) {
         const int r = slotoff(g) + q;
-        return Row{a[0][r], a[1][r], a[2][r], a[3][r], a[4][r], a[5][r], 0.0};
+        return Row{a[0][r], a[1][r], a[2][r], a[3][r], a[4][r], a[5][r], 0.0, 1.0, &wi_[r]};
     }
     MPCQP_HD void set_cs(int, int, double) {}
     static constexpr bool stores_cs = false;
@@ -1361,7 +1498,17 @@ struct Step {
         w.sync();
     }
 
-    // ---- Phi += G' diag(dd) G, dd(Row&) evaluated on finite rows ------------------------------
+    // true: add_GtDG() builds Phi = H̃ + G'DG itself, H̃ read from global memory by the matrix-core pass of the Ŷ rows
+    // (EtDE_add_mfma with Hg); false: Phi must hold H̃ when add_GtDG() is called (load_H)
+    MPCQP_HD bool phi_direct() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return DM::is_static && qp.pair_on(P_Y);
+#else
+        return false;
+#endif
+    }
+
+    // ---- Phi (+)= G' diag(dd) G, dd(Row&) evaluated on finite rows (see phi_direct) ---------------
     template <class Fn>
     MPCQP_HD void add_GtDG(Fn dd) {
         MPCQP_RELANE(3);
@@ -1392,7 +1539,8 @@ struct Step {
         int eps_t0 = -1;          // first step whose Ŷ rows the matrix-core path put into the ϵ row
         if (qp.pair_on(P_Y)) {
             MPCQP_TIC();
-            eps_t0 = qp.EtDE_add(sm + c.tA[P_Y], Phi, 1.0, d.neps ? sm + c.tB[P_Y] : nullptr);
+            eps_t0 = qp.EtDE_add(sm + c.tA[P_Y], Phi, 1.0, d.neps ? sm + c.tB[P_Y] : nullptr,
+                                 phi_direct() ? m.Hpk + (size_t)b * d.npk : nullptr);
             w.sync();      // the MFMA write-back uses its own entry->lane map
             MPCQP_TOC(4);
         }
@@ -1630,7 +1778,7 @@ struct Step {
             const double idl = (v[cc] > thr) ? rsqrt_(v[cc]) : 0.0;
             const double idb = w.bcast(idl, k);
             lk[cc] = v[cc] * idb;
-            if (i == k) myinvd = fmax(idl, 1e-32);
+            if (i == k) myinvd = idl;
             MPCQP_UNROLL
             for (int c2 = cc + 1; c2 < CB; ++c2) v[c2] -= lk[cc] * w.bcast(lk[cc], K0 + c2);
         }
@@ -1676,6 +1824,7 @@ struct Step {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (DM::is_static) {
             chol_static<0>(thr);
+            myinvd = fmx(myinvd, 1e-32);
             chol_broke = w.any(act && myinvd <= 1e-32);
             MPCQP_TOC(6);
             return;
@@ -1718,7 +1867,7 @@ struct Step {
                 const double idl = (v[cc] > thr) ? rsqrt_(v[cc]) : 0.0;   // lane k: 1/sqrt(pivot), 0 if bad
                 const double idb = w.bcast(idl, k);
                 lk[cc] = v[cc] * idb;                    // lane i > k: L[i][k]
-                if (i == k) myinvd = fmax(idl, 1e-32);
+                if (i == k) myinvd = idl;
                 MPCQP_UNROLL
                 for (int c2 = cc + 1; c2 < CB; ++c2) v[c2] -= lk[cc] * w.bcast(lk[cc], k0 + c2);   // L[i][k] L[k2][k]
             }
@@ -1729,6 +1878,7 @@ struct Step {
             }
             w.sync();
         }
+        myinvd = fmx(myinvd, 1e-32);
         chol_broke = w.any(act && myinvd <= 1e-32);
         MPCQP_TOC(6);
     }
@@ -1926,8 +2076,8 @@ struct Step {
             const double hz = h0 + h1;
             const double r = hz + q[k] + gt[k];
             rd[k] = r;
-            mx = fmax(mx, fabs(r));
-            sc = fmax(sc, fmax(fabs(q[k]), fmax(fabs(hz), fabs(gt[k]))));
+            mx = fmx_abs(mx, r);
+            sc = fmx_abs(fmx_abs(fmx_abs(sc, q[k]), hz), gt[k]);
         }
         rdn = w.maxv(mx);
         nd_ = 1.0 + w.maxv(sc);
@@ -1941,7 +2091,7 @@ struct Step {
         apply_G(z, [&](Row& r, double gz) {
             const double v = gz + r.s - r.h;
             r.rp = v;
-            rpmax = fmax(rpmax, fabs(v));
+            rpmax = fmx_abs(rpmax, v);
             musum += r.s * r.lam;
         });
         mu = w.sum(musum) / wsum;
@@ -1992,7 +2142,7 @@ struct Step {
         MPCQP_NOUNROLL
         for (int fact = 0; fact < MPCQP_POLISH_FACTS && !ok; ++fact) {
             ++nfact;
-            load_H();
+            if (!phi_direct()) load_H();
             add_GtDG([&](Row& r) { return rho * r.rp; });
             cholesky();
             if (chol_broke) break;
@@ -2111,8 +2261,12 @@ struct Step {
     //   ds = -(rc + s dl)/lam = -wi (s a + δ rc)            (no division by lam, no cancellation)
     // The rows satisfy  s dl + lam ds = -rc  and  rp + G dz + ds = δ dl.
     MPCQP_HD double row_wi(const Row& r) const { return rcp(fma(delta, r.lam, r.s)); }
+    // The same quantity five times per iteration (D~, two right-hand sides, two row steps): with compile-time dims it
+    // is formed once, when Phi is assembled (row_wi_fresh), and kept in a register until the iterate moves.
+    MPCQP_HD double row_wi_fresh(Row& r) const { const double wi = row_wi(r); if (r.wic) *r.wic = wi; return wi; }
+    MPCQP_HD double row_wi_cached(const Row& r) const { return r.wic ? *r.wic : row_wi(r); }
     MPCQP_HD void row_step(const Row& r, double rc, double& ds, double& dl) const {
-        const double wi = row_wi(r), a = r.rp + r.gd;
+        const double wi = row_wi_cached(r), a = r.rp + r.gd;
         dl = wi * fma(r.lam, a, -rc);
         ds = -wi * fma(r.s, a, delta * rc);
     }
@@ -2121,7 +2275,7 @@ struct Step {
     template <class Fn>
     MPCQP_HD void newton(Fn rc) {
         apply_Gt([&](Row& r) {
-            return row_wi(r) * (rc(r) - r.lam * r.rp);
+            return row_wi_cached(r) * (rc(r) - r.lam * r.rp);
         });
         for (int k = w.lane; k < d.nZ; k += WAVE) gt[k] -= rd[k];
         w.sync();
@@ -2271,27 +2425,28 @@ struct Step {
                 exact = true;                      // Phi, rd, gt were used: start over from exact residuals
                 continue;
             }
-            if (!verified) load_H();
+            if (!verified && !phi_direct()) load_H();
             add_GtDG([&](Row& r) {
-                return r.lam * row_wi(r);                   // D~ = D / (1 + δ D)
+                return r.lam * row_wi_fresh(r);             // D~ = D / (1 + δ D)
             });
             cholesky();
             // Two Newton solves with the same factor, one pass of the loop each (one copy of the
             // code): pass 0 the predictor, rc = s lam; pass 1 the corrector,
             // rc = s lam + ds_aff dl_aff - sigma mu (sigma = (mu_aff/mu)^3 from the predictor).
-            double amin = 1.0, smu = 0.0;
+            double amin = 1.0, smu = 0.0, tmax = 1.0;
             MPCQP_NOUNROLL
             for (int pass = 0; pass < 2; ++pass) {
                 const double cpp = pass ? 1.0 : 0.0;
                 newton([&](Row& r) { return fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)); });
                 double ppsum = 0.0;
-                amin = pass ? 1e300 : 1.0;
+                tmax = pass ? 1e-300 : 1.0;       // 1 / (largest step that keeps s, lam >= 0), capped at 1 for the predictor
                 for_rows([&](int, int, Row& r) {
                     if (!fin(r)) return;
                     double ds, dl;
                     row_step(r, fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)), ds, dl);
-                    if (ds < 0.0) amin = fmin(amin, -r.s * rcp(ds));
-                    if (dl < 0.0) amin = fmin(amin, -r.lam * rcp(dl));
+                    // step to the boundary as 1 / max(-ds/s, -dl/lam): no compare, no select; raw reciprocals
+                    tmax = fmx(tmax, -ds * rcp_fast(r.s));
+                    tmax = fmx(tmax, -dl * rcp_fast(r.lam));
                     // predictor: pp <- ds dl.  corrector: the step is kept in the row (pp <- ds,
                     // gd <- dl): the update below needs nothing else, since the primal residual
                     // follows r_p <- (1 - alpha) r_p + alpha δ dl.
@@ -2300,7 +2455,7 @@ struct Step {
                     ppsum += ds * dl;
                 });
                 if (pass == 0) {
-                    const double aaff = w.minv(amin);
+                    const double aaff = rcp(w.maxv(tmax));
                     // mu after the affine step: sum (s + a ds)(lam + a dl) = sum s lam (1 - a) + a^2 sum ds dl,
                     // because s dl + lam ds = -s lam on every row of the predictor
                     const double muaff = (1.0 - aaff) * mu + aaff * aaff * w.sum(ppsum) / wsum;
@@ -2313,13 +2468,13 @@ struct Step {
             // neighbourhood min_i s_i lam_i >= 0.01 mu, otherwise 0.99.  (An unguarded 0.999 jams
             // about one instance in 20000; with the guard no instance of 65536 needs more
             // iterations than with 0.99 throughout and the mean drops by about 0.9.)
-            amin = w.minv(amin);
+            amin = rcp(w.maxv(tmax));
             const double ahi = fmin(1.0, 0.9999 * amin);
             double pmin = 1e300, psum = 0.0;
             for_rows([&](int, int, Row& r) {
                 if (!fin(r)) return;
                 const double p = (r.s + ahi * r.pp) * (r.lam + ahi * r.gd);
-                pmin = fmin(pmin, p * rcp(r.wt));           // per copy of a merged row
+                pmin = fmn(pmin, r.wt == 1.0 ? p : p * rcp_fast(r.wt));           // per copy of a merged row
                 psum += p;
             });
             pmin = w.minv(pmin);
@@ -2332,12 +2487,12 @@ struct Step {
                 r.lam += alpha * r.gd;
                 r.rp = fma(alpha, delta * r.gd - r.rp, r.rp);
                 musum_c += r.s * r.lam;
-                rpmax_c = fmax(rpmax_c, fabs(r.rp));
+                rpmax_c = fmx_abs(rpmax_c, r.rp);
             });
             step_c = 0.0; zabs_c = 0.0;
             for (int k = w.lane; k < n; k += WAVE) {
                 const double st = alpha * dz[k];
-                if (k < d.nDU) { step_c = fmax(step_c, fabs(st)); zabs_c = fmax(zabs_c, fabs(z[k])); }
+                if (k < d.nDU) { step_c = fmx_abs(step_c, st); zabs_c = fmx_abs(zabs_c, z[k]); }
                 z[k] += st;
                 rd[k] *= (1.0 - alpha);
             }

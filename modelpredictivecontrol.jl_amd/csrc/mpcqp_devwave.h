@@ -43,15 +43,26 @@ struct DevWave {
         const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
         return __hiloint2double(hi, lo);
     }
-    template <class Op>
+    // dpp on the rows of ROWMASK only; the other rows (and lanes without a source) read `old`
+    template <int CTRL, int ROWMASK>
+    static __device__ __forceinline__ double dpp_rows(double v, double old) {
+        int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+        int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    // `self`: x op x == x (min, max): rows outside a step's mask combine with themselves; a sum combines with 0
+    template <bool SELF, class Op>
     static __device__ __forceinline__ double reduce(double v, Op op) {
         v = op(v, dpp<0xB1>(v));     // quad_perm [1,0,3,2]
         v = op(v, dpp<0x4E>(v));     // quad_perm [2,3,0,1]
         v = op(v, dpp<0x141>(v));    // row_half_mirror
         v = op(v, dpp<0x140>(v));    // row_mirror: every lane holds its 16-lane row's value
-        const double a = lane_value(v, 0), b = lane_value(v, 16);
-        const double c = lane_value(v, 32), d = lane_value(v, 48);
-        return op(op(a, b), op(c, d));
+        // rows 1 and 3 take in the row before them (row_bcast:15), then rows 2 and 3 lane 31 (row_bcast:31): row 3
+        // holds (r2 op r3) op (r0 op r1) -- the same pairs as a tree over four v_readlane'd row values, for two DPP
+        // steps and one v_readlane pair instead of four pairs and three scalar-operand operations
+        v = op(v, dpp_rows<0x142, 0xA>(v, SELF ? v : 0.0));
+        v = op(v, dpp_rows<0x143, 0xC>(v, SELF ? v : 0.0));
+        return lane_value(v, 63);
     }
     // sum over each aligned group of four lanes (result in all four)
     __device__ __forceinline__ double quad_sum(double v) {
@@ -59,9 +70,12 @@ struct DevWave {
         v += dpp<0x4E>(v);
         return v;
     }
-    __device__ __forceinline__ double sum(double v) { return reduce(v, [](double x, double y) { return x + y; }); }
-    __device__ __forceinline__ double minv(double v) { return reduce(v, [](double x, double y) { return fmin(x, y); }); }
-    __device__ __forceinline__ double maxv(double v) { return reduce(v, [](double x, double y) { return fmax(x, y); }); }
+    __device__ __forceinline__ double sum(double v) { return reduce<false>(v, [](double x, double y) { return x + y; }); }
+    // (v_min_f64 / v_max_f64 directly: llvm.minnum / maxnum put a canonicalising v_max_f64 x, x, x in front of every operand)
+    static __device__ __forceinline__ double mn_(double x, double y) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+    static __device__ __forceinline__ double mx_(double x, double y) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+    __device__ __forceinline__ double minv(double v) { return reduce<true>(v, [](double x, double y) { return mn_(x, y); }); }
+    __device__ __forceinline__ double maxv(double v) { return reduce<true>(v, [](double x, double y) { return mx_(x, y); }); }
     __device__ __forceinline__ int isum(int v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

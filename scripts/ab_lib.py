@@ -6,6 +6,7 @@ import mpcqp
 from mpcqp import synth
 cfg = synth.C3; B = 65536
 bt = synth.make_batch(cfg, B, seed=0)
+Zref = None
 for path in sys.argv[1:]:
     mpcqp.api._lib = None
     lib = mpcqp.api.load_library(os.path.abspath(path))
@@ -17,5 +18,8 @@ for path in sys.argv[1:]:
     for rep in range(4):
         u0, st, it = hd.step(bt["xhat0"], bt["lastu0"], bt["ry"], Z)
         ms.append(hd.last_step_ms())
-    print(f"{path}: kernel ms {['%.2f' % m for m in ms]}  optimal {np.mean(st == 0):.6f} iters {it.mean():.2f}  checksum {Z.sum():.12e}", flush=True)
+    if Zref is None: Zref = Z.copy()
+    dz = np.max(np.abs(Z - Zref)[:, :-1], axis=1) / np.maximum(1.0, np.max(np.abs(Zref[:, :-1]), axis=1))
+    print(f"{os.path.basename(path)}: kernel ms {['%.2f' % m for m in ms]}  optimal {np.mean(st == 0):.6f} iters {it.mean():.3f}  checksum {Z.sum():.12e}  "
+          f"max rel dU diff vs first {dz.max():.2e} (99.9%: {np.quantile(dz, 0.999):.1e})", flush=True)
     hd.close()
