@@ -5,7 +5,8 @@
  * hand-written gfx950 kernels (csrc/mhe_bodies.h).  The entry points replace, for a batch,
  *   MovingHorizonEstimator(model; He, ...)      src/estimator/mhe/construct.jl:255-460   -> mpcqp_mhe_create + set_model
  *   setconstraint!(estim; x̂min, ..., v̂max)       src/estimator/mhe/construct.jl:858-1049  -> mpcqp_mhe_set_bounds
- *   init_estimate_cov! / setstate!              src/estimator/mhe/execute.jl:2-36        -> mpcqp_mhe_init
+ *   init_estimate_cov!                          src/estimator/mhe/execute.jl:2-36        -> mpcqp_mhe_init
+ *   setstate!                                   src/estimator/execute.jl:424-429         -> mpcqp_mhe_set_state
  *   preparestate!(estim, ym, d)                 src/estimator/mhe/execute.jl:44-57       -> mpcqp_mhe_prepare
  *   updatestate!(estim, u, ym, d)               src/estimator/mhe/execute.jl:76-88       -> mpcqp_mhe_update
  *   getinfo(estim)                              src/estimator/mhe/execute.jl:116-200     -> mpcqp_mhe_get
@@ -71,6 +72,11 @@ int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin,
 /* init_estimate_cov!: empties the data windows (Nk = 0), x̂0 <- xhat0 (nx̂,B; NULL: zeros), arrival
  * covariance P̄ <- P0 (nx̂,nx̂,B; required), d0(-1) <- d0_prev (nd,B; NULL: zeros), lastu0 (nu,B; NULL: zeros). */
 int mpcqp_mhe_init(mpcqp_mhe h, const double* xhat0, const double* P0, const double* d0_prev, const double* lastu0);
+
+/* setstate!(estim, x̂) (src/estimator/execute.jl:424-429): x̂0 <- xhat0 (nx̂,B) and nothing else -- the data windows,
+ * the window length and the arrival covariance stay (the reference raises when a covariance is passed to a
+ * MovingHorizonEstimator, mhe/execute.jl:938-941: callers must not offer one).                                    */
+int mpcqp_mhe_set_state(mpcqp_mhe h, const double* xhat0);
 
 /* preparestate!: current form: add (y0m, d0, lastu0) to the windows, correct the arrival covariance when
  * the window moves, solve the QP, x̂0 <- estimate.  Predictor form: nothing to do (returns MPCQP_OK).

@@ -14,7 +14,7 @@
 module MPCQPShim
 
 using ModelPredictiveControl
-using LinearAlgebra: diag
+using LinearAlgebra: diag, Diagonal
 import ModelPredictiveControl: moveinput!, LinMPC
 
 const lib = get(ENV, "MPCQP_LIB", "libmpcqp.so")
@@ -43,6 +43,7 @@ mutable struct BatchLinMPC
     Z̃::Matrix{Float64}                # (nZ̃, B) previous optima = warm start of the next period
     lastu0::Matrix{Float64}           # (nu, B)
     kernel::Int                       # MPCQP_KERNEL_* the steps run on
+    flags::Cuint                      # MPCQP_FLAG_* given to the constructor (moveinput! only toggles RY_CONSTANT)
 end
 
 function check(rc::Integer)
@@ -97,7 +98,7 @@ function push_blockweight!(h::Ptr{Cvoid}, mpcs)
     check(ccall((:mpcqp_set_output_weight_blocks, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), h, Mb))
 end
 
-isdiagonal(M) = all(iszero, M - LinearAlgebra.Diagonal(diag(M)))
+isdiagonal(M) = all(iszero, M - Diagonal(diag(M)))
 
 function BatchLinMPC(mpcs::Vector{<:LinMPC}; device::Integer=0, flags::Unsigned=FLAG_RY_CONSTANT)
     m = mpcs[1]; est = m.estim; model = est.model; B = length(mpcs)
@@ -131,7 +132,7 @@ function BatchLinMPC(mpcs::Vector{<:LinMPC}; device::Integer=0, flags::Unsigned=
     # machine, cached), never inside a step -- the analogue of init_optimization! (linmpc.jl:303-339)
     kernel = ccall((:mpcqp_prepare, lib), Cint, (Ptr{Cvoid},), h[])
     kernel < 0 && check(kernel)
-    b = BatchLinMPC(h[], mpcs, zeros(m.nϵ + nΔU, B), cat2(c -> c.lastu0, mpcs), kernel)
+    b = BatchLinMPC(h[], mpcs, zeros(m.nϵ + nΔU, B), cat2(c -> c.lastu0, mpcs), kernel, Cuint(flags))
     finalizer(x -> ccall((:mpcqp_destroy, lib), Cint, (Ptr{Cvoid},), x.h), b)
     return b
 end
@@ -148,7 +149,7 @@ function moveinput!(b::BatchLinMPC, ry::AbstractMatrix, d::AbstractMatrix=zeros(
     x̂0  = cat2(c -> c.estim.x̂0, b.mpcs)
     yop = cat2(c -> c.estim.model.yop, b.mpcs); uop = cat2(c -> c.estim.model.uop, b.mpcs)
     held = R̂y === nothing                                       # the held set point is sent once
-    flags = held ? FLAG_RY_CONSTANT : 0x0
+    flags = held ? (b.flags | Cuint(FLAG_RY_CONSTANT)) : (b.flags & ~Cuint(FLAG_RY_CONSTANT))
     check(ccall((:mpcqp_set_flags, lib), Cint, (Ptr{Cvoid}, Cuint), b.h, flags))
     Ry0 = held ? Matrix{Float64}(ry .- yop) : Matrix{Float64}(R̂y .- repeat(yop, Hp))
     Ru0 = R̂u === nothing ? nothing : Matrix{Float64}(R̂u .- repeat(uop, Hp))

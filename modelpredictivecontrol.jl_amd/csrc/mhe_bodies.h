@@ -223,6 +223,7 @@ MPCQP_HD void cov_body(W& w, const Dims& d, const Args& a, int mode, const doubl
         const int b = live ? bq : d.B - 1;
         const double* cst = a.cst + (size_t)b * cm.stride + r;
         double* Pm = a.P + (size_t)b * NX * RL + r;
+        bool good = true;
         if (mode & 4) {
             sfor<NX>([&](auto ic) {
                 constexpr int c = decltype(ic)::v;
@@ -236,7 +237,7 @@ MPCQP_HD void cov_body(W& w, const Dims& d, const Args& a, int mode, const doubl
             O::ld(cst + cm.R, RL, M);
             op.mm(Cm, P, X);                   // Ĉm P          (row = output)
             op.mmt_acc(X, Cm, M, 1.0);         // M = R̂ + (Ĉm P) Ĉm'
-            op.gj(M, r);
+            good = op.gj(M, r) && good;
             op.mm(M, X, Y);                    // M⁻¹ Ĉm P
             sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; M[c] = 0.0; });
             op.mmt_acc(P, Cm, M, 1.0);         // P Ĉm'         (row = state, column = output)
@@ -250,14 +251,22 @@ MPCQP_HD void cov_body(W& w, const Dims& d, const Args& a, int mode, const doubl
             // (padding rows/columns of Q̂ hold the identity: the padded block of P stays the identity)
             op.mmt_acc(X, A, P, 1.0);
         }
-        if (live) {
+        // correct_cov! / update_cov! (mhe/execute.jl:729-780): a new P̄ that is not finite or not positive definite (or
+        // not invertible) is dropped -- P̄ and 2 P̄⁻¹ keep their previous values.  (mode 4 loads the caller's P̂_0.)
+        double fin = 1.0;
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; fin = (P[c] - P[c] == 0.0) ? fin : 0.0; });
+        good = good && w.rmin(fin) > 0.5;
+        typename O::Row Pi;
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Pi[c] = P[c]; });
+        good = op.gj(Pi, r) && good;
+        const bool commit = good || (mode & 4) || mode == 0;        // (mode 0 only reads P̄ back)
+        if (live && commit) {
             O::st(Pm, RL, P);
             if (Pout && r < nx)
                 sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; if (c < nx) Pout[(size_t)b * nx * nx + c * nx + r] = P[c]; });
+            sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Pi[c] *= 2.0; });
+            O::st(a.Pi2 + (size_t)b * NX * RL + r, RL, Pi);
         }
-        op.gj(P, r);
-        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; P[c] *= 2.0; });
-        if (live) O::st(a.Pi2 + (size_t)b * NX * RL + r, RL, P);
     }
 }
 

@@ -303,6 +303,16 @@ int mpcqp_mhe_init(mpcqp_mhe h, const double* xhat0, const double* P0, const dou
     return MPCQP_OK;
 }
 
+int mpcqp_mhe_set_state(mpcqp_mhe h, const double* xhat0) {
+    if (!h || !xhat0) return MPCQP_ERR_NULL;
+    if (!h->have_init) return MPCQP_ERR_ORDER;
+    ON_DEVICE(h);
+    const int rc = up(h, h->a.xhat0, xhat0, (size_t)h->d.B * h->d.nx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
 int mpcqp_mhe_prepare_device(mpcqp_mhe h, const double* y0m_dev, const double* d0_dev) {
     if (!h || !y0m_dev) return MPCQP_ERR_NULL;
     if (h->d.nd > 0 && !d0_dev) return MPCQP_ERR_NULL;

@@ -94,6 +94,47 @@ struct DevWave {
         return __hiloint2double(hi, lo);
     }
     __device__ __forceinline__ bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+    // Substitution chain inside the 16-lane DPP rows selected by ROWS (DPP row mask, bit = row): four steps of
+    //   r += (r of lane K+u of this lane's row) * c_u        u = 0..3 (REV: 3..0)
+    // The broadcast is the DPP modifier of the multiply-add itself (v_fmac_f64_dpp, row_newbcast -- the one DPP control
+    // 64-bit operations have); rows outside ROWS keep r.  The hardware does not interlock a DPP read of a VGPR that the
+    // previous VALU instruction wrote (two wait states), and the compiler does not look inside the asm: hence the s_nop.
+    template <int K, int ROWS, bool REV>
+    static __device__ __forceinline__ void chain4(double& r, double c0, double c1, double c2, double c3) {
+        if constexpr (!REV)
+            asm("s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%5 row_mask:%9 bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %2 row_newbcast:%6 row_mask:%9 bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %3 row_newbcast:%7 row_mask:%9 bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%8 row_mask:%9 bank_mask:0xf"
+                : "+v"(r)
+                : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "n"(K), "n"(K + 1), "n"(K + 2), "n"(K + 3), "n"(ROWS));
+        else
+            asm("s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%8 row_mask:%9 bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %3 row_newbcast:%7 row_mask:%9 bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %2 row_newbcast:%6 row_mask:%9 bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%5 row_mask:%9 bank_mask:0xf"
+                : "+v"(r)
+                : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "n"(K), "n"(K + 1), "n"(K + 2), "n"(K + 3), "n"(ROWS));
+    }
+    // acc += sum_u (x of lane K+u of this lane's row) * c_u, rows of ROWS only (x is not written inside the block)
+    template <int K, int ROWS>
+    static __device__ __forceinline__ void fmabc4(double& acc, double x, double c0, double c1, double c2, double c3) {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%6 row_mask:%10 bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%7 row_mask:%10 bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%8 row_mask:%10 bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%9 row_mask:%10 bank_mask:0xf"
+            : "+v"(acc)
+            : "v"(x), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "n"(K), "n"(K + 1), "n"(K + 2), "n"(K + 3), "n"(ROWS));
+    }
 };
 
 extern __shared__ __attribute__((aligned(16))) double mpcqp_smem[];

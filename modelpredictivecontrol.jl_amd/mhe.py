@@ -19,7 +19,7 @@ import numpy as np
 from . import api
 from .api import MpcqpError, _chk, _f64, _ptr, colmajor
 
-EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_set_softness", "mpcqp_mhe_init",
+EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_set_softness", "mpcqp_mhe_init", "mpcqp_mhe_set_state",
            "mpcqp_mhe_prepare", "mpcqp_mhe_update", "mpcqp_mhe_prepare_device", "mpcqp_mhe_update_device",
            "mpcqp_mhe_sync", "mpcqp_mhe_get", "mpcqp_mhe_device_ptr", "mpcqp_mhe_nk", "mpcqp_mhe_last_ms",
            "mpcqp_mhe_register_columns")
@@ -43,6 +43,7 @@ def _bind(lib):
     lib.mpcqp_mhe_set_bounds.argtypes = [C.c_void_p] * 7
     lib.mpcqp_mhe_set_softness.argtypes = [C.c_void_p] * 8
     lib.mpcqp_mhe_init.argtypes = [C.c_void_p] * 5
+    lib.mpcqp_mhe_set_state.argtypes = [C.c_void_p] * 2
     lib.mpcqp_mhe_prepare.argtypes = [C.c_void_p] * 3
     lib.mpcqp_mhe_update.argtypes = [C.c_void_p] * 4
     lib.mpcqp_mhe_prepare_device.argtypes = [C.c_void_p] * 3
@@ -101,6 +102,9 @@ class MheHandle:
         arrs = [None if xhat0 is None else _f64(xhat0), colmajor(P0), None if d0_prev is None else _f64(d0_prev),
                 None if lastu0 is None else _f64(lastu0)]
         _chk(self.lib, self.lib.mpcqp_mhe_init(self._h, *[_ptr(a) for a in arrs]))
+
+    def set_state(self, xhat0):
+        _chk(self.lib, self.lib.mpcqp_mhe_set_state(self._h, _ptr(_f64(xhat0))))
 
     def _failed(self, rc):
         if rc < 0:
@@ -259,11 +263,15 @@ class BatchMHE:
         return self
 
     def setstate(self, x̂, P̂=None):
-        """setstate!(estim, x̂, P̂): new estimate (and arrival covariance); the windows restart."""
-        self.x̂0 = np.broadcast_to(np.asarray(x̂, float), (self.B, self.nx̂)) - self.x̂op
+        """setstate!(estim, x̂) (src/estimator/execute.jl:424-429): only the current estimate changes; the data windows
+        and the arrival covariance stay.  A covariance is an error, as in the reference (mhe/execute.jl:938-941)."""
         if P̂ is not None:
-            self.P̂_0 = np.broadcast_to(np.asarray(P̂, float), (self.B, self.nx̂, self.nx̂)).copy()
-        self.handle.init(self.x̂0, self.P̂_0)
+            raise MpcqpError("MovingHorizonEstimator does not compute an estimation covariance matrix P̂.")
+        x = np.asarray(x̂, float)
+        if x.shape not in ((self.nx̂,), (self.B, self.nx̂)):
+            raise ValueError(f"x̂ size must be ({self.nx̂},)")
+        self.x̂0 = np.broadcast_to(x, (self.B, self.nx̂)) - self.x̂op
+        self.handle.set_state(self.x̂0)
         return self
 
     def initstate(self, x̂, u=None, d=None):

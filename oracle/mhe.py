@@ -57,27 +57,31 @@ class KalmanFilterOracle(es.SteadyKalmanFilterOracle):
         return self.x0 + self.xhop
 
 
-def _attach_cov(kf, model, sigmaQ, sigmaR, sigmaQint_ym):
-    """Q̂, R̂ of the augmented model (the SteadyKalmanFilterOracle keeps only the gain)."""
-    nint = kf.nxh - model.nx
+def _attach_cov(kf, model, sigmaQ, sigmaR, sigmaQint_ym, sigmaQint_u=None, nint_u_tot=0):
+    """Q̂, R̂ of the augmented model (the SteadyKalmanFilterOracle keeps only the gain); augmented states in the
+    order [x; integrators on u; integrators on ym] (augment_model, src/estimator/construct.jl)."""
+    nint_y = kf.nxh - model.nx - nint_u_tot
     sQ = np.full(model.nx, 1.0 / model.nx) if sigmaQ is None else np.asarray(sigmaQ, float)
     sR = np.ones(len(kf.i_ym)) if sigmaR is None else np.asarray(sigmaR, float)
-    sQy = np.ones(nint) if sigmaQint_ym is None else np.asarray(sigmaQint_ym, float)
-    kf.Q = np.diag(np.concatenate([sQ, sQy]) ** 2)
+    sQu = np.ones(nint_u_tot) if sigmaQint_u is None else np.asarray(sigmaQint_u, float)
+    sQy = np.ones(nint_y) if sigmaQint_ym is None else np.asarray(sigmaQint_ym, float)
+    kf.Q = np.diag(np.concatenate([sQ, sQu, sQy]) ** 2)
     kf.R = np.diag(sR ** 2)
 
 
 def make_kalman_filter(model, direct=True, sigmaQ=None, sigmaR=None, sigmaQint_ym=None, sigmaP_0=None,
-                       sigmaPint_ym_0=None, nint_ym=None, P_0=None):
+                       sigmaPint_ym_0=None, nint_ym=None, P_0=None, nint_u=0, sigmaQint_u=None, sigmaPint_u_0=None):
     kf = KalmanFilterOracle.__new__(KalmanFilterOracle)
-    es.SteadyKalmanFilterOracle.__init__(kf, model, sigmaQ=sigmaQ, sigmaR=sigmaR, nint_ym=nint_ym,
-                                         sigmaQint_ym=sigmaQint_ym)
-    _attach_cov(kf, model, sigmaQ, sigmaR, sigmaQint_ym)
+    es.SteadyKalmanFilterOracle.__init__(kf, model, sigmaQ=sigmaQ, sigmaR=sigmaR, nint_u=nint_u, nint_ym=nint_ym,
+                                         sigmaQint_u=sigmaQint_u, sigmaQint_ym=sigmaQint_ym)
+    nu_int = int(np.sum(nint_u))
+    _attach_cov(kf, model, sigmaQ, sigmaR, sigmaQint_ym, sigmaQint_u, nu_int)
     kf.direct = direct
-    nint = kf.nxh - model.nx
+    nint = kf.nxh - model.nx - nu_int
     sP = np.full(model.nx, 1.0 / model.nx) if sigmaP_0 is None else np.asarray(sigmaP_0, float)
+    sPu = np.ones(nu_int) if sigmaPint_u_0 is None else np.asarray(sigmaPint_u_0, float)
     sPy = np.ones(nint) if sigmaPint_ym_0 is None else np.asarray(sigmaPint_ym_0, float)
-    kf.P0 = np.diag((sP if len(sP) == kf.nxh else np.concatenate([sP, sPy])) ** 2)
+    kf.P0 = np.diag((sP if len(sP) == kf.nxh else np.concatenate([sP, sPu, sPy])) ** 2)
     if P_0 is not None:                      # (setstate!(estim, x̂, P̂): a full matrix)
         kf.P0 = np.asarray(P_0, float).copy()
     kf.P = kf.P0.copy()
@@ -148,11 +152,13 @@ class MHEOracle:
     SingleShooting, default arrival covariance estimator (KalmanFilter with the same covariances)."""
 
     def __init__(self, model, He, direct=True, Cwt=np.inf, sigmaQ=None, sigmaR=None, sigmaQint_ym=None,
-                 sigmaP_0=None, sigmaPint_ym_0=None, nint_ym=None, P_0=None):
+                 sigmaP_0=None, sigmaPint_ym_0=None, nint_ym=None, P_0=None, nint_u=0, sigmaQint_u=None,
+                 sigmaPint_u_0=None):
         self.model, self.He, self.direct, self.Cwt = model, int(He), direct, float(Cwt)
         self.neps = 0 if np.isinf(Cwt) else 1
         kw = dict(sigmaQ=sigmaQ, sigmaR=sigmaR, sigmaQint_ym=sigmaQint_ym, sigmaP_0=sigmaP_0,
-                  sigmaPint_ym_0=sigmaPint_ym_0, nint_ym=nint_ym, P_0=P_0)
+                  sigmaPint_ym_0=sigmaPint_ym_0, nint_ym=nint_ym, P_0=P_0, nint_u=nint_u, sigmaQint_u=sigmaQint_u,
+                  sigmaPint_u_0=sigmaPint_u_0)
         self.cov = make_kalman_filter(model, direct=direct, **kw)          # covestim
         c = self.cov
         self.Ah, self.Bhu, self.Ch, self.Bhd, self.Dhd = c.Ah, c.Bhu, c.Ch, c.Bhd, c.Dhd

@@ -118,6 +118,107 @@ def reference_known_answers(lib=None, B=2, forms=(True, False)):
     return out
 
 
+def _plant_u():
+    """LinModel(sys, Ts, i_u=[1,2]) of the reference's test module (test/0_test_module.jl), minimal realisation."""
+    Ts = 400.0
+    a1, a2 = np.exp(-Ts / 1800.0), np.exp(-Ts / 800.0)
+    return es.LinModelOracle(np.diag([a1, a2]), np.array([[1 - a1, 1 - a1], [-(1 - a2), 1 - a2]]), np.diag([1.90, 0.74]),
+                             np.zeros((2, 0)), np.zeros((2, 0)), Ts=Ts)
+
+
+class _OracleMHE:
+    """oracle/mhe.py behind the keyword vocabulary of BatchMHE (one estimator, answers with a leading batch axis)."""
+
+    def __init__(self, e):
+        self.e = e
+
+    def setconstraint(self, **kw):
+        inv = {v: k for k, v in PRODUCT_KEYS.items()}
+        self.e.setconstraint(**{inv[k]: v for k, v in kw.items()})
+
+    def preparestate(self, ym, d=()):
+        return self.e.preparestate(ym, d)[None]
+
+    def updatestate(self, u, ym, d=()):
+        x = self.e.updatestate(u, ym, d)[None]
+        assert self.e.status == 0
+        return x
+
+    def getinfo(self):
+        e = self.e
+        return {"Ŵ": e.Zt[e.neps + e.nxh:][:e.nxh * e.Nk][None], "V̂": e.Vhat[None], "status": np.array([e.status])}
+
+
+def reference_constraint_violation(soft, lib=None, B=2, oracle=False):
+    """"MHE constraint violation (LinModel)" of the reference (test/2_test_state_estim.jl:1491-1539), same call
+    sequence: He = 1, nint_ym = 0, Cwt = 1e5 with every softness parameter on (soft) or Cwt = Inf (hard); a bound
+    that excludes the operating point is set on x̂, then ŵ, then v̂, and the estimate / Ŵ / V̂ must sit on it
+    (atol 5e-2 in the reference).  Returns {label: worst |answer - expected|} of the product (or of the oracle)."""
+    model = _plant_u().setop(uop=[10, 50], yop=[50, 30])
+    Cwt = 1e5 if soft else np.inf
+    e = om.MHEOracle(model, He=1, direct=True, Cwt=Cwt, nint_ym=[0, 0])
+    if oracle:
+        bm = _OracleMHE(e)
+    else:
+        rep = lambda M: np.repeat(np.asarray(M, float)[None], B, 0)
+        bm = pm.BatchMHE(rep(e.Ah), rep(e.Bhu), rep(e.Chm), He=1, Q̂=rep(e.Q), R̂=rep(e.R), P̂_0=rep(e.cov.P0), direct=True,
+                         Cwt=Cwt, uop=model.uop, yop_m=model.yop[e.i_ym], x̂op=e.xhop, f̂op=e.fhop, lib=lib)
+    big, nbig = [100.0, 100.0], [-100.0, -100.0]
+    wide = dict(x̂min=nbig, x̂max=big, ŵmin=nbig, ŵmax=big, v̂min=nbig, v̂max=big)
+    bm.setconstraint(**wide)
+    if soft:
+        bm.setconstraint(c_x̂min=[1, 1], c_x̂max=[1, 1], c_ŵmin=[0.1, 0.1], c_ŵmax=[0.1, 0.1], c_v̂min=[1, 1], c_v̂max=[1, 1])
+    out = {}
+
+    def period():
+        bm.preparestate([50, 30])
+        x = bm.updatestate([10, 50], [50, 30])
+        info = bm.getinfo()
+        assert np.all(info["status"] == 0)
+        return x, info
+
+    bm.setconstraint(x̂min=[1, 1], x̂max=big)
+    out["x̂min"] = np.abs(period()[0] - [1, 1]).max()
+    bm.setconstraint(x̂min=nbig, x̂max=[-1, -1])
+    out["x̂max"] = np.abs(period()[0] - [-1, -1]).max()
+    bm.setconstraint(**wide)
+    bm.setconstraint(ŵmin=[1, 1], ŵmax=big)
+    out["ŵmin"] = np.abs(period()[1]["Ŵ"] - [1, 1]).max()
+    bm.setconstraint(ŵmin=nbig, ŵmax=[-1, -1])
+    out["ŵmax"] = np.abs(period()[1]["Ŵ"] - [-1, -1]).max()
+    bm.setconstraint(**wide)
+    bm.setconstraint(v̂min=[1, 1], v̂max=big)
+    out["v̂min"] = np.abs(period()[1]["V̂"] - [1, 1]).max()
+    bm.setconstraint(v̂min=nbig, v̂max=[-1, -1])
+    out["v̂max"] = np.abs(period()[1]["V̂"] - [-1, -1]).max()
+    return out
+
+
+def reference_unfilled_window(direct, lib=None, B=2, oracle=False):
+    """"MHE estimation with unfilled window" of the reference (test/2_test_state_estim.jl:1313-1337): the plant
+    x+ = 0.5x + u, y = x (linear, so the LinModel estimator applies), an integrator on the input (nint_u = [1]),
+    He = 3; the estimator is told u = 0 while the plant receives u = 0.1 for 40 periods: the estimated output must
+    equal the plant output (atol 1e-6).  Returns |ŷ - y|."""
+    model = es.LinModelOracle(np.array([[0.5]]), np.array([[1.0]]), np.array([[1.0]]), np.zeros((1, 0)), np.zeros((1, 0)), Ts=10.0)
+    e = om.MHEOracle(model, He=3, direct=direct, nint_u=[1])
+    if oracle:
+        prep, upd = (lambda y: e.preparestate(y)), (lambda u, y: e.updatestate(u, y))
+        yhat = lambda: e.evaloutput()
+    else:
+        rep = lambda M: np.repeat(np.asarray(M, float)[None], B, 0)
+        bm = pm.BatchMHE(rep(e.Ah), rep(e.Bhu), rep(e.Chm), He=3, Q̂=rep(e.Q), R̂=rep(e.R), P̂_0=rep(e.cov.P0), direct=direct, lib=lib)
+        prep, upd = (lambda y: bm.preparestate(y)), (lambda u, y: bm.updatestate(u, y))
+        yhat = lambda: np.einsum("ij,bj->bi", e.Ch, bm.x̂0)
+    x = np.zeros(1)
+    for _ in range(40):
+        y = x.copy()
+        prep(y)
+        upd([0.0], y)
+        x = 0.5 * x + 0.1
+    prep(x.copy())
+    return float(np.abs(yhat() - x).max())
+
+
 def random_family(seed, lib=None, B=5):
     """One randomised MovingHorizonEstimator family (dimensions, form, horizon, bound classes, hard / soft) driven
     through He + 3 periods on the product and on oracle/mhe.py, every member compared.  Returns (worst relative

@@ -240,3 +240,20 @@ def test_randomised_families_match_oracle(seed):
     is recorded in profiles/r2c/family_sweeps.txt (seed 227 is its worst case, 3e-6: a weakly active bound)."""
     worst, ncmp, nfail = mhe_util.random_family(seed)
     assert ncmp > 0 and worst <= 1e-5, (worst, ncmp, nfail)         # north-star tolerance
+
+
+@pytest.mark.parametrize("soft", [True, False], ids=["soft", "hard"])
+def test_reference_constraint_violation_through_the_product(soft):
+    """"MHE constraint violation (LinModel)", test/2_test_state_estim.jl:1491-1539, through BatchMHE on the GPU:
+    x̂, Ŵ, V̂ sit on the violated bound (atol 5e-2 in the reference) and agree with the oracle's answers."""
+    got = mhe_util.reference_constraint_violation(soft, B=3)
+    ref = mhe_util.reference_constraint_violation(soft, oracle=True)
+    for k in ref:
+        assert got[k] <= 5e-2, (k, got[k])
+        assert abs(got[k] - ref[k]) <= 1e-5, (k, got[k], ref[k])
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_reference_unfilled_window_through_the_product(direct):
+    """"MHE estimation with unfilled window", test/2_test_state_estim.jl:1313-1337 (atol 1e-6 there)."""
+    assert mhe_util.reference_unfilled_window(direct, B=3) <= 1e-6

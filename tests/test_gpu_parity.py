@@ -84,11 +84,12 @@ def test_full_size_properties_C3(hiplib):
     # shard of the seeded generator is the same as slicing the big batch
     bt3 = synth.make_batch(cfg, n, seed=0, lo=lo)
     assert np.array_equal(bt3["Ahat"], sub["Ahat"])
-    # sampled parity at full size
+    # sampled parity at full size: every sampled instance, certified by the oracle or not (test_step_matches_oracle)
     idx = np.arange(0, B, 1024)
     ref = oracle_batch(cfg, {k: (v[idx] if isinstance(v, np.ndarray) else v) for k, v in bt.items()})
     err = rel_err(Z[idx], ref["Z"], nDU)
-    assert err[ref["certified"]].max() <= TOL
+    assert ref["certified"].mean() > 0.95
+    assert err.max() <= TOL
     # every one of the 65536 instances against the oracle's C port (same iteration, dense algebra,
     # host threads): two independent float64 evaluations of the same optimum
     from oracle import cport
@@ -96,14 +97,15 @@ def test_full_size_properties_C3(hiplib):
     assert np.all(stc == 0)
     dif = rel_err(Z, Zc, nDU)
     assert np.percentile(dif, 99.99) <= 0.2 * TOL
-    # The ill-conditioned tail (slack > 1: soft rows violated by more than the bound itself,
-    # multipliers ~1e6) is where two float64 normal-equation solvers can part by more than that:
-    # at most a handful of the 65536, and the kernel is still within TOL of the certified optimum.
-    hard = np.argsort(-dif)[:6]
-    assert (dif > TOL).sum() <= 3
+    assert dif.max() <= TOL                    # no instance is allowed to part from the C port by more than TOL
+    # The C port is the kernel's twin, not an independent optimum: the instances where the two differ most (the
+    # ill-conditioned tail -- slack > 1, multipliers ~1e6, up to 77 iterations) go to the independent oracle, ALL of
+    # them: each must carry the oracle's exact active-set certificate and the kernel must be within TOL of it.
+    hard = np.argsort(-dif)[:12]
     refh = oracle_batch(cfg, {k: (v[hard] if isinstance(v, np.ndarray) else v) for k, v in bt.items()})
+    assert np.all(refh["certified"]), hard[~refh["certified"]]
     errh = rel_err(Z[hard], refh["Z"], nDU)
-    assert errh[refh["certified"]].max() <= TOL
+    assert errh.max() <= TOL, (hard[np.argmax(errh)], errh.max())
 
 
 def test_c_client_runs_steps_on_gpu(tmp_path, hiplib):
@@ -593,7 +595,7 @@ def test_small_problem_kernel_on_gpu(hiplib):
 
 def test_small_problem_kernel_full_batch_C2(hiplib):
     """65536 C2 controllers on the small-problem kernel: all optimal (the wide-neighbourhood safeguard of the step
-    length matters: instance 10539 cycles without it), bounds respected, first 64 against the oracle."""
+    length matters: instance 10539 cycles without it), bounds respected, a strided sample of 1024 instances against the oracle."""
     cfg = synth.C2
     B = 65536
     bt = synth.make_batch(cfg, B, seed=0)
@@ -607,6 +609,7 @@ def test_small_problem_kernel_full_batch_C2(hiplib):
     assert DU.max() <= cfg.dumax + 1e-9 and DU.min() >= cfg.dumin - 1e-9
     U = np.cumsum(DU.reshape(B, cfg.Hc, cfg.nu), axis=1) + bt["lastu0"][:, None, :]
     assert U.max() <= cfg.umax + 1e-9 and U.min() >= cfg.umin - 1e-9
-    sub = {k: (v[:64] if isinstance(v, np.ndarray) else v) for k, v in bt.items()}
+    idx = np.arange(0, B, 64)                      # a strided sample of 1024 instances over the whole batch
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) else v) for k, v in bt.items()}
     ref = oracle_batch(cfg, sub)
-    assert rel_err(mpc.Z[:64], ref["Z"], nDU).max() <= TOL
+    assert rel_err(mpc.Z[idx], ref["Z"], nDU).max() <= TOL

@@ -148,3 +148,41 @@ def test_horizon_of_one_on_emulator(emulib, kw):
     cfg = synth.MheConfig("he1", **kw)
     rows, _ = mhe_util.run_periods(cfg, synth.make_mhe_batch(cfg, 4, seed=3), 4, [0, 1, 3], lib=emulib)
     assert all(np.all(r["status"] == 0) and max(r["ex"], r["ew"]) <= 2e-6 and r["ep"] <= 1e-13 for r in rows)
+
+
+def test_reference_constraint_violation_through_the_product_on_emulator(emulib):
+    """test/2_test_state_estim.jl:1491-1539 through BatchMHE (kernel bodies on the CPU wave emulator), hard bounds
+    (soft: GPU suite)."""
+    got = mhe_util.reference_constraint_violation(False, lib=emulib, B=1)
+    for k, v in got.items():
+        assert v <= 1e-5, (k, v)
+
+
+def test_reference_unfilled_window_through_the_product_on_emulator(emulib):
+    assert mhe_util.reference_unfilled_window(True, lib=emulib, B=1) <= 1e-6
+
+
+def test_setstate_keeps_windows_and_arrival_covariance(emulib):
+    """setstate!(::MovingHorizonEstimator, x̂) overwrites x̂0 only (src/estimator/execute.jl:424-429) and raises when a
+    covariance is offered (mhe/execute.jl:938-941): the product follows the oracle through a setstate in mid-window."""
+    cfg = synth.MheConfig("setst", nx=2, nu=1, nym=2, nd=0, He=4, xabs=1.5)
+    bt = synth.make_mhe_batch(cfg, 3, seed=5)
+    Y, U, D = synth.make_mhe_data(cfg, bt, 7, seed=2)
+    bm = mhe_util.make_product(cfg, bt, lib=emulib)
+    ors = mhe_util.make_oracles(cfg, bt, [0, 1, 2])
+    for k in range(7):
+        xg = bm.preparestate(Y[k])
+        xo = np.array([e.preparestate(Y[k][b]) for b, e in enumerate(ors)])
+        assert np.abs(xg - xo).max() <= 2e-6 * max(1.0, np.abs(xo).max()), k
+        bm.updatestate(U[k], Y[k])
+        for b, e in enumerate(ors):
+            e.updatestate(U[k][b], Y[k][b])
+        if k == 2:
+            Nk, Pb = bm.handle.Nk, bm.handle.get(pm.GET_PBAR).copy()
+            xnew = 0.3 * np.ones((3, cfg.nxh))
+            bm.setstate(xnew)
+            for b, e in enumerate(ors):
+                e.setstate(xnew[b])
+            assert bm.handle.Nk == Nk and np.array_equal(bm.handle.get(pm.GET_PBAR), Pb)
+            with pytest.raises(mpcqp.MpcqpError):
+                bm.setstate(xnew, P̂=np.eye(cfg.nxh))

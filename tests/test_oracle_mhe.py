@@ -6,6 +6,10 @@ MovingHorizonEstimator:
   prediction form (direct = false) and current form (direct = true), atol 1e-6 in the reference;
 * "MHE estimation and getinfo (LinModel)" (:1034-1075): estimates stay at the operating point, and
   the estimated outputs follow a step in the plant to 1e-3 / 1e-2 after 40 periods;
+* "MHE constraint violation (LinModel)" (:1491-1539): the constraint rows (relaxX̂/Ŵ/V̂, linconstraint!) -- a bound that
+  excludes the operating point on x̂, then ŵ, then v̂ puts the estimate / Ŵ / V̂ on the bound, hard (Cwt = Inf) and soft
+  (Cwt = 1e5, every softness parameter on), He = 1, atol 5e-2 in the reference;
+* "MHE estimation with unfilled window" (:1313-1337): integrator on the input, He = 3, both forms, ŷ = y to 1e-6;
 * hard and soft bounds (setconstraint!, :1192-1260 checks activation of x̂, ŵ, v̂ bounds).
 The plant of those tests (`sys`, test/0_test_module.jl) is rebuilt in a minimal realisation: the
 equivalences do not depend on the state coordinates."""
@@ -84,3 +88,21 @@ def test_mhe_bounds_are_active():
         hit = hit or abs(X[:, 0].max() - 0.1) <= 1e-6
         assert est.Vhat.min() >= -0.2 - eps - 1e-8 and eps >= -1e-12
     assert hit                                              # the hard state bound did limit the estimate
+
+
+@pytest.mark.parametrize("soft", [True, False], ids=["soft", "hard"])
+def test_reference_constraint_violation_known_answers(soft):
+    """test/2_test_state_estim.jl:1491-1539 on the oracle: x̂ ≈ ±[1,1], Ŵ ≈ ±[1,1], V̂ ≈ ±[1,1] (atol 5e-2 there; the
+    hard answers are exact, the soft ones give way by ε ~ 1e-4)."""
+    from tests import mhe_util
+    res = mhe_util.reference_constraint_violation(soft, oracle=True)
+    assert set(res) == {"x̂min", "x̂max", "ŵmin", "ŵmax", "v̂min", "v̂max"}
+    for k, v in res.items():
+        assert v <= (5e-4 if soft else 1e-8), (k, v)
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_reference_unfilled_window(direct):
+    """test/2_test_state_estim.jl:1313-1337 on the oracle (atol 1e-6 in the reference)."""
+    from tests import mhe_util
+    assert mhe_util.reference_unfilled_window(direct, oracle=True) <= 1e-9
