@@ -14,7 +14,8 @@ Workload (BASELINE.json):
           controllers per GPU, global 65536 N) is measured in the same run and reported under
           `config.weak_scaling`.  `--mode weak` makes the weak run the headline instead.
 After the timed region the ranks gather status and first moves of the whole batch with ONE all_gather
-each over RCCL (the scatter/gather of the north star; it is outside the step).
+each over RCCL, and one period's inputs born on rank 0 are scattered to the ranks with ONE scatter each (the
+scatter/gather of the north star; both are outside the step and timed separately: config.scatter / config.gather).
 
 `--config C5` runs BASELINE configs[4] instead (linear MovingHorizonEstimator, one estimator period per
 step): see bench_mhe.py.
@@ -143,6 +144,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 / C5 records of config.secondary")
     args = ap.parse_args()
 
     import torch
@@ -217,6 +219,26 @@ def main():
         gather = {"ms": (time.perf_counter() - t0) * 1e3, "bytes_per_rank": int(B * (4 + 8 * cfg.nu)),
                   "optimal_fraction": float((st_all == 0).double().mean().item()),
                   "u0_checksum": float(u_all.sum().item()), "collective": "all_gather (RCCL), one per array"}
+
+    # ... and the scatter: one period's inputs (x̂0, lastu0, ry of the whole batch) born on rank 0 reach the ranks as their
+    # slices, ONE scatter collective per array; checked against the shard every rank generated itself
+    scatter = None
+    if dist is not None:
+        from mpcqp import synth as _synth
+        whole = _synth.make_batch(cfg, Bglobal, seed=args.seed) if rank == 0 else None
+        dev_c = args.coll_device
+        src = {k: (torch.from_numpy(whole[k]).to(dev_c) if rank == 0 else None) for k in ("xhat0", "lastu0", "ry")}
+        like = {"xhat0": sh.t_x, "lastu0": sh.t_lu, "ry": sh.t_ry}
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        got = {k: sharding.scatter(src[k], Bglobal, dist, src=0, device=dev_c, like=like[k]) for k in src}
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        same = all(torch.equal(got[k].to(like[k].device), like[k]) for k in got)
+        scatter = {"ms": ms, "bytes_per_rank": int(B * 8 * (cfg.nxh + cfg.nu + cfg.ny)), "matches_local_shard": bool(same),
+                   "collective": "scatter (RCCL), one per array, source rank 0"}
+        del whole, src, got
 
     # weak-scaling figure next to the config-4 run
     weak = None
@@ -305,7 +327,7 @@ def main():
                        "median_kernel_ms": kmed,
                        "recondense_ms": recond_ms, "recondense_K1_ms": k1_ms, "recondense_K2_ms": recond_ms - k1_ms,
                        "end_to_end_ms": e2e_ms, "active_rows": active, "closed_loop": loop,
-                       "weak_scaling": weak, "gather": gather,
+                       "weak_scaling": weak, "scatter": scatter, "gather": gather,
                        "sharding": "contiguous index ranges (sharding.shard_range), no collective on the data path"},
             "roofline": {"bound": "mfma", "kernel": "k_step", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -319,10 +341,57 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args, B)
+    # the other single-GPU BASELINE configurations, after the headline's timed region: config.secondary
+    if world == 1 and args.config == "C3" and not args.batch and not args.no_secondary:
+        del sh, hd
+        torch.cuda.empty_cache()
+        out["config"]["secondary"] = secondary(args, local)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary(args, local):
+    """BASELINE configs[1] (C2: nx=2 nu=2 Hp=20 Hc=5, batch 1024 -- the reference's own CPU-runnable case -- and batch
+    65536) and configs[4] (C5: linear MovingHorizonEstimator, He=20, batch 65536) on this GPU: value, kernel time and
+    roofline fraction of each, measured like the headline (inputs resident, W warm-up + K timed steps, kernel time from
+    HIP events on the launch stream)."""
+    import copy
+    import torch
+    import bench_mhe
+    from mpcqp import synth
+    recs = []
+    for name, B in (("C2", 1024), ("C2", 65536)):
+        cfg = synth.get_config(name)
+        sh = Shard(cfg, 0, B, args.seed, local)
+        elapsed, kern_ms = timed_run(sh, args.steps, args.warmup, None)
+        status, iters = sh.t_st.cpu().numpy(), sh.t_it.cpu().numpy()
+        rows_u = (int(np.isfinite(cfg.umin)) + int(np.isfinite(cfg.umax))) * sh.hd.nU
+        rows_y = (int(np.isfinite(cfg.ymin)) + int(np.isfinite(cfg.ymax))) * sh.hd.nY
+        flops, _, _ = algorithmic_flops(cfg, float(iters.mean()), rows_u, rows_y)
+        kms = float(np.mean(kern_ms))
+        ach = flops * B / (kms * 1e-3) / 1e12
+        recs.append({"workload": cfg.name, "batch": B, "metric": "QP solves/sec (moveinput!)", "value": B * args.steps / elapsed,
+                     "unit": "solves/s", "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kms,
+                     "ipm_mean_iters": float(iters.mean()), "optimal_fraction": float((status == 0).mean()),
+                     "kernel": {0: "runtime-dimension", 1: "ahead-of-time specialisation", 2: "on-demand specialisation",
+                                3: "small-problem kernel (four controllers per wavefront)"}[sh.kernel],
+                     "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / FP64_PEAK_TFLOPS, "flops_per_solve": flops}})
+        del sh
+        torch.cuda.empty_cache()
+    a5 = copy.copy(args)
+    a5.config, a5.batch = "C5", 0
+    r5 = bench_mhe.measure(a5, 0, 1, local, None, cpu=not args.no_cpu_baseline)
+    recs.append({"workload": r5["config"]["workload"], "batch": r5["config"]["batch_per_gpu"], "metric": r5["metric"],
+                 "value": r5["value"], "unit": r5["unit"], "ms_per_step": r5["ms_per_step"],
+                 "kernel_ms": r5["roofline"]["kernel_ms"], "ipm_mean_iters": r5["config"]["ipm_mean_iters"],
+                 "optimal_fraction": r5["config"]["optimal_fraction"], "kernel": "k_mhe_step (+ 2 k_mhe_cov per period)",
+                 "roofline": {k: r5["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flops_per_solve")},
+                 "cpu_baseline": r5.get("cpu_baseline")})
+    return recs
 
 
 def cpu_baseline(cfg, args, B):

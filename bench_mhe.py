@@ -68,7 +68,8 @@ class MheShard:
             self.kern_ms.append(self.h.last_ms())
 
 
-def run(args, rank, world, local, dist):
+def measure(args, rank, world, local, dist, cpu=True):
+    """One benchmark of the estimator period; returns the JSON-able record on rank 0 (None elsewhere)."""
     import torch
     from mpcqp import mhe as pm
     from mpcqp import synth
@@ -110,7 +111,7 @@ def run(args, rank, world, local, dist):
         dist.all_reduce(agg)
         n_opt, it_sum = int(agg[0].item()), float(agg[1].item())
     if rank != 0:
-        return
+        return None
     mean_it = it_sum / Bglobal
     # (the reported iteration count of an estimator is its last iteration index: factorisations = it + 1)
     flops, w_iter = mhe_flops(cfg, mean_it + 1.0)
@@ -150,44 +151,84 @@ def run(args, rank, world, local, dist):
                              "streams through HBM: traffic / kernel_ms is the measured HBM rate (peak 8000 GB/s), the "
                              "limiter of this kernel next to its dependent sweeps"},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and cpu and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args)
-    print(json.dumps(out), flush=True)
+    return out
 
 
-def cpu_baseline(cfg, args):
-    """oracle/mhe.py (dense NumPy restatement of the reference's condensed QP + exact active-set solve) on one
-    host core: a bounded number of steady-state periods of the first estimators of the same workload."""
+def run(args, rank, world, local, dist):
+    out = measure(args, rank, world, local, dist)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def _cpu_worker(job):
+    """Steady-state periods of ONE estimator of the workload on one core (oracle/mhe.py); returns (periods, seconds)."""
+    cfg, seed, b, budget = job
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
     from mpcqp import synth
     from oracle import estim as es
     from oracle import mhe as om
-    n = 2
-    bt = synth.make_mhe_batch(cfg, n, seed=args.seed)
+    bt = synth.make_mhe_batch(cfg, 1, seed=seed, lo=b)
     nper = cfg.He + 64
-    Y, U, D = synth.make_mhe_data(cfg, bt, nper, seed=args.seed)
-    ests = []
-    for b in range(n):
-        model = es.LinModelOracle(bt["A"][b], bt["Bu"][b], bt["C"][b], bt["Bd"][b] if cfg.nd else None,
-                                  np.zeros((cfg.nym, cfg.nd)) if cfg.nd else None)
-        e = om.MHEOracle(model, He=cfg.He, direct=cfg.direct, sigmaQ=np.full(cfg.nx, cfg.sigmaQ),
-                         sigmaR=np.full(cfg.nym, cfg.sigmaR), sigmaQint_ym=np.full(cfg.nym, cfg.sigmaQint),
-                         sigmaP_0=np.full(cfg.nx, cfg.sigmaP0), sigmaPint_ym_0=np.full(cfg.nym, cfg.sigmaP0),
-                         nint_ym=[1] * cfg.nym)
-        if np.isfinite(cfg.xabs):
-            e.setconstraint(xhatmin=np.full(cfg.nxh, -cfg.xabs), xhatmax=np.full(cfg.nxh, cfg.xabs))
-        ests.append(e)
+    Y, U, D = synth.make_mhe_data(cfg, bt, nper, seed=seed, lo=b)
+    model = es.LinModelOracle(bt["A"][0], bt["Bu"][0], bt["C"][0], bt["Bd"][0] if cfg.nd else None,
+                              np.zeros((cfg.nym, cfg.nd)) if cfg.nd else None)
+    e = om.MHEOracle(model, He=cfg.He, direct=cfg.direct, sigmaQ=np.full(cfg.nx, cfg.sigmaQ),
+                     sigmaR=np.full(cfg.nym, cfg.sigmaR), sigmaQint_ym=np.full(cfg.nym, cfg.sigmaQint),
+                     sigmaP_0=np.full(cfg.nx, cfg.sigmaP0), sigmaPint_ym_0=np.full(cfg.nym, cfg.sigmaP0),
+                     nint_ym=[1] * cfg.nym)
+    if np.isfinite(cfg.xabs):
+        e.setconstraint(xhatmin=np.full(cfg.nxh, -cfg.xabs), xhatmax=np.full(cfg.nxh, cfg.xabs))
     done, t_solve, k = 0, 0.0, 0
-    while k < nper and (k < cfg.He + 2 or t_solve < args.cpu_seconds):
-        for b, e in enumerate(ests):
-            d = D[k][b] if cfg.nd else ()
-            t0 = time.perf_counter()
-            e.preparestate(Y[k][b], d)
-            e.updatestate(U[k][b], Y[k][b], d)
-            if k >= cfg.He:                       # steady state only
-                t_solve += time.perf_counter() - t0
-                done += 1
+    while k < nper and (k < cfg.He + 2 or t_solve < budget):
+        d = D[k][0] if cfg.nd else ()
+        t0 = time.perf_counter()
+        e.preparestate(Y[k][0], d)
+        e.updatestate(U[k][0], Y[k][0], d)
+        if k >= cfg.He:                       # steady state only
+            t_solve += time.perf_counter() - t0
+            done += 1
         k += 1
-    return {"value": done / t_solve if t_solve > 0 else None, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": f"{done} steady-state periods (full window) of the first {n} estimators, {t_solve:.1f} s; "
-                      "oracle/mhe.py: the reference's condensed QP (nZ̃ = 252) built densely in NumPy and solved by "
-                      "oracle/qp.py"}
+    return done, t_solve
+
+
+def cpu_baseline(cfg, args):
+    """oracle/mhe.py (dense NumPy restatement of the reference's condensed QP + exact active-set solve) on every host
+    core: one estimator of the same workload per core (single-threaded BLAS), a bounded number of steady-state periods
+    each; value = sum over the cores of periods / seconds.  Runs in a fresh interpreter (no GPU runtime in the process
+    that forks the workers)."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline", str(args.config), str(float(args.cpu_seconds)), str(int(args.seed))]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.abspath(__file__)))
+    if r.returncode != 0:
+        return {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _cpu_baseline_main(name, budget, seed):
+    import multiprocessing as mp
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from mpcqp import synth
+    cfg = synth.get_mhe_config(name)
+    cores = max(1, len(os.sched_getaffinity(0)))
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(cfg, seed, b, budget) for b in range(cores)])
+    wall = time.perf_counter() - t0
+    rate = sum(d / t for d, t in res if t > 0)
+    done = sum(d for d, _ in res)
+    print(json.dumps({"value": rate, "unit": "solves/s", "cores": cores, "kind": "port",
+                      "sample": f"{done} steady-state periods (full window) in all, one estimator of the workload per core, "
+                                f"{budget:.0f} s of solves per core ({wall:.0f} s wall with the window fill); oracle/mhe.py: the "
+                                "reference's condensed QP (nZ̃ = 252) built densely in NumPy and solved by oracle/qp.py, "
+                                "single-threaded BLAS per process"}))
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 5 and sys.argv[1] == "--cpu-baseline":
+        _cpu_baseline_main(sys.argv[2], float(sys.argv[3]), int(sys.argv[4]))

@@ -117,7 +117,7 @@ int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const 
 
 /* Diagonal weights: Mdiag (nY,B), Ndiag (nDU,B), Ldiag (nU,B), Cwt (B) (ignored when neps == 0).
  * (`Diagonal(repeat(Mwt,Hp))` etc., src/controller/linmpc.jl:236-238.)  Runs K2 when the model
- * is set.  Block-diagonal M_Hp: mpcqp_set_output_weight_blocks; dense N_Hc/L_Hp: not in this ABI. */
+ * is set.  Block-diagonal M_Hp: mpcqp_set_output_weight_blocks; dense M_Hp / N_Hc / L_Hp: mpcqp_set_dense_weights. */
 int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
                       const double* Ldiag, const double* Cwt);
 
@@ -131,7 +131,7 @@ int mpcqp_set_flags(mpcqp_handle h, uint32_t flags);
  * This is the `M_Hp=` keyword of LinMPC (src/controller/linmpc.jl:205-214) for the weights the
  * reference's own tests use: a terminal cost, M_Hp = blkdiag(M, ..., M, P)
  * (test/3_test_predictive_control.jl:498-527).  NULL returns to the diagonal weight.  A weight that
- * couples different prediction steps is not supported (MPCQP_ERR_UNSUPPORTED on the host side).  */
+ * couples different prediction steps goes through mpcqp_set_dense_weights.                        */
 int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk);
 
 /* Dense (Hermitian) weight matrices, the reference's M_Hp=, N_Hc=, L_Hp= keywords in full generality
@@ -298,7 +298,8 @@ const char* mpcqp_last_build_error(void);
  * for everything else (mpcqp_get, kf_*, prepare ...); mpcqp_multi_shard its offset and size.
  * Device-resident data: call mpcqp_step_device on the shard handles with per-device pointers, and
  * mpcqp_multi_gather_device to collect Z (nZ,B), u0 (nu,B), status (B) of all shards into buffers on
- * one root device (hipMemcpyPeerAsync over xGMI; stream = a stream of the root device, or NULL). */
+ * one root device (hipMemcpyPeerAsync over xGMI; stream = a stream of the root device, or NULL);
+ * mpcqp_multi_scatter_device is the way in: per-period inputs born on one device, sliced to the shards. */
 typedef struct mpcqp_multi_s* mpcqp_multi;
 int mpcqp_multi_create(const mpcqp_dims* dims, const int32_t* device_ids, int32_t ndev, mpcqp_multi* out);
 int mpcqp_multi_destroy(mpcqp_multi mh);
@@ -317,6 +318,14 @@ int mpcqp_multi_step(mpcqp_multi mh, const double* xhat0, const double* lastu0, 
 int mpcqp_multi_gather_device(mpcqp_multi mh, int32_t root, const double* const* Z_shards,
                               const double* const* u0_shards, const int32_t* const* status_shards,
                               double* Z_root, double* u0_root, int32_t* status_root, void* stream);
+
+/* The scatter of a period's inputs that were born on ONE device (the estimates of a plant-wide observer, set points of
+ * a supervisory layer): x̂0 (nx̂,B), lastu0 (nu,B) and Ry (ry_rows,B; ry_rows = ny with MPCQP_FLAG_RY_CONSTANT, else ny Hp)
+ * on `root` are sliced into the per-device buffers of the shards, hipMemcpyPeerAsync over xGMI on `stream` (a stream of
+ * the root device, or NULL: the root handle's stream, synchronised before returning).  Twin of the gather above.     */
+int mpcqp_multi_scatter_device(mpcqp_multi mh, int32_t root, const double* xhat0_root, const double* lastu0_root,
+                               const double* Ry_root, int32_t ry_rows, double* const* xhat0_shards,
+                               double* const* lastu0_shards, double* const* Ry_shards, void* stream);
 
 /* Device time of the kernels of the last step / recondense on this handle, measured with HIP
  * events on the stream they ran on (milliseconds; < 0 if not available).                     */

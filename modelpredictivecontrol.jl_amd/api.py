@@ -39,7 +39,8 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_set_flags", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_lds_bytes", "mpcqp_row_groups", "mpcqp_prebuild",
            "mpcqp_last_build_error", "mpcqp_multi_create", "mpcqp_multi_destroy", "mpcqp_multi_ndev",
            "mpcqp_multi_handle", "mpcqp_multi_shard", "mpcqp_multi_set_model", "mpcqp_multi_set_weights",
-           "mpcqp_multi_set_bounds", "mpcqp_multi_prepare", "mpcqp_multi_step", "mpcqp_multi_gather_device")
+           "mpcqp_multi_set_bounds", "mpcqp_multi_prepare", "mpcqp_multi_step", "mpcqp_multi_gather_device",
+           "mpcqp_multi_scatter_device")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -134,6 +135,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_multi_prepare.argtypes = [C.c_void_p]
     lib.mpcqp_multi_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
     lib.mpcqp_multi_gather_device.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
+    lib.mpcqp_multi_scatter_device.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 4
     _lib = lib
     return lib
 
@@ -368,6 +370,7 @@ class MultiHandle:
         self.B, self.nxhat, self.nu, self.ny, self.nd, self.Hp, self.Hc = B, nxhat, nu, ny, nd, Hp, Hc
         self.nDU, self.nZ, self.nU, self.nY, self.nD = nu * Hc, nu * Hc + neps, nu * Hp, ny * Hp, nd * Hp
         self.flags = flags
+        self._devices = [int(v) for v in devices]
         self.ndev = self.lib.mpcqp_multi_ndev(self.h)
 
     def close(self):
@@ -423,6 +426,33 @@ class MultiHandle:
         _chk(self.lib, self.lib.mpcqp_multi_step(self.h, _ptr(x), _ptr(lu), _ptr(ry), _ptr(ru), _ptr(dd0), _ptr(dh),
                                                  _ptr(Z), _ptr(u0), _ptr(status), _ptr(iters), _ptr(yh)))
         return (u0, status, iters, yh) if want_Yhat else (u0, status, iters)
+
+
+    # ---- device-resident path: per-device buffers, nothing crosses PCIe --------------------------------------
+    def device_of(self, g):
+        """CUDA/HIP ordinal the shard g lives on (as given to the constructor)."""
+        return self._devices[g]
+
+    def step_device_shard(self, g, xhat0, lastu0, Ry, Z, u0, status, iters=0, stream=0):
+        """mpcqp_step_device on the handle of shard g: integer device addresses of that shard's buffers."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        hg = C.c_void_p(self.lib.mpcqp_multi_handle(self.h, g))
+        _chk(self.lib, self.lib.mpcqp_step_device(hg, v(xhat0), v(lastu0), v(Ry), None, None, None, v(Z), v(u0), v(status),
+                                                  v(iters), None, v(stream)))
+
+    def scatter_device(self, root, xhat0_root, lastu0_root, Ry_root, ry_rows, xhat0_shards, lastu0_shards, Ry_shards, stream=0):
+        """mpcqp_multi_scatter_device: whole-batch inputs on device `root` -> the shards' buffers (integer addresses)."""
+        arr = lambda ps: (C.c_void_p * len(ps))(*[C.c_void_p(int(p)) for p in ps])
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _chk(self.lib, self.lib.mpcqp_multi_scatter_device(self.h, root, v(xhat0_root), v(lastu0_root), v(Ry_root), int(ry_rows),
+                                                          arr(xhat0_shards), arr(lastu0_shards), arr(Ry_shards), v(stream)))
+
+    def gather_device(self, root, Z_shards, u0_shards, status_shards, Z_root, u0_root, status_root, stream=0):
+        """mpcqp_multi_gather_device: the shards' Z̃, u0, status -> whole-batch buffers on device `root`."""
+        arr = lambda ps: (C.c_void_p * len(ps))(*[C.c_void_p(int(p)) for p in ps])
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _chk(self.lib, self.lib.mpcqp_multi_gather_device(self.h, root, arr(Z_shards), arr(u0_shards), arr(status_shards),
+                                                         v(Z_root), v(u0_root), v(status_root), v(stream)))
 
 
 def steady_kalman_gain(Ahat, Chat, Qhat, Rhat, i_ym=None):

@@ -1040,6 +1040,27 @@ int mpcqp_multi_gather_device(mpcqp_multi mh, int32_t root, const double* const*
     return MPCQP_OK;
 }
 
+int mpcqp_multi_scatter_device(mpcqp_multi mh, int32_t root, const double* xhat0_root, const double* lastu0_root,
+                               const double* Ry_root, int32_t ry_rows, double* const* xhat0_shards,
+                               double* const* lastu0_shards, double* const* Ry_shards, void* stream) {
+    if (!mh || !xhat0_root || !lastu0_root || !Ry_root || !xhat0_shards || !lastu0_shards || !Ry_shards) return MPCQP_ERR_NULL;
+    if (root < 0 || root >= (int)mh->h.size() || ry_rows <= 0) return MPCQP_ERR_ARG;
+    mpcqp_handle hr = mh->h[root];
+    ON_DEVICE(hr);
+    hipStream_t st = stream ? (hipStream_t)stream : hr->stream;
+    const Dims& d = mh->d;
+    for (size_t g = 0; g < mh->h.size(); ++g) {
+        const int o = mh->off[g], dst = mh->h[g]->device;
+        const size_t B = mh->cnt[g];
+        if (!xhat0_shards[g] || !lastu0_shards[g] || !Ry_shards[g]) return MPCQP_ERR_NULL;
+        HIPCHK(hipMemcpyPeerAsync(xhat0_shards[g], dst, shard_of(xhat0_root, o, d.nxh), hr->device, B * d.nxh * sizeof(double), st));
+        HIPCHK(hipMemcpyPeerAsync(lastu0_shards[g], dst, shard_of(lastu0_root, o, d.nu), hr->device, B * d.nu * sizeof(double), st));
+        HIPCHK(hipMemcpyPeerAsync(Ry_shards[g], dst, shard_of(Ry_root, o, ry_rows), hr->device, B * (size_t)ry_rows * sizeof(double), st));
+    }
+    if (!stream) HIPCHK(hipStreamSynchronize(st));
+    return MPCQP_OK;
+}
+
 static double elapsed(hipEvent_t a, hipEvent_t b, bool timed) {
     if (!timed) return -1.0;
     if (hipEventSynchronize(b) != hipSuccess) return -1.0;

@@ -5,7 +5,10 @@ splits into contiguous index ranges with NO collective on the data path.
   of the global batch -- the same rule as `mpcqp_multi_create` in the library -- and `gather` collects
   the per-rank results on every rank with ONE all_gather per array (RCCL over xGMI on the GPU box,
   gloo in the CPU tests);
-* one process driving several GPUs: `mpcqp.MultiHandle` (mpcqp_multi_* of the C-ABI).
+  `scatter` is the way in when a period's inputs are born on ONE rank (a plant-wide observer, a supervisory layer): ONE
+  scatter collective per array hands every rank its slice;
+* one process driving several GPUs: `mpcqp.MultiHandle` (mpcqp_multi_* of the C-ABI; mpcqp_multi_scatter_device /
+  mpcqp_multi_gather_device move the slices with peer copies over xGMI).
 """
 from __future__ import annotations
 
@@ -40,3 +43,33 @@ def gather(local, B: int, dist, device=None):
     dist.all_gather(parts, pad)
     out = torch.cat([parts[r][: shard_range(B, r, world)[1]] for r in range(world)])
     return out if isinstance(local, torch.Tensor) else out.cpu().numpy()
+
+
+def scatter(whole, B: int, dist, src: int = 0, device=None, like=None):
+    """Rank `src` holds the whole-batch problem-major array `whole` ((B, ...) NumPy array or torch tensor; ignored on the
+    other ranks, which pass `like`: any array / tensor with the trailing shape and dtype); every rank receives its
+    contiguous shard (shard_range) with ONE scatter collective (RCCL on the GPU box, gloo in the CPU tests).  Shards
+    may differ by one row: they travel padded to the largest."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ref = whole if rank == src else like
+    as_numpy = not isinstance(ref, torch.Tensor)
+    t = torch.from_numpy(np.ascontiguousarray(ref)) if as_numpy else ref
+    if device is not None:
+        t = t.to(device)
+    cmax = shard_range(B, 0, world)[1]
+    tail = tuple(t.shape[1:])
+    recv = torch.empty((cmax,) + tail, dtype=t.dtype, device=t.device)
+    parts = None
+    if rank == src:
+        if t.shape[0] != B:
+            raise ValueError(f"whole-batch array has {t.shape[0]} rows, expected {B}")
+        parts = []
+        for r in range(world):
+            o, n = shard_range(B, r, world)
+            p = torch.zeros((cmax,) + tail, dtype=t.dtype, device=t.device)
+            p[:n] = t[o:o + n]
+            parts.append(p)
+    dist.scatter(recv, parts, src=src)
+    out = recv[: shard_range(B, rank, world)[1]].contiguous()
+    return out.cpu().numpy() if as_numpy else out

@@ -145,6 +145,62 @@ def test_multi_device_entry_points_on_gpu(hiplib):
     assert [mh.shard(g) for g in range(3)] == [(0, 334), (334, 333), (667, 333)]
 
 
+def _device_resident_multi(devices):
+    """Inputs born on the root device -> mpcqp_multi_scatter_device -> mpcqp_step_device per shard ->
+    mpcqp_multi_gather_device: equals the single-handle run bit for bit, nothing crosses PCIe in between."""
+    import torch
+    cfg = synth.C3
+    B = 1000
+    bt = synth.make_batch(cfg, B, seed=6)
+    ref = run_batch(cfg, bt, cold_start=True)
+    mh = mpcqp.MultiHandle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, devices, neps=1,
+                           flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START)
+    mh.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
+    mh.set_weights(np.full((B, mh.nY), cfg.Mwt), np.full((B, mh.nDU), cfg.Nwt), np.full((B, mh.nU), cfg.Lwt), np.full(B, cfg.Cwt))
+    mh.set_bounds(U0min=np.full((B, mh.nU), cfg.umin), U0max=np.full((B, mh.nU), cfg.umax), Y0max=np.full((B, mh.nY), cfg.ymax))
+    assert mh.prepare() == mpcqp.KERNEL_AOT
+    root = 0
+    dr = torch.device("cuda", devices[root])
+    x_r, lu_r, ry_r = (torch.from_numpy(bt[k]).to(dr) for k in ("xhat0", "lastu0", "ry"))
+    sh = []
+    for g, dv in enumerate(devices):
+        o, n = mh.shard(g)
+        d = torch.device("cuda", dv)
+        f = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=d)
+        sh.append(dict(x=f(n, cfg.nxh), lu=f(n, cfg.nu), ry=f(n, cfg.ny), Z=f(n, mh.nZ), u=f(n, cfg.nu),
+                       st=f(n, dt=torch.int32), it=f(n, dt=torch.int32)))
+    torch.cuda.synchronize()
+    ptrs = lambda k: [s_[k].data_ptr() for s_ in sh]
+    mh.scatter_device(root, x_r.data_ptr(), lu_r.data_ptr(), ry_r.data_ptr(), cfg.ny, ptrs("x"), ptrs("lu"), ptrs("ry"))
+    for g, s_ in enumerate(sh):
+        o, n = mh.shard(g)
+        assert np.array_equal(s_["x"].cpu().numpy(), bt["xhat0"][o:o + n])
+        mh.step_device_shard(g, s_["x"].data_ptr(), s_["lu"].data_ptr(), s_["ry"].data_ptr(), s_["Z"].data_ptr(),
+                             s_["u"].data_ptr(), s_["st"].data_ptr(), iters=s_["it"].data_ptr())
+    for dv in set(devices):
+        torch.cuda.synchronize(dv)
+    Z_r = torch.zeros((B, mh.nZ), dtype=torch.float64, device=dr)
+    u_r = torch.zeros((B, cfg.nu), dtype=torch.float64, device=dr)
+    st_r = torch.full((B,), -1, dtype=torch.int32, device=dr)
+    mh.gather_device(root, ptrs("Z"), ptrs("u"), ptrs("st"), Z_r.data_ptr(), u_r.data_ptr(), st_r.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(Z_r.cpu().numpy(), ref["Z"]) and np.all(st_r.cpu().numpy() == 0)
+    assert np.array_equal(u_r.cpu().numpy(), ref["u"])
+
+
+def test_device_resident_scatter_step_gather_one_gpu(hiplib):
+    _device_resident_multi([0, 0, 0])
+
+
+def test_device_resident_scatter_step_gather_distinct_gpus(hiplib):
+    """The same on distinct ordinals (peer copies over xGMI): needs a box with >= 2 GPUs."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU on this box")
+    _device_resident_multi(list(range(min(n, 4))))
+
+
 def test_fused_loop_equals_separate_steps_on_gpu(hiplib):
     """mpcqp_loop_device (one launch per control period) against kf_correct + step + kf_predict."""
     import torch

@@ -1,6 +1,7 @@
 """N > 1 paths on CPU, through PRODUCT code (the CPU wave emulator stands in for the device, see
 tests/emu): (1) two `gloo` ranks each build their shard with `sharding.shard_range`, step it through
-the C-ABI and collect the batch with `sharding.gather` (what bench.py does per GPU, RCCL there);
+the C-ABI -- the period's inputs arrive from rank 0 through `sharding.scatter` -- and collect the batch with
+`sharding.gather` (what bench.py does per GPU, RCCL there);
 (2) one process drives two "devices" through the library's multi-device entry points
 (`mpcqp_multi_*`: slicing, concurrent steps, gather into the caller's arrays).  Both must reproduce
 the unsharded run bit for bit: no collective on the data path."""
@@ -53,6 +54,13 @@ def _worker(rank, world, port, B, q):
     lib = mpcqp.api.load_library(EMU)
     lo, n = sharding.shard_range(B, rank, world)                       # this rank's shard
     bt = synth.make_batch(CFG, n, seed=4, lo=lo)
+    # the scatter of the north star: this period's inputs are born on rank 0 (whole batch) and reach the ranks as
+    # their contiguous slices, one scatter collective per array
+    whole = synth.make_batch(CFG, B, seed=4) if rank == 0 else None
+    for key in ("xhat0", "lastu0", "ry"):
+        got = sharding.scatter(whole[key] if rank == 0 else None, B, dist, src=0, like=bt[key])
+        assert got.shape == bt[key].shape and np.array_equal(got, bt[key]), key
+        bt[key] = got
     Z, u0, st = _solve(CFG, bt, lib)
     Zall = sharding.gather(Z, B, dist)
     stall = sharding.gather(st, B, dist)
