@@ -46,6 +46,24 @@
 namespace mpcqp {
 namespace mhe {
 
+// 1/x: v_rcp_f64 + one Newton step (2e-15 relative, see rcp() in mpcqp_bodies.h) / the raw instruction (5e-8) on the
+// GPU; a plain division on the host (CPU wave emulator).
+MPCQP_HD inline double recip(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+#else
+    return 1.0 / x;
+#endif
+}
+MPCQP_HD inline double recip_fast(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    return 1.0 / x;
+#endif
+}
+
 template <int I>
 struct IC { static constexpr int v = I; };
 template <int N, int I = 0, class F>
@@ -102,7 +120,7 @@ struct Ops {
             constexpr int k = decltype(ik)::v;
             const double dk = w.template rowbc<k>(a[k]);
             ok = ok && (dk > 1e-280) && (dk < 1e280);
-            const double pinv = 1.0 / dk;
+            const double pinv = recip(dk);
             const bool piv = (r == k);
             // a[c] <- m a[c] + g (a[c] of lane k):  pivot row (m = 0, g = 1/dk): a[c]/dk;  other rows (m = 1,
             // g = -a[k]/dk): a[c] - a[k] a_k[c] / dk
@@ -273,25 +291,29 @@ MPCQP_HD void cov_body(W& w, const Dims& d, const Args& a, int mode, const doubl
 // ---------------------------------------------------------------------------------------------
 // one inequality row: slack sv, multiplier lv, primal residual rp = g'z + s - h.
 struct RowK {
-    double Dt, wv, c;
+    double Dt, c;
 };
+// Everything a row needs is ONE reciprocal, wi = 1/(s + δλ) (the row algebra of Step::row_step in mpcqp_bodies.h):
+//   D̃ = λ wi,   w/s = wi,   c = wi rc - D̃ rp,   dλ = wi (λ a - rc),   ds = -wi (s a + δ rc),   a = rp + g'dz
+// -- v_rcp_f64 + one Newton step (recip) instead of the three / four IEEE divisions (~12 instructions each) of the
+// textbook formulas; algebraically the same quantities.
 MPCQP_HD inline RowK row_rhs(bool has, double sv, double lv, double rp, double extra, double delta) {
     // D̃ = D/(1 + δD), c = w rc/s - D̃ rp with rc = s λ + extra (Step::run of mpcqp_bodies.h)
     RowK k;
-    const double D = lv / sv;
-    k.wv = 1.0 / (1.0 + delta * D);
-    k.Dt = has ? D * k.wv : 0.0;
-    const double rc = sv * lv + extra;
-    k.c = has ? k.wv * rc / sv - k.Dt * rp : 0.0;
+    const double wi = recip(fma(delta, lv, sv));
+    k.Dt = has ? lv * wi : 0.0;
+    const double rc = fma(sv, lv, extra);
+    k.c = has ? fma(wi, rc, -k.Dt * rp) : 0.0;
     return k;
 }
 MPCQP_HD inline void row_dir(bool has, double sv, double lv, double rp, double gd, double extra, double delta,
                              double& ds, double& dl) {
-    const double D = lv / sv, wv = 1.0 / (1.0 + delta * D), Dt = D * wv, rc = sv * lv + extra;
-    dl = has ? -wv * rc / sv + Dt * (rp + gd) : 0.0;
-    ds = has ? -wv * ((rp + gd) + delta * rc / sv) : 0.0;
+    const double wi = recip(fma(delta, lv, sv)), rc = fma(sv, lv, extra), a = rp + gd;
+    dl = has ? wi * fma(lv, a, -rc) : 0.0;
+    ds = has ? -wi * fma(sv, a, delta * rc) : 0.0;
 }
-MPCQP_HD inline double ratio(double v, double dv) { return dv < 0.0 ? -v / dv : 1e300; }
+// step to the boundary along dv < 0 (raw v_rcp_f64, 5e-8 relative: the fraction-to-the-boundary factor leaves 1e-4)
+MPCQP_HD inline double ratio(double v, double dv) { return dv < 0.0 ? -v * recip_fast(dv) : 1e300; }
 
 // ---------------------------------------------------------------------------------------------
 // CM: compile-time set of bound classes the code is generated for (a handle whose classes are a subset runs it)
@@ -565,16 +587,16 @@ struct Solver {
                 // rows of this stage
                 if (cX) {
                     const double s0 = fmax(xc - xlo, 1.0), s1 = fmax(xhi - xc, 1.0);
-                    Sst(sm.XR + 4 * s + 0, s0); Sst(sm.XR + 4 * s + 1, lam0 / s0);
-                    Sst(sm.XR + 4 * s + 2, s1); Sst(sm.XR + 4 * s + 3, lam0 / s1);
+                    Sst(sm.XR + 4 * s + 0, s0); Sst(sm.XR + 4 * s + 1, lam0 * recip(s0));
+                    Sst(sm.XR + 4 * s + 2, s1); Sst(sm.XR + 4 * s + 3, lam0 * recip(s1));
                     m_l += (hxlo ? 1 : 0) + (hxhi ? 1 : 0);
                     if (hxlo) nh_l = fmax(nh_l, fabs(xlo) + 1.0);
                     if (hxhi) nh_l = fmax(nh_l, fabs(xhi) + 1.0);
                 }
                 if (cW && s < N) {          // ŵ(s) = 0 at the starting point
                     const double s0 = fmax(0.0 - wlo, 1.0), s1 = fmax(whi - 0.0, 1.0);
-                    Sst(sm.WR + 4 * s + 0, s0); Sst(sm.WR + 4 * s + 1, lam0 / s0);
-                    Sst(sm.WR + 4 * s + 2, s1); Sst(sm.WR + 4 * s + 3, lam0 / s1);
+                    Sst(sm.WR + 4 * s + 0, s0); Sst(sm.WR + 4 * s + 1, lam0 * recip(s0));
+                    Sst(sm.WR + 4 * s + 2, s1); Sst(sm.WR + 4 * s + 3, lam0 * recip(s1));
                     m_l += (hwlo ? 1 : 0) + (hwhi ? 1 : 0);
                     if (hwlo) nh_l = fmax(nh_l, fabs(wlo) + 1.0);
                     if (hwhi) nh_l = fmax(nh_l, fabs(whi) + 1.0);
@@ -583,8 +605,8 @@ struct Solver {
                     O::ldo(w.uniform(cbase + cm.Cm), coff, RL, T);
                     const double vv = ei - op.mv(T, xc);
                     const double s0 = fmax(vv - vlo, 1.0), s1 = fmax(vhi - vv, 1.0);
-                    Sst(sm.VR + 4 * i + 0, s0); Sst(sm.VR + 4 * i + 1, lam0 / s0);
-                    Sst(sm.VR + 4 * i + 2, s1); Sst(sm.VR + 4 * i + 3, lam0 / s1);
+                    Sst(sm.VR + 4 * i + 0, s0); Sst(sm.VR + 4 * i + 1, lam0 * recip(s0));
+                    Sst(sm.VR + 4 * i + 2, s1); Sst(sm.VR + 4 * i + 3, lam0 * recip(s1));
                     m_l += (hvlo ? 1 : 0) + (hvhi ? 1 : 0);
                     if (hvlo) nh_l = fmax(nh_l, fabs(vlo) + 1.0);
                     if (hvhi) nh_l = fmax(nh_l, fabs(vhi) + 1.0);

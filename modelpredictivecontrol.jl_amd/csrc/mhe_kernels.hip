@@ -64,8 +64,11 @@ hipError_t launch_step(const Dims& d, const Args& a, hipStream_t st) {
 
 }  // namespace mhe
 
+#ifndef MPCQP_SMALL_WAVES
+#define MPCQP_SMALL_WAVES 2      // register budget of the small-problem step kernel, in waves per SIMD
+#endif
 template <int NX>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_step_small(Dims d, Model m, StepIO io) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_SMALL_WAVES, 8))) void k_step_small(Dims d, Model m, StepIO io) {
     mhe::MheDevWave w{(int)threadIdx.x};
     step_small_body<mhe::MheDevWave, NX>(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
 }

@@ -162,18 +162,19 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         gmul(z, g2, g3);
         s0 = fmax(h0 + z, 1.0); s1 = fmax(h1 - z, 1.0); s2 = fmax(h2 - g2, 1.0); s3 = fmax(h3 - g3, 1.0);
         if (!p0) s0 = 1.0; if (!p1) s1 = 1.0; if (!p2) s2 = 1.0; if (!p3) s3 = 1.0;
-        l0 = p0 ? 10.0 * w0 / s0 : 0.0; l1 = p1 ? 10.0 * w1 / s1 : 0.0; l2 = p2 ? 10.0 * w2 / s2 : 0.0; l3 = p3 ? 10.0 * w3 / s3 : 0.0;
+        l0 = p0 ? 10.0 * w0 * mhe::recip(s0) : 0.0; l1 = p1 ? 10.0 * w1 * mhe::recip(s1) : 0.0; l2 = p2 ? 10.0 * w2 * mhe::recip(s2) : 0.0; l3 = p3 ? 10.0 * w3 * mhe::recip(s3) : 0.0;
     }
     const double delta = d.dual_reg;
     int st = 1, it = 0;
     bool done = false;
     double laststep = 1e300, rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0, rpn = 0.0;
-    struct RowD { double Dt, wv; };
+    double mu_seen = 0.0, rd_seen = 0.0;      // what the convergence test saw last (audit record)
+    // one reciprocal per row, wi = 1/(s + δλ): D̃ = λ wi, w/s = wi (mhe::row_rhs)
+    struct RowD { double Dt, wi; };
     auto rowd = [&](bool has, double sv, double lv) {
         RowD r;
-        const double D = lv / sv;
-        r.wv = 1.0 / (1.0 + delta * D);
-        r.Dt = has ? D * r.wv : 0.0;
+        r.wi = mhe::recip(fma(delta, lv, sv));
+        r.Dt = has ? lv * r.wi : 0.0;
         return r;
     };
     for (int pass = 0; pass < d.max_iter; ++pass) {
@@ -194,6 +195,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
 #endif
         if (!done) {
             it = pass;
+            mu_seen = mu; rd_seen = rdn / ndd;
             if (!(mu == mu) || !(rdn == rdn)) { st = 2; done = true; }
             const bool stalled = rdn >= 0.5 * rdn_prev && lastscale <= 0.1;
             rdn_prev = rdn;
@@ -205,11 +207,19 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         if (!w.any(!done)) break;
         // ---- Φ = H̃ + Gᵀ D̃ G, Φ⁻¹
         const RowD d0 = rowd(p0, s0, l0), d1 = rowd(p1, s1, l1), d2 = rowd(p2, s2, l2), d3 = rowd(p3, s3, l3);
-        Row Phi, T, U;
-        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = H[c]; T[c] = (d2.Dt + d3.Dt) * GU[c]; });
+        Row Phi;
+        // P̃u' (D̃2 + D̃3) P̃u without forming the product: entry (l, c) of two variables of the same input channel is the
+        // sum of D̃ over the intervals from the later of the two on, i.e. the suffix sum `suf` of the later one -- the
+        // lane's own for the columns up to its own, the column's lane's (row broadcast) for the later columns.
+        // (GU = 1 on the columns c <= l of the lane's channel, GUt = 1 on the columns c >= l: both include c = l.)
+        const double suf = op.mv(GUt, d2.Dt + d3.Dt);
+        mhe::sfor<NX>([&](auto ic) {
+            constexpr int c = decltype(ic)::v;
+            const double later = w.template rowbc<c>(suf);
+            Phi[c] = fma(GU[c], suf, H[c]);
+            Phi[c] = fma(GUt[c], later - (l == c ? suf : 0.0), Phi[c]);
+        });
         O::add_diag(Phi, l, d0.Dt + d1.Dt);
-        op.mm(GUt, T, U);                              // P̃u' (D̃2 + D̃3) P̃u
-        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += U[c]; });
         if (d.neps) {      // ϵ column / row: Φ[k][ϵ] = sum_j P̃u[j][k] (D̃2 cs0 - D̃3 cs1)_j,  Φ[ϵ][ϵ] += sum_j D̃2 cs0² + D̃3 cs1²
             const double col = op.mv(GUt, d2.Dt * cs0 - d3.Dt * cs1);
             const double dee = w.rsum(d2.Dt * cs0 * cs0 + d3.Dt * cs1 * cs1);
@@ -227,7 +237,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         double ds0 = 0, ds1 = 0, ds2 = 0, ds3 = 0, dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0;
         for (int phase = 0; phase < 2; ++phase) {
             auto cof = [&](bool has, const RowD& rr, double sv, double lv, double rp, double ex) {
-                return has ? rr.wv * (sv * lv + ex) / sv - rr.Dt * rp : 0.0;
+                return has ? fma(rr.wi, fma(sv, lv, ex), -rr.Dt * rp) : 0.0;
             };
             const double e0 = phase ? a0 - w0 * smu : 0.0, e1 = phase ? a1 - w1 * smu : 0.0;
             const double e2 = phase ? a2 - w2 * smu : 0.0, e3 = phase ? a3 - w3 * smu : 0.0;
@@ -239,9 +249,9 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             double gd2, gd3;
             gmul(dz, gd2, gd3);
             auto dir = [&](bool has, const RowD& rr, double sv, double lv, double rp, double gd, double ex, double& ds, double& dl) {
-                const double rc = sv * lv + ex;
-                dl = has ? -rr.wv * rc / sv + rr.Dt * (rp + gd) : 0.0;
-                ds = has ? -rr.wv * ((rp + gd) + delta * rc / sv) : 0.0;
+                const double rc = fma(sv, lv, ex), a = rp + gd;
+                dl = has ? rr.wi * fma(lv, a, -rc) : 0.0;
+                ds = has ? -rr.wi * fma(sv, a, delta * rc) : 0.0;
             };
             dir(p0, d0, s0, l0, rp0, -dz, e0, ds0, dl0); dir(p1, d1, s1, l1, rp1, dz, e1, ds1, dl1);
             dir(p2, d2, s2, l2, rp2, gd2, e2, ds2, dl2); dir(p3, d3, s3, l3, rp3, gd3, e3, ds3, dl3);
@@ -264,7 +274,8 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
                 auto pr = [&](bool has, double sv, double ds, double lv, double dl) { return has ? (sv + alpha * ds) * (lv + alpha * dl) : 0.0; };
                 const double q0 = pr(p0, s0, ds0, l0, dl0), q1 = pr(p1, s1, ds1, l1, dl1), q2 = pr(p2, s2, ds2, l2, dl2), q3 = pr(p3, s3, ds3, l3, dl3);
                 const double psum = w.rsum(q0 + q1 + q2 + q3);
-                const double pmin = w.rmin(fmin(fmin(p0 ? q0 / w0 : 1e300, p1 ? q1 / w1 : 1e300), fmin(p2 ? q2 / w2 : 1e300, p3 ? q3 / w3 : 1e300)));
+                const double iwt = mhe::recip_fast(wt);         // (w0 = w1 = 1, w2 = w3 = wt)
+                const double pmin = w.rmin(fmin(fmin(p0 ? q0 : 1e300, p1 ? q1 : 1e300), fmin(p2 ? q2 * iwt : 1e300, p3 ? q3 * iwt : 1e300)));
                 if (!(pmin * wsum >= 0.01 * psum)) alpha = fmin(1.0, 0.99 * amin);
             }
         }
@@ -307,7 +318,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             if (io.iters) io.iters[b] = it;                          // factorisations (0: closed form, no finite row)
             if (io.audit) {
                 double* au = io.audit + (size_t)b * 4;
-                au[0] = 0.0; au[1] = 0.0; au[2] = rpn / nh; au[3] = 0.0;
+                au[0] = mu_seen; au[1] = rd_seen; au[2] = rpn / nh; au[3] = 0.0;     // (no polish in this kernel)
             }
         }
     }
