@@ -28,6 +28,7 @@ struct mpcqp_mhe_s {
     std::vector<void*> owned;
     // device arrays
     double *lastu = nullptr, *P0 = nullptr, *Pout = nullptr;
+    double* raw_own[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device copies of set_model's arrays
     double* bnd[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* sft[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* Cwt = nullptr;
@@ -176,12 +177,14 @@ int mpcqp_mhe_set_model(mpcqp_mhe h, const double* Ahat, const double* Bhu, cons
     ON_DEVICE(h);
     const size_t B = d.B, nx = d.nx, nu = d.nu, nym = d.nym, nd = d.nd;
     int rc = MPCQP_OK;
+    // (the sizes are fixed by the handle's dimensions: a second set_model -- setmodel! -- reuses the first one's arrays)
+    int k = 0;
     auto put = [&](const double** slot, const double* src, size_t n) {
+        double*& keep = h->raw_own[k++];
         if (rc || !src || n == 0) { if (!src) *slot = nullptr; return; }
-        double* p = nullptr;
-        rc = dalloc_t(h, &p, n);
-        if (!rc) rc = up(h, p, src, n);
-        *slot = p;
+        if (!keep) rc = dalloc_t(h, &keep, n);
+        if (!rc) rc = up(h, keep, src, n);
+        *slot = keep;
     };
     put(&h->raw.Ahat, Ahat, B * nx * nx); put(&h->raw.Bu, Bhu, B * nx * nu); put(&h->raw.Cm, Chm, B * nym * nx);
     put(&h->raw.Bd, Bhd, B * nx * nd); put(&h->raw.Ddm, Dhdm, B * nym * nd); put(&h->raw.fx, fx, B * nx);

@@ -61,6 +61,15 @@ static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
     return MPCQP_OK;
 }
 
+// give a scratch array back before the handle goes (temporaries of mpcqp_prepare's self-test)
+static void dev_release(mpcqp_handle h, DBuf& b) {
+    if (!b.p) return;
+    for (size_t i = 0; i < h->owned.size(); ++i)
+        if (h->owned[i] == b.p) { h->owned.erase(h->owned.begin() + (long)i); break; }
+    (void)hipFree(b.p);
+    b = DBuf{};
+}
+
 // A step enqueued on a caller's stream (mpcqp_step_device) may still read the handle's device
 // arrays: every upload into them is ordered behind the end of that step (event ev_s1).
 static int upload(mpcqp_handle h, DBuf& b, const void* src, size_t bytes) {
@@ -753,20 +762,27 @@ const char* mpcqp_last_build_error(void) { return g_build_err.c_str(); }
 
 // One cold-started step of the first few controllers of the handle on pseudo-random states / set points, once
 // with the on-demand specialisation and once with the runtime-dimension kernel: same iterates up to rounding.
+static int self_test_spec_impl(mpcqp_handle h, double* worst, DBuf& yh, DBuf& in, DBuf& out, DBuf& sti);
 static int self_test_spec(mpcqp_handle h, double* worst) {
+    DBuf yh, in, out, sti;           // scratch of the comparison: released on every path
+    const int rc = self_test_spec_impl(h, worst, yh, in, out, sti);
+    (void)hipStreamSynchronize(h->stream);
+    dev_release(h, yh); dev_release(h, in); dev_release(h, out); dev_release(h, sti);
+    return rc;
+}
+static int self_test_spec_impl(mpcqp_handle h, double* worst, DBuf& yh, DBuf& in, DBuf& out, DBuf& sti) {
     Dims d = h->d;
     d.B = d.B < 8 ? d.B : 8;
     d.flags = (d.flags | MPCQP_FLAG_COLD_START) & ~(uint32_t)(MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL);
     const size_t n = d.B, nry = (d.flags & MPCQP_FLAG_RY_CONSTANT) ? d.ny : d.nY;
     const size_t cnt[] = {n * d.nxh, n * d.nu, n * nry, n * (d.nd ? d.nd : 1), n * (d.nD ? d.nD : 1), n * d.nZ, n * d.nZ, n * d.nu, n * d.nu};
-    DBuf yh;                      // (Ŷ as well: the specialisation's predict! path is part of what is tested)
+    // (Ŷ as well: the specialisation's predict! path is part of what is tested)
     { int rcy = dev_alloc(h, yh, n * d.nY * sizeof(double)); if (rcy) return rcy; }
     std::vector<double> host(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4], 0.0);
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     auto rnd = [&] { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
     for (size_t i = 0; i < cnt[0]; ++i) host[i] = rnd();
     for (size_t i = 0; i < cnt[2]; ++i) host[cnt[0] + cnt[1] + i] = 2.0 * rnd();
-    DBuf in, out, sti;
     size_t total_in = host.size(), total_out = cnt[5] + cnt[6] + cnt[7] + cnt[8];
     int rc = dev_alloc(h, in, total_in * sizeof(double));
     if (!rc) rc = dev_alloc(h, out, total_out * sizeof(double));
@@ -783,7 +799,7 @@ static int self_test_spec(mpcqp_handle h, double* worst) {
     io.Z = pout; io.u0 = pout + cnt[5] + cnt[6]; io.status = pst; io.iters = pst + n;
     io.Yhat0 = (double*)yh.p;
     io.kf_predict = 0;
-    HIPCHK(launch_step_spec_or_aot(d, h->m, io, h->stream));
+    HIPCHK(launch_step_unverified_spec(d, h->m, io, h->stream));
     io.Z = pout + cnt[5]; io.u0 = pout + cnt[5] + cnt[6] + cnt[7]; io.status = pst + 2 * n; io.iters = pst + 3 * n;
     HIPCHK(launch_step_generic(d, h->m, io, h->stream));
     std::vector<double> z(cnt[5] + cnt[6]);
@@ -961,11 +977,13 @@ int mpcqp_multi_set_bounds(mpcqp_multi mh, const mpcqp_bounds* b) {
 
 int mpcqp_multi_prepare(mpcqp_multi mh) {
     if (!mh) return MPCQP_ERR_NULL;
-    int kind = MPCQP_KERNEL_ONDEMAND;
+    // every shard has the same dimensions, hence the same kernel -- unless a shard's on-demand kernel was rejected on
+    // its device: the runtime-dimension kernel of ANY shard is what the caller has to know about
+    int kind = -1;
     for (mpcqp_handle hg : mh->h) {
         const int k = mpcqp_prepare(hg);
         if (k < 0) return k;
-        if (k < kind || k == MPCQP_KERNEL_AOT) kind = k;
+        if (kind < 0 || k == MPCQP_KERNEL_GENERIC) kind = k;
     }
     return kind;
 }

@@ -90,10 +90,12 @@ struct SpecLib {
     int (*matches_dims)(const Dims*) = nullptr;
     int (*step)(const Dims*, const Model*, const StepIO*, void*) = nullptr;
     int (*hessian)(const Dims*, const Model*, void*) = nullptr;
+    bool verified = false;        // compared with the runtime-dimension kernel on this machine (marker <object>.ok)
 };
 using SpecKey = std::tuple<int, int, int, int, int, int, unsigned, int>;
 static std::mutex g_spec_mu;
 static std::map<SpecKey, SpecLib> g_spec;        // failed loads are cached as empty entries
+static const SpecLib* find_verified_spec(const Dims& d);
 
 static std::string lib_dir() {
     Dl_info info;
@@ -121,12 +123,21 @@ static std::string cache_dir() {
     if (const char* x = getenv("XDG_CACHE_HOME")) base = x;
     if (base.empty()) {
         const char* home = getenv("HOME");
-        base = std::string(home ? home : "/tmp") + "/.cache";
+        if (!home || !home[0]) return "";        // no private place to keep shared objects: no on-demand kernels
+        base = std::string(home) + "/.cache";
         (void)dir_writable(base);
     }
     const std::string d = base + "/mpcqp";
     (void)dir_writable(d);
     return d;
+}
+
+// Shared objects are only loaded from a directory that belongs to this user (or root) and that others cannot write.
+static bool cache_dir_trusted(const std::string& d) {
+    struct stat sb;
+    if (d.empty() || stat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) return false;
+    if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
+    return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
 static std::string hipcc_path() {
@@ -183,6 +194,10 @@ static int run_process(const std::vector<std::string>& argv, const std::string& 
 static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
     const std::string cache = cache_dir(), so = cache + "/" + spec_name(d);
     if (path_out) *path_out = so;
+    if (!cache_dir_trusted(cache)) {
+        if (err) *err = "specialisation cache directory '" + cache + "' is missing, not owned by this user or writable by others (set MPCQP_CACHE_DIR)";
+        return -1;
+    }
     struct stat sb;
     if (stat(so.c_str(), &sb) == 0) return 0;
     if (access(cache.c_str(), W_OK | X_OK) != 0) {
@@ -227,7 +242,9 @@ static const SpecLib* find_spec(const Dims& d, bool load) {
     auto it = g_spec.find(key);
     if (it != g_spec.end()) return it->second.step ? &it->second : nullptr;
     if (!load) return nullptr;
-    const std::string so = cache_dir() + "/" + spec_name(d);
+    const std::string cdir = cache_dir();
+    if (!cache_dir_trusted(cdir)) return nullptr;
+    const std::string so = cdir + "/" + spec_name(d);
     struct stat sb;
     if (stat(so.c_str(), &sb) != 0) return nullptr;              // not built (yet): nothing is remembered
     SpecLib sl;
@@ -264,7 +281,7 @@ int step_kernel_kind(const Dims& d) {
 int step_kernel_kind_other(const Dims& d) {
     if (force_generic() || d.dense_w) return 0;
     if (aot_matches(d)) return 1;
-    return find_spec(d, true) ? 2 : 0;
+    return find_verified_spec(d) ? 2 : 0;
 }
 
 // Make the specialised kernel of `d` available (compile if needed, load).  Returns the kernel kind
@@ -307,6 +324,21 @@ bool spec_verified(const Dims& d) {
 void mark_spec_verified(const Dims& d) {
     if (FILE* f = fopen((cache_dir() + "/" + spec_name(d) + ".ok").c_str(), "w")) fclose(f);
 }
+// the specialisation a STEP may run: loaded AND verified (mpcqp_prepare's self-test, or the marker of an earlier one);
+// an object that some other process, a build pipeline (mpcqp_prebuild) or a prepare without a model put into the cache
+// runs only after this machine has compared it with the runtime-dimension kernel
+static const SpecLib* find_verified_spec(const Dims& d) {
+    const SpecLib* sl = find_spec(d, true);
+    if (!sl) return nullptr;
+    if (sl->verified) return sl;
+    if (!spec_verified(d)) return nullptr;
+    std::lock_guard<std::mutex> lock(g_spec_mu);
+    auto it = g_spec.find(SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb});
+    if (it == g_spec.end() || !it->second.step) return nullptr;
+    it->second.verified = true;
+    return &it->second;
+}
+
 void reject_spec(const Dims& d) {
     const std::string so = cache_dir() + "/" + spec_name(d);
     (void)rename(so.c_str(), (so + ".bad").c_str());
@@ -356,13 +388,19 @@ hipError_t launch_step_spec_or_aot(const Dims& d, const Model& m, const StepIO& 
         }
         MPCQP_SPECIALIZATIONS(X)
 #undef X
-        if (const SpecLib* sl = find_spec(d, true)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
+        if (const SpecLib* sl = find_verified_spec(d)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
     }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_step, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_step, dim3(d.B), dim3(WAVE), lds, st, d, m, io);
     return hipGetLastError();
+}
+
+// the on-demand specialisation itself, verified or not: only mpcqp_prepare's comparison calls this
+hipError_t launch_step_unverified_spec(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
+    if (const SpecLib* sl = find_spec(d, true)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
+    return launch_step_spec_or_aot(d, m, io, st);
 }
 
 static int kf_npad(const Dims& d) {

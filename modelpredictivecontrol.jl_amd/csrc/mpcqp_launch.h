@@ -23,6 +23,7 @@ bool spec_verified(const Dims& d);
 void mark_spec_verified(const Dims& d);
 void reject_spec(const Dims& d);
 hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
+hipError_t launch_step_unverified_spec(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);   // self-test only
 // Small problems (nZ~ <= 16, box and input-bound rows only): four controllers per wavefront (mpcqp_small_bodies.h)
 hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
 inline bool small_eligible(const Dims& d, const Model& m, const StepIO& io) {

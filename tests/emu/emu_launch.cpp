@@ -175,6 +175,7 @@ bool spec_verified(const Dims&) { return true; }
 void mark_spec_verified(const Dims&) {}
 void reject_spec(const Dims&) {}
 hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) { return launch_step(d, m, io, st); }
+hipError_t launch_step_unverified_spec(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) { return launch_step(d, m, io, st); }
 size_t step_lds_bytes(const Dims& d) { return (size_t)make_carve(d).total * sizeof(double); }
 
 }  // namespace mpcqp
