@@ -828,12 +828,9 @@ struct Qp {
 // ------------------------------------------------------------------------------------------
 // K1: prediction tables of one problem.  LDS: see predmat_lds_doubles().
 // ------------------------------------------------------------------------------------------
-// steps of the K table written together: PREDMAT_KSTAGE ny doubles are contiguous in a row of Ktab (128 B for ny = 4)
-constexpr int PREDMAT_KSTAGE = 4;
 MPCQP_HD inline int predmat_lds_doubles(const Dims& d) {
     int nx = d.nxh;
-    return nx * nx * 3 + nx * d.nu * 2 + d.ny * nx * 3 + nx * 2 + nx * (d.nd > 0 ? d.nd : 1) * 2 + 8 +
-           PREDMAT_KSTAGE * d.ny * nx;                 // K blocks of PREDMAT_KSTAGE steps staged for full-line stores
+    return nx * nx * 3 + nx * d.nu * 2 + d.ny * nx * 3 + nx * 2 + nx * (d.nd > 0 ? d.nd : 1) * 2 + 8;
 }
 
 template <class W>
@@ -851,7 +848,6 @@ MPCQP_HD void predmat_body(W& w, const Dims& d, const Model& m, int b, double* s
     double* v1 = v0 + nx;
     double* X0 = v1 + nx;                   // Â^m B̂d ping  X[i + nx*e]
     double* X1 = X0 + nx * (nd > 0 ? nd : 1);
-    double* Kst = X1 + nx * (nd > 0 ? nd : 1) + 8;          // [PREDMAT_KSTAGE][ny*nx] staged K blocks
     const double* gA = m.Ahat + (size_t)b * nx * nx;
     const double* gB = m.Bu + (size_t)b * nx * nu;
     const double* gC = m.C + (size_t)b * ny * nx;
@@ -884,21 +880,9 @@ MPCQP_HD void predmat_body(W& w, const Dims& d, const Model& m, int b, double* s
             for (int l = 0; l < nx; ++l) acc += Cm[a + ny * l] * W0[l + nx * cc];
             Stab[(t * ny + a) * nu + cc] = acc;
         }
-        // K block t = Ĉ Â^{t+1}: row k of Ktab holds the ny entries of step t next to those of step t+1, so the blocks of
-        // PREDMAT_KSTAGE steps are staged in LDS and leave as runs of PREDMAT_KSTAGE ny doubles (whole 128-byte lines
-        // for ny = 4; a 32-byte piece per step and row left the write-back cache one partial line at a time)
-        {
-            const int ts = t % PREDMAT_KSTAGE;
-            for (int i = w.lane; i < ny * nx; i += WAVE) Kst[ts * ny * nx + i] = P0[i];
-            if (ts == PREDMAT_KSTAGE - 1 || t == Hp - 1) {
-                w.sync();
-                const int t0 = t - ts, run = (ts + 1) * ny;
-                for (int i = w.lane; i < nx * run; i += WAVE) {
-                    const int k = i / run, off = i - k * run, tt = off / ny, a = off - tt * ny;
-                    Ktab[(size_t)k * d.nY + t0 * ny + off] = Kst[tt * ny * nx + a + ny * k];
-                }
-                w.sync();
-            }
+        for (int i = w.lane; i < ny * nx; i += WAVE) {          // K block t = Ĉ Â^{t+1}
+            int a = i % ny, k = i / ny;
+            Ktab[(size_t)k * d.nY + t * ny + a] = P0[i];
         }
         for (int a = w.lane; a < ny; a += WAVE) {               // B block t = Ĉ S(t) dop
             double acc = 0.0;
