@@ -44,7 +44,7 @@ typedef struct {
     int32_t device;
     uint32_t flags;     /* MPCQP_MHE_*                                                            */
     int32_t max_iter;   /* 0: default (80)                                                       */
-    double gap_tol, res_tol, dual_reg;   /* 0: defaults of the LinMPC step (1e-12, 1e-11, 1e-12) */
+    double gap_tol, res_tol, dual_reg;   /* 0: defaults 1e-12, 1e-11 (as the LinMPC step) and 1e-10 */
 } mpcqp_mhe_dims;
 
 int mpcqp_mhe_create(const mpcqp_mhe_dims* dims, mpcqp_mhe* out);
@@ -58,9 +58,18 @@ int mpcqp_mhe_set_model(mpcqp_mhe h, const double* Ahat, const double* Bhu, cons
                         const double* Dhdm, const double* fx, const double* Qhat, const double* Rhat);
 
 /* setconstraint!: per-channel hard bounds in deviation variables, (nx̂,B) / (nym,B) host arrays, NULL or
- * +-Inf entries = no bound.  x̂ bounds apply to the arrival state and to every state of the window. */
+ * +-Inf entries = no bound.  x̂ bounds apply to the arrival state and to every state of the window
+ * (stage-dependent bounds: mpcqp_mhe_set_bounds_window). */
 int mpcqp_mhe_set_bounds(mpcqp_mhe h, const double* xmin, const double* xmax, const double* wmin, const double* wmax,
                          const double* vmin, const double* vmax);
+
+/* Window-long bounds, setconstraint!(estim; X̂min, X̂max, Ŵmin, Ŵmax, V̂min, V̂max) (construct.jl:858-935): one bound per
+ * channel AND stage.  Xmin / Xmax (nx̂ (He+1), B): the arrival state first, then the He window states oldest first;
+ * Wmin / Wmax (nx̂ He, B); Vmin / Vmax (nym He, B); deviation variables, +-Inf = no bound, NULL = class absent.  A window
+ * that is not full yet (Nk < He) uses the LAST Nk blocks, like the reference (trunc_bounds).  Replaces the bounds of
+ * mpcqp_mhe_set_bounds (and vice versa).  Softness stays per channel (mpcqp_mhe_set_softness).                      */
+int mpcqp_mhe_set_bounds_window(mpcqp_mhe h, const double* Xmin, const double* Xmax, const double* Wmin, const double* Wmax,
+                                const double* Vmin, const double* Vmax);
 
 /* Soft constraints (MovingHorizonEstimator(...; Cwt) + setconstraint!(estim; c_x̂min, ..., c_v̂max), construct.jl:858-1049,
  * 1151-1288): Cwt (B) finite weights of ε² (NULL: Cwt = Inf, hard constraints only, the reference's default) and the
@@ -77,6 +86,13 @@ int mpcqp_mhe_init(mpcqp_mhe h, const double* xhat0, const double* P0, const dou
  * the window length and the arrival covariance stay (the reference raises when a covariance is passed to a
  * MovingHorizonEstimator, mhe/execute.jl:938-941: callers must not offer one).                                    */
 int mpcqp_mhe_set_state(mpcqp_mhe h, const double* xhat0);
+
+/* setmodel!(estim, model) (src/estimator/execute.jl:483-497, mhe/execute.jl:943-1046) in two calls: mpcqp_mhe_set_model
+ * with the new augmented model (and covariances), and this one for the operating points -- the data windows, lastu0,
+ * x̂0 and x̂0arr are deviation variables, so a change of (yop, uop, dop, x̂op) moves them by
+ * dy0m = yop_old - yop_new (nym,B), du0 = uop_old - uop_new (nu,B), dd0 (nd,B), dx0 = x̂op_old - x̂op_new (nx̂,B);
+ * NULL = unchanged.  Bounds on x̂ are deviation variables too: send them again (mpcqp_mhe_set_bounds).            */
+int mpcqp_mhe_shift_windows(mpcqp_mhe h, const double* dy0m, const double* du0, const double* dd0, const double* dx0);
 
 /* preparestate!: current form: add (y0m, d0, lastu0) to the windows, correct the arrival covariance when
  * the window moves, solve the QP, x̂0 <- estimate.  Predictor form: nothing to do (returns MPCQP_OK).

@@ -39,6 +39,9 @@
 #ifndef MPCQP_MHE_DEPTH_U
 #define MPCQP_MHE_DEPTH_U 2
 #endif
+#ifndef MPCQP_MHE_EXACT_PIVOT
+#define MPCQP_MHE_EXACT_PIVOT 0
+#endif
 #ifndef MPCQP_MHE_BMID_LDS
 #define MPCQP_MHE_BMID_LDS 1     // middle diagonal block of the Hessian in LDS (18 KB per wave) or read from the constant block (12 KB)
 #endif
@@ -120,7 +123,11 @@ struct Ops {
             constexpr int k = decltype(ik)::v;
             const double dk = w.template rowbc<k>(a[k]);
             ok = ok && (dk > 1e-280) && (dk < 1e280);
+#if MPCQP_MHE_EXACT_PIVOT
+            const double pinv = 1.0 / dk;
+#else
             const double pinv = recip(dk);
+#endif
             const bool piv = (r == k);
             // a[c] <- m a[c] + g (a[c] of lane k):  pivot row (m = 0, g = 1/dk): a[c]/dk;  other rows (m = 1,
             // g = -a[k]/dk): a[c] - a[k] a_k[c] / dk
@@ -345,6 +352,7 @@ struct Solver {
     double xlo, xhi, wlo, whi, vlo, vhi;
     bool hxlo, hxhi, hwlo, hwhi, hvlo, hvhi;
     bool cS;                                   // a slack variable ε >= 0 relaxes the rows with softness c > 0
+    bool cL;                                   // window-long bounds (CLS_L): xlo .. vhi are re-read for every stage
     double cx0, cx1, cw0, cw1, cv0, cv1;       // softness of this lane's rows (0: hard)
 
     MPCQP_HD Solver(W& w_, const Dims& d_, const Args& a_, double* smem, int wave_id)
@@ -358,6 +366,7 @@ struct Solver {
         p = d.direct ? 0 : 1;
         cX = (CM & CLS_X) && (d.cls & CLS_X); cW = (CM & CLS_W) && (d.cls & CLS_W); cV = (CM & CLS_V) && (d.cls & CLS_V);
         cS = (CM & CLS_S) && (d.cls & CLS_S);
+        cL = (CM & (CLS_W | CLS_V)) && (d.cls & CLS_L);      // (served by the all-class variants only)
     }
     // Scratch accesses are raw buffer loads / stores: the slot offset is the instruction's scalar offset, the lane's
     // byte offset ONE register for the whole kernel, and the idle lanes carry an out-of-range offset -- the
@@ -377,6 +386,31 @@ struct Solver {
     MPCQP_HD int dslot(int i) const { return (d.hd + i) % (d.He + 1); }
     // measurement attached to state s (p = 0: i = s-1, p = 1: i = s), -1: none
     MPCQP_HD int meas_of(int s) const { const int i = s - 1 + p; return (i >= 0 && i < N) ? i : -1; }
+
+    // Window-long bounds (setconstraint!(estim; X̂min, ..., V̂max), construct.jl:858-935): the rows of stage s -- state
+    // x(s) (s = 0: the arrival state's own bound), ŵ(s), v̂ of the measurement attached to s -- take their bounds from
+    // block (He - N + .) of the He-long vectors: a window of N < He periods uses the LAST N blocks (trunc_bounds).
+    MPCQP_HD void stage_bounds(int s) {
+        if (!cL) return;
+        const int He = d.He, blk = He - N;
+        auto at = [&](const double* p_, int nblk, int j, double dflt) {
+            return p_ ? p_[((size_t)b * nblk + j) * RL + r] : dflt;
+        };
+        if (cX) {
+            const int j = s == 0 ? 0 : 1 + blk + (s - 1);
+            xlo = at(a.xmin, He + 1, j, -BIG); xhi = at(a.xmax, He + 1, j, BIG);
+            hxlo = xlo > -BIG; hxhi = xhi < BIG;
+        }
+        if (cW && s < N) {
+            wlo = at(a.wmin, He, blk + s, -BIG); whi = at(a.wmax, He, blk + s, BIG);
+            hwlo = wlo > -BIG; hwhi = whi < BIG;
+        }
+        const int im = meas_of(s);
+        if (cV && im >= 0) {
+            vlo = at(a.vmin, He, blk + im, -BIG); vhi = at(a.vmax, He, blk + im, BIG);
+            hvlo = vlo > -BIG; hvhi = vhi < BIG;
+        }
+    }
 
     // O(j) = Oc - D̃w(j) Â: sub-diagonal block (j+1, j) of the Newton matrix (D̃w(j) from the forward sweep of phase 0)
     MPCQP_HD void load_O(int j, Row& Ob) {
@@ -537,7 +571,7 @@ struct Solver {
             O::ldo(w.uniform(cbase + cm.Bmid), coff, RL, T); O::st(lds + (size_t)2 * NX * WAVE, WAVE, T);
 #endif
         }
-        auto bnd = [&](const double* p_, bool on, int n, double dflt) { return (on && p_ && r < n) ? p_[(size_t)b * RL + r] : dflt; };
+        auto bnd = [&](const double* p_, bool on, int n, double dflt) { return (on && p_ && r < n && !cL) ? p_[(size_t)b * RL + r] : dflt; };
         xlo = bnd(a.xmin, cX, nx, -BIG); xhi = bnd(a.xmax, cX, nx, BIG);
         wlo = bnd(a.wmin, cW, nx, -BIG); whi = bnd(a.wmax, cW, nx, BIG);
         vlo = bnd(a.vmin, cV, nym, -BIG); vhi = bnd(a.vmax, cV, nym, BIG);
@@ -559,6 +593,7 @@ struct Solver {
             Row T;
             double xc = xbar, gprev = 0.0;
             for (int s = 0; s <= N; ++s) {
+                stage_bounds(s);
                 const double gs = s < N ? g_of(s) : 0.0;
                 if (s < N) Sst(sm.G + s, gs);
                 double q = 0.0;
@@ -631,7 +666,8 @@ struct Solver {
 
         int st = 1, it = 0;
         bool done = false;
-        double laststep = 1e300, rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0, rpn = 0.0;
+        double laststep = 1e300, rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0, rpn = 0.0, rd_best = 1e300;
+        int nflat = 0;
 
         for (int pass = 0; pass < d.max_iter; ++pass) {
             double mu = 0.0, smu = 0.0, alpha = 1.0;
@@ -645,6 +681,7 @@ struct Solver {
                     double xm = 0.0, xc = Sld(sm.X + 0), tprev = 0.0, tpprev = 0.0;
                     double dd_carry = 0.0, gl_carry = 0.0, cr_carry = 0.0, ph_carry = 0.0;
                     auto stage = [&](int s, StageIn& in) {
+                        stage_bounds(s);
                         const double xp = in.x;
                         double gl = gl_carry, dd = dd_carry, cr = cr_carry, ph = ph_carry;
                         dd_carry = gl_carry = cr_carry = ph_carry = 0.0;
@@ -832,9 +869,15 @@ struct Solver {
                         if (!(mu == mu) || !(rdn == rdn)) { st = 2; done = true; }
                         const bool stalled = rdn >= 0.5 * rdn_prev && lastscale <= 0.1;
                         rdn_prev = rdn;
+                        // ... or it has not come below half of its best value for four iterations (at the floor the
+                        // directions are noise: the steps get short and the rule above, which asks for a nearly
+                        // full step, never fires -- a soft-bound family ran into the iteration limit that way)
+                        nflat = rdn >= 0.5 * rd_best ? nflat + 1 : 0;
+                        rd_best = fmin(rd_best, rdn);
+                        const bool flat = nflat >= 4;
                         const bool pstalled = rpn >= 0.5 * rpn_prev && lastscale <= 0.1 && rpn <= 1e-9 * nh;
                         rpn_prev = rpn;
-                        if (!done && mu <= d.gap_tol && (rdn <= d.res_tol * ndd || stalled) &&
+                        if (!done && mu <= d.gap_tol && (rdn <= d.res_tol * ndd || stalled || flat) &&
                             (rpn <= 10.0 * d.res_tol * nh || pstalled) && laststep <= 1e-6) { st = 0; done = true; }
                         if (!done && !ok) { st = 2; done = true; }
                     }
@@ -863,6 +906,7 @@ struct Solver {
                 };
                 // rows of stage s for the direction dx(s) (dxn = dx(s+1)); stores the ŵ / v̂ row directions
                 auto rows_stage = [&](int s, StageIn& in, double dx, double dxn) {
+                    stage_bounds(s);
                     if (cX) rows2(hxlo, hxhi, in.xr, in.x, xlo, xhi, in.dxa, dx, cx0, cx1, delta);
                     if (cW && s < N) {
                         Row A;
@@ -971,6 +1015,7 @@ struct Solver {
                     }
                 };
                 auto stage = [&](int s, StageIn& in) {
+                    stage_bounds(s);
                     const double xc = in.x, dx = in.a0;
                     if (cX) upd2(hxlo, hxhi, sm.XR + 4 * s, in.xr, xc, xlo, xhi, in.dxa, dx, cx0, cx1, delta);
                     if (cW && s < N) upd2(hwlo, hwhi, sm.WR + 4 * s, in.wr, in.ww, wlo, whi, in.wga, in.wg, cw0, cw1, delta_w);

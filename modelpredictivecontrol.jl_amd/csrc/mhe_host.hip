@@ -30,6 +30,7 @@ struct mpcqp_mhe_s {
     double *lastu = nullptr, *P0 = nullptr, *Pout = nullptr;
     double* raw_own[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device copies of set_model's arrays
     double* bnd[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* bndw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // window-long bound arrays (CLS_L)
     double* sft[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* Cwt = nullptr;
     bool soft = false;       // finite Cwt: a slack variable exists
@@ -128,7 +129,9 @@ int mpcqp_mhe_create(const mpcqp_mhe_dims* in, mpcqp_mhe* out) {
     d.max_iter = in->max_iter > 0 ? in->max_iter : 80;
     d.gap_tol = in->gap_tol > 0 ? in->gap_tol : 1e-12;
     d.res_tol = in->res_tol > 0 ? in->res_tol : 1e-11;
-    d.dual_reg = in->dual_reg > 0 ? in->dual_reg : 1e-12;
+    // (dual regularisation: rows held at D~ = 1/δ; 1e-10 -- two soft-bound families of the randomised sweeps sat on the noise floor of
+    // the block recursion with 1e-12, errors 1e-5..7e-5 -- δ vanishes from the converged solution)
+    d.dual_reg = in->dual_reg > 0 ? in->dual_reg : 1e-10;
     d.nwaves = mhe::waves_for(in->device, d.B, d.NX);
     d.cst_stride = mhe::cst_map(d.NX, d.nu, d.nd).stride;
     d.opt = getenv("MPCQP_MHE_OPT") ? (uint32_t)atoi(getenv("MPCQP_MHE_OPT")) : 0u;
@@ -232,6 +235,44 @@ int mpcqp_mhe_set_bounds(mpcqp_mhe h, const double* xmin, const double* xmax, co
     return MPCQP_OK;
 }
 
+int mpcqp_mhe_set_bounds_window(mpcqp_mhe h, const double* Xmin, const double* Xmax, const double* Wmin, const double* Wmax,
+                                const double* Vmin, const double* Vmax) {
+    if (!h) return MPCQP_ERR_NULL;
+    ON_DEVICE(h);
+    mhe::Dims& d = h->d;
+    const double* src[6] = {Xmin, Xmax, Wmin, Wmax, Vmin, Vmax};
+    const int n[6] = {d.nx, d.nx, d.nx, d.nx, d.nym, d.nym};
+    const int nblk[6] = {d.He + 1, d.He + 1, d.He, d.He, d.He, d.He};
+    const uint32_t bit[6] = {mhe::CLS_X, mhe::CLS_X, mhe::CLS_W, mhe::CLS_W, mhe::CLS_V, mhe::CLS_V};
+    const double** dst[6] = {&h->a.xmin, &h->a.xmax, &h->a.wmin, &h->a.wmax, &h->a.vmin, &h->a.vmax};
+    uint32_t cls = 0;
+    for (int k = 0; k < 6; ++k) {
+        const bool lower = (k % 2) == 0;
+        bool any = false;
+        std::vector<double> buf((size_t)d.B * nblk[k] * mhe::RL);
+        for (size_t b = 0; b < (size_t)d.B; ++b)
+            for (int j = 0; j < nblk[k]; ++j)
+                for (int r = 0; r < mhe::RL; ++r) {
+                    double v = (src[k] && r < n[k]) ? src[k][(b * nblk[k] + j) * n[k] + r] : (lower ? -INFINITY : INFINITY);
+                    if (v != v) return MPCQP_ERR_ARG;
+                    if (std::isinf(v) || std::fabs(v) >= BIG) v = lower ? -BIG : BIG; else any = true;
+                    buf[(b * nblk[k] + j) * mhe::RL + r] = v;
+                }
+        if (any) {
+            if (!h->bndw[k]) { int rc = dalloc_t(h, &h->bndw[k], buf.size()); if (rc) return rc; }
+            int rc = up(h, h->bndw[k], buf.data(), buf.size());
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(h->stream));
+            *dst[k] = h->bndw[k];
+            cls |= bit[k];
+        } else {
+            *dst[k] = nullptr;
+        }
+    }
+    d.cls = cls | (d.cls & mhe::CLS_S) | mhe::CLS_L;
+    return MPCQP_OK;
+}
+
 int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin, const double* c_xmax, const double* c_wmin,
                            const double* c_wmax, const double* c_vmin, const double* c_vmax) {
     if (!h) return MPCQP_ERR_NULL;
@@ -314,6 +355,40 @@ int mpcqp_mhe_set_state(mpcqp_mhe h, const double* xhat0) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
+}
+
+int mpcqp_mhe_shift_windows(mpcqp_mhe h, const double* dy0m, const double* du0, const double* dd0, const double* dx0) {
+    if (!h) return MPCQP_ERR_NULL;
+    if (!h->have_init) return MPCQP_ERR_ORDER;
+    ON_DEVICE(h);
+    const mhe::Dims& d = h->d;
+    const size_t B = d.B;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // (a rare host-side operation: the windows come down, take the offsets and go back)
+    auto shift = [&](double* dev, size_t blocks, size_t n, const double* delta) -> int {
+        if (!delta || !dev || n == 0 || blocks == 0) return MPCQP_OK;
+        std::vector<double> w(B * blocks * n);
+        HIPCHK(hipMemcpy(w.data(), dev, w.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < B; ++b)
+            for (size_t j = 0; j < blocks; ++j)
+                for (size_t i = 0; i < n; ++i) w[(b * blocks + j) * n + i] += delta[b * n + i];
+        HIPCHK(hipMemcpy(dev, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+        return MPCQP_OK;
+    };
+    int rc = shift(h->a.Y0m, d.He, d.nym, dy0m);
+    if (!rc) rc = shift(h->a.U0, d.He, d.nu, du0);
+    if (!rc) rc = shift(h->lastu, 1, d.nu, du0);
+    if (!rc) rc = shift(h->a.D0, d.He + 1, d.nd, dd0);
+    if (!rc) rc = shift(h->a.X0old, d.He, d.nx, dx0);
+    if (!rc) rc = shift(h->a.xhat0, 1, d.nx, dx0);
+    if (!rc && h->a.Zt && dx0) {          // x̂0arr of the last solve (first nx̂ entries of Z̃ per estimator)
+        std::vector<double> z(B * (size_t)(d.nx + d.He * d.nx));
+        HIPCHK(hipMemcpy(z.data(), h->a.Zt, z.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < B; ++b)
+            for (int i = 0; i < d.nx; ++i) z[b * (size_t)(d.nx + d.He * d.nx) + i] += dx0[b * d.nx + i];
+        HIPCHK(hipMemcpy(h->a.Zt, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return rc;
 }
 
 int mpcqp_mhe_prepare_device(mpcqp_mhe h, const double* y0m_dev, const double* d0_dev) {

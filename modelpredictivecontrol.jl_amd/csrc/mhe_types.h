@@ -19,7 +19,8 @@ namespace mhe {
 
 constexpr int RL = 16;    // lanes per estimator: one DPP row
 constexpr int GPW = 4;    // estimators per wavefront
-enum { CLS_X = 1u, CLS_W = 2u, CLS_V = 4u, CLS_S = 8u };   // bound classes; CLS_S: a slack variable ε relaxes some rows
+enum { CLS_X = 1u, CLS_W = 2u, CLS_V = 4u, CLS_S = 8u, CLS_L = 16u };   // bound classes; CLS_S: a slack variable ε relaxes some rows;
+                                                                        // CLS_L: the bound arrays are window-long (one row per stage)
 
 struct Dims {
     int B, nx, nu, nym, nd, He;
@@ -88,7 +89,9 @@ struct Args {
     double* cst;                 // [B][cst_stride]
     double* P;                   // [B][NX*RL]  arrival covariance P̄ (row-lane)
     double* Pi2;                 // [B][NX*RL]  2 P̄⁻¹
-    const double *xmin, *xmax, *wmin, *wmax, *vmin, *vmax;   // [B][RL] per channel, |v| >= BIG: absent (null: class absent)
+    const double *xmin, *xmax, *wmin, *wmax, *vmin, *vmax;   // [B][RL] per channel, |v| >= BIG: absent (null: class absent);
+                                                             // with CLS_L: x [B][He+1][RL] (arrival state, then the window blocks
+                                                             // oldest first), w and v [B][He][RL]; a window of Nk < He uses the LAST Nk blocks
     const double *cxmin, *cxmax, *cwmin, *cwmax, *cvmin, *cvmax;   // [B][RL] softness c >= 0 of the rows (null: hard), CLS_S
     const double* Cwt;           // [B] weight of ε² (CLS_S)
     double* eps_out;             // [B] optimal slack ε (CLS_S)

@@ -822,7 +822,7 @@ static int self_test_spec_impl(mpcqp_handle h, double* worst, DBuf& yh, DBuf& in
 int mpcqp_prepare(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
     g_build_err.clear();
-    int kind = prepare_step(h->d, &g_build_err);
+    int kind = prepare_step(h->d, h->m, &g_build_err);
     // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
     // it with the runtime-dimension kernel once; needs the model and weights (BatchLinMPC prepares before its first step)
     const bool ondemand = kind == MPCQP_KERNEL_ONDEMAND || (kind == MPCQP_KERNEL_SMALL && step_kernel_kind_other(h->d) == MPCQP_KERNEL_ONDEMAND);
@@ -854,7 +854,7 @@ int mpcqp_lds_bytes(mpcqp_handle h) {
 
 int mpcqp_kernel_kind(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
-    return step_kernel_kind(h->d);
+    return step_kernel_kind(h->d, h->m);
 }
 
 int mpcqp_row_groups(mpcqp_handle h, uint32_t* row_groups) {

@@ -272,8 +272,8 @@ static bool aot_matches(const Dims& d) {
 
 // Which kernel a step of `d` runs on: 0 the runtime-dimension kernel, 1 an ahead-of-time
 // specialisation, 2 an on-demand one (already loaded or loadable from the cache).
-int step_kernel_kind(const Dims& d) {
-    if (!force_generic() && small_eligible(d, Model{}, StepIO{})) return 3;
+int step_kernel_kind(const Dims& d, const Model& m) {
+    if (!force_generic() && small_eligible(d, m, StepIO{})) return 3;
     return step_kernel_kind_other(d);
 }
 
@@ -301,10 +301,10 @@ static int prepare_step_other(const Dims& d, std::string* err) {
     return 0;
 }
 
-int prepare_step(const Dims& d, std::string* err) {
+int prepare_step(const Dims& d, const Model& m, std::string* err) {
     // (the kernel behind the small one is prepared as well: steps that ask for Ŷ or fuse the Kalman steps run on it)
     const int other = prepare_step_other(d, err);
-    return (!force_generic() && small_eligible(d, Model{}, StepIO{})) ? 3 : other;
+    return (!force_generic() && small_eligible(d, m, StepIO{})) ? 3 : other;
 }
 
 // compile only (no device, no load): for build pipelines

@@ -14,9 +14,9 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
 hipError_t launch_step_spec_or_aot(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);   // never the small-problem kernel
 size_t step_lds_bytes(const Dims& d);
 // kernel a step runs on: 0 runtime-dimension kernel, 1 ahead-of-time specialisation, 2 on-demand specialisation
-int step_kernel_kind(const Dims& d);
+int step_kernel_kind(const Dims& d, const Model& m);   // (m: the handle's arrays -- a block / dense M_Hp excludes the small-problem kernel)
 int step_kernel_kind_other(const Dims& d);   // ... of the steps the small-problem kernel (kind 3) does not take
-int prepare_step(const Dims& d, std::string* err);     // compile (if needed) + load; returns the kind
+int prepare_step(const Dims& d, const Model& m, std::string* err);     // compile (if needed) + load; returns the kind
 int prebuild_step(const Dims& d, std::string* err);    // compile only; -1 on failure
 // one-time check of an on-demand kernel against the runtime-dimension kernel (see mpcqp_prepare)
 bool spec_verified(const Dims& d);

@@ -19,7 +19,7 @@ import numpy as np
 from . import api
 from .api import MpcqpError, _chk, _f64, _ptr, colmajor
 
-EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_set_softness", "mpcqp_mhe_init", "mpcqp_mhe_set_state",
+EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_set_bounds_window", "mpcqp_mhe_set_softness", "mpcqp_mhe_init", "mpcqp_mhe_set_state", "mpcqp_mhe_shift_windows",
            "mpcqp_mhe_prepare", "mpcqp_mhe_update", "mpcqp_mhe_prepare_device", "mpcqp_mhe_update_device",
            "mpcqp_mhe_sync", "mpcqp_mhe_get", "mpcqp_mhe_device_ptr", "mpcqp_mhe_nk", "mpcqp_mhe_last_ms",
            "mpcqp_mhe_register_columns")
@@ -41,9 +41,11 @@ def _bind(lib):
     lib.mpcqp_mhe_destroy.argtypes = [C.c_void_p]
     lib.mpcqp_mhe_set_model.argtypes = [C.c_void_p] * 9
     lib.mpcqp_mhe_set_bounds.argtypes = [C.c_void_p] * 7
+    lib.mpcqp_mhe_set_bounds_window.argtypes = [C.c_void_p] * 7
     lib.mpcqp_mhe_set_softness.argtypes = [C.c_void_p] * 8
     lib.mpcqp_mhe_init.argtypes = [C.c_void_p] * 5
     lib.mpcqp_mhe_set_state.argtypes = [C.c_void_p] * 2
+    lib.mpcqp_mhe_shift_windows.argtypes = [C.c_void_p] * 5
     lib.mpcqp_mhe_prepare.argtypes = [C.c_void_p] * 3
     lib.mpcqp_mhe_update.argtypes = [C.c_void_p] * 4
     lib.mpcqp_mhe_prepare_device.argtypes = [C.c_void_p] * 3
@@ -93,6 +95,11 @@ class MheHandle:
         arrs = [None if a is None else _f64(a) for a in (xmin, xmax, wmin, wmax, vmin, vmax)]
         _chk(self.lib, self.lib.mpcqp_mhe_set_bounds(self._h, *[_ptr(a) for a in arrs]))
 
+    def set_bounds_window(self, Xmin=None, Xmax=None, Wmin=None, Wmax=None, Vmin=None, Vmax=None):
+        """Window-long bounds: (B, (He+1) nx̂) [arrival; window oldest first], (B, He nx̂), (B, He nym); None = absent."""
+        arrs = [None if a is None else _f64(a) for a in (Xmin, Xmax, Wmin, Wmax, Vmin, Vmax)]
+        _chk(self.lib, self.lib.mpcqp_mhe_set_bounds_window(self._h, *[_ptr(a) for a in arrs]))
+
     def set_softness(self, Cwt=None, c_xmin=None, c_xmax=None, c_wmin=None, c_wmax=None, c_vmin=None, c_vmax=None):
         """Cwt (B,) finite or None (= Inf, hard only); softness arrays (B, n) >= 0 or None."""
         arrs = [None if a is None else _f64(a) for a in (Cwt, c_xmin, c_xmax, c_wmin, c_wmax, c_vmin, c_vmax)]
@@ -105,6 +112,10 @@ class MheHandle:
 
     def set_state(self, xhat0):
         _chk(self.lib, self.lib.mpcqp_mhe_set_state(self._h, _ptr(_f64(xhat0))))
+
+    def shift_windows(self, dy0m=None, du0=None, dd0=None, dx0=None):
+        arrs = [None if a is None else _f64(a) for a in (dy0m, du0, dd0, dx0)]
+        _chk(self.lib, self.lib.mpcqp_mhe_shift_windows(self._h, *[_ptr(a) for a in arrs]))
 
     def _failed(self, rc):
         if rc < 0:
@@ -222,13 +233,16 @@ class BatchMHE:
     # -- setconstraint! (construct.jl:858-1049): per-channel hard bounds --------------------------------
     def setconstraint(self, *, x̂min=None, x̂max=None, ŵmin=None, ŵmax=None, v̂min=None, v̂max=None, c_x̂min=None, c_x̂max=None,
                       c_ŵmin=None, c_ŵmax=None, c_v̂min=None, c_v̂max=None, **other):
-        full = [k for k in other if k in ("X̂min", "X̂max", "Ŵmin", "Ŵmax", "V̂min", "V̂max", "C_x̂min", "C_x̂max", "C_ŵmin",
-                                          "C_ŵmax", "C_v̂min", "C_v̂max")]
+        full = [k for k in other if k in ("C_x̂min", "C_x̂max", "C_ŵmin", "C_ŵmax", "C_v̂min", "C_v̂max")]
         if full:
-            raise MpcqpError(f"window-long bound vectors {full} are not supported by this build")
+            raise MpcqpError(f"window-long softness vectors {full} are not supported by this build")
+        win = {k: other.pop(k) for k in ("X̂min", "X̂max", "Ŵmin", "Ŵmax", "V̂min", "V̂max") if k in other}
         if other:
             raise TypeError(f"unknown setconstraint keywords {sorted(other)}")
         B = self.B
+        if win or getattr(self, "_win", None):
+            self._setconstraint_window(win, dict(x̂min=x̂min, x̂max=x̂max, ŵmin=ŵmin, ŵmax=ŵmax, v̂min=v̂min, v̂max=v̂max))
+            x̂min = x̂max = ŵmin = ŵmax = v̂min = v̂max = None
         con = dict(self._con)              # (validated before it replaces the current set)
         for key, val, n, shift in (("xmin", x̂min, self.nx̂, self.x̂op), ("xmax", x̂max, self.nx̂, self.x̂op),
                                    ("wmin", ŵmin, self.nx̂, None), ("wmax", ŵmax, self.nx̂, None),
@@ -244,7 +258,8 @@ class BatchMHE:
             if lo in con and hi in con and np.any(con[lo] > con[hi]):
                 raise ValueError(f"{lo} > {hi}: infeasible bounds")
         self._con = con
-        self.handle.set_bounds(**self._con)
+        if not getattr(self, "_win", None):
+            self.handle.set_bounds(**self._con)
         # softness parameters (construct.jl:960-1020): nonnegative, and only with a finite Cwt
         for key, val, n in (("c_xmin", c_x̂min, self.nx̂), ("c_xmax", c_x̂max, self.nx̂), ("c_wmin", c_ŵmin, self.nx̂),
                             ("c_wmax", c_ŵmax, self.nx̂), ("c_vmin", c_v̂min, self.nym), ("c_vmax", c_v̂max, self.nym)):
@@ -262,6 +277,35 @@ class BatchMHE:
             self.handle.set_softness(np.full(B, self.Cwt), **self._soft)
         return self
 
+    def _setconstraint_window(self, win, chan):
+        """Window-long bounds X̂min ... V̂max (construct.jl:858-935): (n (He+1),) / (n He,) vectors (or (B, .)), a bound per
+        channel and stage; a per-channel keyword given in the same or a later call fills its whole vector like the
+        reference does.  Once a window-long vector has been given the estimator stays on window-long bounds."""
+        B, nx, nym, He = self.B, self.nx̂, self.nym, self.He
+        cur = dict(getattr(self, "_win", None) or {})
+        spec = {"X̂min": (nx, He + 1, -np.inf, "x̂min", "xmin"), "X̂max": (nx, He + 1, np.inf, "x̂max", "xmax"),
+                "Ŵmin": (nx, He, -np.inf, "ŵmin", "wmin"), "Ŵmax": (nx, He, np.inf, "ŵmax", "wmax"),
+                "V̂min": (nym, He, -np.inf, "v̂min", "vmin"), "V̂max": (nym, He, np.inf, "v̂max", "vmax")}
+        for K, (n, nblk, dflt, k, old) in spec.items():
+            shift = np.tile(self.x̂op, (1, nblk)) if K[0] == "X" else 0.0
+            if K in win and win[K] is not None:
+                v = np.asarray(win[K], float)
+                if v.shape not in ((n * nblk,), (B, n * nblk)):
+                    raise ValueError(f"{K} size {v.shape} ≠ ({n * nblk},)")                 # DimensionMismatch
+                cur[K] = np.broadcast_to(v, (B, n * nblk)) - shift
+            elif chan.get(k) is not None:
+                v = np.asarray(chan[k], float)
+                if v.shape not in ((n,), (B, n)):
+                    raise ValueError(f"{k} size {v.shape} ≠ ({n},) or ({B}, {n})")
+                cur[K] = np.tile(np.broadcast_to(v, (B, n)), (1, nblk)) - shift
+            elif K not in cur:          # first window-long call: start from the per-channel bounds in force
+                cur[K] = np.tile(self._con[old], (1, nblk)) if old in self._con else np.full((B, n * nblk), dflt)
+        for lo, hi in (("X̂min", "X̂max"), ("Ŵmin", "Ŵmax"), ("V̂min", "V̂max")):
+            if np.any(cur[lo] > cur[hi]):
+                raise ValueError(f"{lo} > {hi}: infeasible bounds")
+        self._win = cur
+        self.handle.set_bounds_window(cur["X̂min"], cur["X̂max"], cur["Ŵmin"], cur["Ŵmax"], cur["V̂min"], cur["V̂max"])
+
     def setstate(self, x̂, P̂=None):
         """setstate!(estim, x̂) (src/estimator/execute.jl:424-429): only the current estimate changes; the data windows
         and the arrival covariance stay.  A covariance is an error, as in the reference (mhe/execute.jl:938-941)."""
@@ -272,6 +316,45 @@ class BatchMHE:
             raise ValueError(f"x̂ size must be ({self.nx̂},)")
         self.x̂0 = np.broadcast_to(x, (self.B, self.nx̂)) - self.x̂op
         self.handle.set_state(self.x̂0)
+        return self
+
+    def setmodel(self, Ahat=None, Bhu=None, Chm=None, Bhd=None, Dhdm=None, *, uop=None, yop_m=None, dop=None, x̂op=None,
+                 f̂op=None, Q̂=None, R̂=None):
+        """setmodel!(estim, model; Q̂, R̂) (src/estimator/execute.jl:483-497, mhe/execute.jl:943-1046): new augmented model
+        matrices and / or operating points and / or covariances.  The data windows, lastu0, x̂0, x̂0arr and the x̂ bounds
+        are deviation variables: they keep their ENGINEERING values, i.e. move by (old − new) operating point."""
+        B, nx = self.B, self.nx̂
+        z = lambda v, n, old: old if v is None else np.broadcast_to(np.asarray(v, float), (B, n)).copy()
+        uop, yop_m, dop = z(uop, self.nu, self.uop), z(yop_m, self.nym, self.yop_m), z(dop, self.nd, self.dop)
+        xop, fop = z(x̂op, nx, self.x̂op), z(f̂op, nx, self.f̂op)
+        for M, n, name in ((Q̂, nx, "Q̂"), (R̂, self.nym, "R̂")):
+            if M is not None:
+                M = np.asarray(M, float)
+                if M.shape != (B, n, n):
+                    raise ValueError(f"{name} size {M.shape} ≠ ({B}, {n}, {n})")
+                if np.any(np.linalg.eigvalsh(M) <= 0):
+                    raise MpcqpError(f"{name} is not positive definite")
+        pick = lambda new, old: old if new is None else np.asarray(new, float)
+        self._Ahat, self._Bhu, self._Chm = pick(Ahat, self._Ahat), pick(Bhu, self._Bhu), pick(Chm, self._Chm)
+        self._Bhd, self._Dhdm = pick(Bhd, self._Bhd), pick(Dhdm, self._Dhdm)
+        self.Q̂, self.R̂ = pick(Q̂, self.Q̂), pick(R̂, self.R̂)
+        dx = self.x̂op - xop
+        self.handle.shift_windows(self.yop_m - yop_m, (self.uop - uop) if self.nu else None,
+                                  (self.dop - dop) if self.nd else None, dx)
+        self.x̂0 = self.x̂0 + dx
+        self.uop, self.yop_m, self.dop, self.x̂op, self.f̂op = uop, yop_m, dop, xop, fop
+        self.handle.set_model(self._Ahat, self._Bhu if self.nu else None, self._Chm, self._Bhd if self.nd else None,
+                              self._Dhdm if self.nd else None, self.f̂op - self.x̂op, self.Q̂, self.R̂)
+        for k in ("xmin", "xmax"):                   # x̂ bounds: same engineering values, new deviation values
+            if k in self._con:
+                self._con[k] = self._con[k] + dx
+        if getattr(self, "_win", None):
+            for K in ("X̂min", "X̂max"):
+                self._win[K] = self._win[K] + np.tile(dx, (1, self.He + 1))
+            w = self._win
+            self.handle.set_bounds_window(w["X̂min"], w["X̂max"], w["Ŵmin"], w["Ŵmax"], w["V̂min"], w["V̂max"])
+        elif self._con:
+            self.handle.set_bounds(**self._con)
         return self
 
     def initstate(self, x̂, u=None, d=None):

@@ -209,12 +209,44 @@ class MHEOracle:
         self.lastu0 = u0.copy()
         return x
 
+    def setmodel(self, model):
+        """setmodel!(estim, model) -- src/estimator/execute.jl:483-497 + setmodel_estimator! (mhe/execute.jl:943-1046):
+        new LinModel (same dimensions), augmented matrices and prediction matrices rebuilt, every deviation variable
+        (windows, lastu0, x̂0, x̂0arr, x̂ bounds) moved from the old to the new operating points."""
+        old, c = self.model, self.cov
+        uop_old, yop_old, dop_old, xhop_old = old.uop.copy(), old.yop.copy(), old.dop.copy(), self.xhop.copy()
+        kf = make_kalman_filter(model, direct=self.direct, nint_ym=[0] * self.nym if self.nxh == model.nx else None)
+        assert kf.nxh == self.nxh, "setmodel: the stochastic model (integrators) must stay the same"
+        kf.Q, kf.R, kf.P0 = c.Q, c.R, c.P0
+        self.model, self.cov = model, kf
+        self.Ah, self.Bhu, self.Ch, self.Bhd, self.Dhd = kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd
+        self.Chm, self.Dhdm, self.xhop, self.fhop = kf.Chm, kf.Dhdm, kf.xhop, kf.fhop
+        (self.E, self.G, self.J, self.B, self.exbar, self.EX, self.GX, self.JX, self.BX) = init_predmat_mhe(
+            self.Ah, self.Bhu, self.Chm, self.Bhd, self.Dhdm, self.xhop, self.fhop, self.He, self.direct)
+        nx, nu, nd, nym, He = self.nxh, self.nu, self.nd, self.nym, self.He
+        dx = xhop_old - self.xhop
+        self.x0 = self.x0 + dx
+        for k in ("x0min", "x0max"):
+            self.con[k] = self.con[k] + dx
+        for k in ("X0min", "X0max"):
+            self.con[k] = self.con[k] + np.tile(dx, He)
+        self.Y0m = self.Y0m + np.tile(yop_old[self.i_ym] - model.yop[self.i_ym], He)
+        self.U0 = self.U0 + np.tile(uop_old - model.uop, He)
+        if nd:
+            self.D0 = self.D0 + np.tile(dop_old - model.dop, He + 1)
+        self.X0_old = self.X0_old + np.tile(dx, He)
+        self.lastu0 = self.lastu0 + (uop_old - model.uop)
+        self.Zt[self.neps:self.neps + nx] += dx
+        self.x0arr_old = self.x0arr_old + dx
+        return self
+
     def setstate(self, xhat):
         self.x0 = np.asarray(xhat, float) - self.xhop
         return self
 
     def setconstraint(self, xhatmin=None, xhatmax=None, whatmin=None, whatmax=None, vhatmin=None, vhatmax=None,
-                      c_xhatmin=None, c_xhatmax=None, c_whatmin=None, c_whatmax=None, c_vhatmin=None, c_vhatmax=None):
+                      c_xhatmin=None, c_xhatmax=None, c_whatmin=None, c_whatmax=None, c_vhatmin=None, c_vhatmax=None,
+                      Xhatmin=None, Xhatmax=None, Whatmin=None, Whatmax=None, Vhatmin=None, Vhatmax=None):
         """setconstraint! -- construct.jl:858-1049 (per-channel bounds repeated over the window; the
         arrival state takes the same x̂ bounds)."""
         He, nx = self.He, self.nxh
@@ -227,6 +259,17 @@ class MHEOracle:
         for key, v in (("Wmin", whatmin), ("Wmax", whatmax), ("Vmin", vhatmin), ("Vmax", vhatmax)):
             if v is not None:
                 self.con[key] = np.tile(np.asarray(v, float), He)
+        # window-long vectors (construct.jl:890-935): X̂ = [arrival; the He window states], Ŵ and V̂ He blocks
+        for k0, k1, v in (("x0min", "X0min", Xhatmin), ("x0max", "X0max", Xhatmax)):
+            if v is not None:
+                v = np.asarray(v, float)
+                assert v.shape == (nx * (He + 1),)
+                self.con[k0], self.con[k1] = v[:nx] - self.xhop, v[nx:] - np.tile(self.xhop, He)
+        for key, v, n in (("Wmin", Whatmin, nx), ("Wmax", Whatmax, nx), ("Vmin", Vhatmin, self.nym), ("Vmax", Vhatmax, self.nym)):
+            if v is not None:
+                v = np.asarray(v, float)
+                assert v.shape == (n * He,)
+                self.con[key] = v.copy()
         for k0, k1, v in (("c_x0min", "C_xmin", c_xhatmin), ("c_x0max", "C_xmax", c_xhatmax)):
             if v is not None:
                 self.soft[k0], self.soft[k1] = np.asarray(v, float).copy(), np.tile(np.asarray(v, float), He)

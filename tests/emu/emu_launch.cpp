@@ -167,9 +167,9 @@ hipError_t launch_kf_predict(const Dims& d, const Model& m, double* xhat0, const
     return hipSuccess;
 }
 // (the emulator has no on-demand kernels: every shape it was not compiled for runs the runtime-dims body)
-int step_kernel_kind(const Dims& d) { return small_eligible(d, Model{}, StepIO{}) ? 3 : 0; }
+int step_kernel_kind(const Dims& d, const Model& m) { return small_eligible(d, m, StepIO{}) ? 3 : 0; }
 int step_kernel_kind_other(const Dims&) { return 0; }
-int prepare_step(const Dims& d, std::string*) { return small_eligible(d, Model{}, StepIO{}) ? 3 : 0; }
+int prepare_step(const Dims& d, const Model& m, std::string*) { return small_eligible(d, m, StepIO{}) ? 3 : 0; }
 int prebuild_step(const Dims&, std::string*) { return 0; }
 bool spec_verified(const Dims&) { return true; }
 void mark_spec_verified(const Dims&) {}

@@ -219,7 +219,136 @@ def reference_unfilled_window(direct, lib=None, B=2, oracle=False):
     return float(np.abs(yhat() - x).max())
 
 
-def random_family(seed, lib=None, B=5):
+def reference_setmodel(lib=None, B=2, oracle=False):
+    """"MHE set model" of the reference (test/2_test_state_estim.jl:1668-1718): He = 5, nint_ym = 0, predictor form,
+    x̂ ∈ [-1000, 1000]; setmodel! with a new Â and new (uop, yop), then new (xop, fop); a second estimator goes through
+    setmodel! + initstate!.  Returns {label: (value, expected)} from the product (or from the oracle)."""
+    def lin(a, b, uop, yop, xop, fop):
+        return es.LinModelOracle(np.array([[a]]), np.array([[b]]), np.array([[1.0]]), np.zeros((1, 0)), np.zeros((1, 0)),
+                                 Ts=10.0).setop(uop=[uop], yop=[yop], xop=[xop], fop=[fop])
+    rep = lambda M: np.repeat(np.asarray(M, float)[None], B, 0)
+
+    def product_of(e, model):
+        bm = pm.BatchMHE(rep(e.Ah), rep(e.Bhu), rep(e.Chm), He=5, Q̂=rep(e.Q), R̂=rep(e.R), P̂_0=rep(e.cov.P0), direct=False,
+                         uop=model.uop, yop_m=model.yop[e.i_ym], x̂op=e.xhop, f̂op=e.fhop, lib=lib)
+        return bm
+
+    def product_setmodel(bm, e, model):
+        bm.setmodel(rep(e.Ah), rep(e.Bhu), rep(e.Chm), uop=model.uop, yop_m=model.yop[e.i_ym], x̂op=e.xhop, f̂op=e.fhop)
+
+    out = {}
+    m1 = lin(0.5, 0.3, 2.0, 50.0, 3.0, 3.0)
+    e = om.MHEOracle(m1, He=5, direct=False, nint_ym=[0])
+    e.setconstraint(xhatmin=[-1000], xhatmax=[1000])
+    bm = None
+    if not oracle:
+        bm = product_of(e, m1)
+        bm.setconstraint(x̂min=[-1000], x̂max=[1000])
+    first = lambda v: float(np.asarray(v).ravel()[0])
+    # (the oracle goes through every period too: it provides the augmented matrices of setmodel! and the comparison values)
+    def step(u, y):
+        xo = first(e.updatestate(u, y))
+        return xo if oracle else first(bm.updatestate(u, y))
+
+    def prep(y):
+        xo = first(e.preparestate(y))
+        return xo if oracle else first(bm.preparestate(y))
+    prep([50.0])
+    out["x̂ after the first period"] = (step([2.0], [50.0]), 3.0)
+    m2 = lin(0.2, 0.3, 3.0, 55.0, 3.0, 3.0)
+    e.setmodel(m2)
+    if not oracle:
+        product_setmodel(bm, e, m2)
+        out["ŷ after setmodel!"] = (first(e.Ch @ bm.x̂0[0] + m2.yop), 55.0)
+    else:
+        out["ŷ after setmodel!"] = (first(e.evaloutput()), 55.0)
+        out["lastu0"] = (first(e.lastu0), -1.0)
+        out["U0[1]"] = (first(e.U0), -1.0)
+        out["Y0m[1]"] = (first(e.Y0m), -5.0)
+    out["x̂ with the new model"] = (prep([55.0]), 3.0)
+    m3 = lin(0.2, 0.3, 3.0, 55.0, 8.0, 8.0)
+    e.setmodel(m3)
+    if not oracle:
+        product_setmodel(bm, e, m3)
+        out["x̂0 after the new operating point"] = (first(bm.x̂0), -5.0)
+        out["x̂0min"] = (first(bm._con["xmin"]), -1008.0)
+        # the estimator keeps working on the shifted windows: product against oracle over three more periods
+        for k in range(3):
+            xg = step([3.0 + 0.1 * k], [55.0 + 0.2 * k])
+            out[f"x̂ period {k} after setmodel!"] = (xg, first(e.x0 + e.xhop))
+    else:
+        out["x̂0 after the new operating point"] = (first(e.x0), -5.0)
+        out["X̂0_old[1]"] = (first(e.X0_old), -5.0)
+        out["x̂0arr_old"] = (first(e.x0arr_old), -5.0)
+        out["X̂0min"] = (first(e.con["X0min"]), -1008.0)
+    # second estimator: setmodel! followed by initstate!
+    m4 = lin(0.5, 0.3, 2.0, 50.0, 3.0, 3.0)
+    e2 = om.MHEOracle(m4, He=5, direct=False, nint_ym=[0])
+    m5 = lin(0.5, 0.9, 3.0, 55.0, 8.0, 8.0)
+    if oracle:
+        out["x̂ (second estimator)"] = (first(e2.updatestate([3.0], [50.0])), 3.3)
+        e2.setmodel(m5)
+        e2.initstate([3.0], [55.0])
+        out["x̂ after setmodel! + initstate!"] = (first(e2.updatestate([4.0], [55.0])), 8.9)
+    else:
+        b2 = product_of(e2, m4)
+        out["x̂ (second estimator)"] = (first(b2.updatestate([3.0], [50.0])), 3.3)
+        e2.setmodel(m5)
+        product_setmodel(b2, e2, m5)
+        x_init = e2.initstate([3.0], [55.0])
+        b2.initstate(x_init, u=[3.0])
+        out["x̂ after setmodel! + initstate!"] = (first(b2.updatestate([4.0], [55.0])), 8.9)
+    return out
+
+
+def window_long_bounds(lib=None, B=3, seed=21, soft=False, nper=9):
+    """setconstraint!(estim; X̂min, ..., V̂max): a bound per channel AND stage (construct.jl:858-935), product against
+    oracle over a growing and then moving window.  Returns the worst relative errors (x̂, Ŵ) and the number of periods in
+    which some stage bound of the oracle's optimum was active."""
+    cfg = synth.MheConfig("winlong", nx=3, nu=1, nym=2, nd=0, He=5, **({"Cwt": 1e4} if soft else {}))
+    bt = synth.make_mhe_batch(cfg, B, seed=seed)
+    Y, U, D = synth.make_mhe_data(cfg, bt, nper, seed=seed)
+    rng = np.random.default_rng(seed)
+    nx, nym, He = cfg.nxh, cfg.nym, cfg.He
+    # stage-dependent boxes: tight on some stages, absent (Inf) on others
+    Xw = rng.uniform(0.3, 1.5, nx * (He + 1)); Xw[rng.random(Xw.size) < 0.3] = np.inf
+    Ww = rng.uniform(0.05, 0.4, nx * He); Ww[rng.random(Ww.size) < 0.3] = np.inf
+    Vw = rng.uniform(0.2, 0.8, nym * He); Vw[rng.random(Vw.size) < 0.3] = np.inf
+    bm = make_product(cfg, bt, lib=lib, bounds={})
+    ors = make_oracles(cfg, bt, list(range(B)), bounds={})
+    if soft:
+        bm.setconstraint(c_x̂max=np.full(nx, 0.5), c_v̂min=np.ones(nym))
+        for e in ors:
+            e.setconstraint(c_xhatmax=np.full(nx, 0.5), c_vhatmin=np.ones(nym))
+    bm.setconstraint(X̂min=-Xw, X̂max=Xw, Ŵmin=-Ww, Ŵmax=Ww, V̂min=-Vw, V̂max=Vw)
+    for e in ors:
+        e.setconstraint(Xhatmin=-Xw, Xhatmax=Xw, Whatmin=-Ww, Whatmax=Ww, Vhatmin=-Vw, Vhatmax=Vw)
+    ex = ew = 0.0
+    active = 0
+    for k in range(nper):
+        xg = bm.preparestate(Y[k])
+        xo = np.array([e.preparestate(Y[k][b]) for b, e in enumerate(ors)])
+        if not cfg.direct:
+            xg = bm.updatestate(U[k], Y[k])
+            xo = np.array([e.updatestate(U[k][b], Y[k][b]) for b, e in enumerate(ors)])
+        info = bm.getinfo()
+        assert np.all(info["status"] == 0) and all(e.status == 0 for e in ors), k
+        Nk = info["Nk"]
+        Wo = np.array([e.Zt[e.neps + nx:e.neps + nx + Nk * nx] for e in ors])
+        sc = max(1.0, np.abs(xo).max())
+        ex = max(ex, np.abs(xg - xo).max() / sc)
+        ew = max(ew, np.abs(info["Ŵ"] - Wo).max() / sc)
+        for e in ors:
+            Xb = Xw[nx:][(He - Nk) * nx:]
+            active += int(np.any(np.abs(np.abs(e.X0[:Nk * nx]) - Xb) <= 1e-6) or np.any(np.abs(np.abs(Wo) - Ww[(He - Nk) * nx:]) <= 1e-6))
+        if cfg.direct:
+            bm.updatestate(U[k], Y[k])
+            for b, e in enumerate(ors):
+                e.updatestate(U[k][b], Y[k][b])
+    return ex, ew, active
+
+
+def random_family(seed, lib=None, B=5, **solver):
     """One randomised MovingHorizonEstimator family (dimensions, form, horizon, bound classes, hard / soft) driven
     through He + 3 periods on the product and on oracle/mhe.py, every member compared.  Returns (worst relative
     error over the periods where the oracle's QP was solved, number of compared solves, failures seen)."""
@@ -248,7 +377,7 @@ def random_family(seed, lib=None, B=5):
                 bounds["c_" + key + "max"] = np.where(rng.random(n) < 0.6, rng.uniform(0.2, 1.5, n), 0.0)
     nper = cfg.He + 3
     Y, U, D = synth.make_mhe_data(cfg, bt, nper, seed=seed)
-    bm = make_product(cfg, bt, lib=lib, bounds=bounds)
+    bm = make_product(cfg, bt, lib=lib, bounds=bounds, **solver)
     ors = make_oracles(cfg, bt, range(B), bounds=bounds)
     clean = np.ones(B, bool)
     worst, ncmp, nfail = 0.0, 0, 0

@@ -257,3 +257,18 @@ def test_reference_constraint_violation_through_the_product(soft):
 def test_reference_unfilled_window_through_the_product(direct):
     """"MHE estimation with unfilled window", test/2_test_state_estim.jl:1313-1337 (atol 1e-6 there)."""
     assert mhe_util.reference_unfilled_window(direct, B=3) <= 1e-6
+
+
+@pytest.mark.parametrize("soft", [False, True], ids=["hard", "soft"])
+def test_window_long_bounds(soft):
+    """setconstraint!(estim; X̂min, ..., V̂max) (construct.jl:858-935): a bound per channel and stage; a window that is
+    not full uses the last Nk blocks."""
+    ex, ew, active = mhe_util.window_long_bounds(B=6, soft=soft, nper=10)
+    assert active > 0
+    assert ex <= TOL and ew <= TOL, (ex, ew)
+
+
+def test_reference_setmodel_through_the_product():
+    """setmodel!(::MovingHorizonEstimator, model), test/2_test_state_estim.jl:1668-1718."""
+    for k, (v, want) in mhe_util.reference_setmodel(B=3).items():
+        assert abs(v - want) <= 1e-3 * max(1.0, abs(want)), (k, v, want)

@@ -186,3 +186,17 @@ def test_setstate_keeps_windows_and_arrival_covariance(emulib):
             assert bm.handle.Nk == Nk and np.array_equal(bm.handle.get(pm.GET_PBAR), Pb)
             with pytest.raises(mpcqp.MpcqpError):
                 bm.setstate(xnew, P̂=np.eye(cfg.nxh))
+
+
+def test_window_long_bounds_on_emulator(emulib):
+    """setconstraint!(estim; X̂min, ..., V̂max): stage-dependent bounds, growing then moving window, against the oracle."""
+    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=2, nper=7)
+    assert active > 0
+    assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
+
+
+def test_reference_setmodel_through_the_product_on_emulator(emulib):
+    """setmodel!(::MovingHorizonEstimator, model), test/2_test_state_estim.jl:1668-1718, through BatchMHE.setmodel
+    (mpcqp_mhe_set_model + mpcqp_mhe_shift_windows)."""
+    for k, (v, want) in mhe_util.reference_setmodel(lib=emulib, B=1).items():
+        assert abs(v - want) <= 1e-3 * max(1.0, abs(want)), (k, v, want)

@@ -106,3 +106,10 @@ def test_reference_unfilled_window(direct):
     """test/2_test_state_estim.jl:1313-1337 on the oracle (atol 1e-6 in the reference)."""
     from tests import mhe_util
     assert mhe_util.reference_unfilled_window(direct, oracle=True) <= 1e-9
+
+
+def test_reference_setmodel_known_answers():
+    """"MHE set model", test/2_test_state_estim.jl:1668-1718, on the oracle (atol 1e-3 for the estimates there)."""
+    from tests import mhe_util
+    for k, (v, want) in mhe_util.reference_setmodel(oracle=True).items():
+        assert abs(v - want) <= 1e-3 * max(1.0, abs(want)), (k, v, want)
