@@ -57,6 +57,12 @@
 #ifndef MPCQP_SOLVE_DPP
 #define MPCQP_SOLVE_DPP 1         // triangular solves of the specialised kernels blocked by DPP rows (Step::solve_static)
 #endif
+#ifndef MPCQP_POLISH_MU
+#define MPCQP_POLISH_MU 1e-6      // complementarity gap at which the first polish attempt is made (then every factor 100)
+#endif
+#ifndef MPCQP_POLISH_RP
+#define MPCQP_POLISH_RP 1e-6      // ... and the relative primal residual it needs
+#endif
 #ifndef MPCQP_ETAPPLY_NB
 #define MPCQP_ETAPPLY_NB 3        // steps per (double-buffered) batch of E'w
 #endif
@@ -2399,7 +2405,11 @@ struct Step {
                 const bool last = rpa <= 1e-13 * nh && !retry;
                 apply_Gt([&](Row& r) { return last ? r.pp : r.rp * fma(rho, r.gd, r.pp); });
                 double rdn2, ndd2;
-                dual_residual(m.Hpk + (size_t)b * d.npk, rdn2, ndd2);
+                {
+                    MPCQP_TIC();
+                    dual_residual(m.Hpk + (size_t)b * d.npk, rdn2, ndd2);
+                    MPCQP_TOC(2);
+                }
                 if (!(rdn2 == rdn2)) break;
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_DEBUG_POLISH)
                 if (w.lane == 0) printf("  polish b=%d fact %d round %d rpa %.3e (nh %.2e) rdn %.3e ndd %.3e last %d\n", b, fact, round, rpa, nh, rdn2, ndd2, (int)last);
@@ -2588,7 +2598,7 @@ struct Step {
         double step_c = 1e300, zabs_c = 0.0;                     // |alpha dU_k|, |dU_k| of this lane's entry
         double rd_exact_prev = 1e300, scale_since_exact = 1.0;   // stall detection of the exact dual residual
         bool rd_stalled = false, rp_stalled = false;
-        double polmu_next = 1e-6;
+        double polmu_next = MPCQP_POLISH_MU;
         int npolish = 0;
         bool polished = false;
         double rpn_last = 1e300;
@@ -2650,9 +2660,12 @@ struct Step {
             }
             // Active-set polish once the gap is small: first at mu <= 1e-6, again after every further
             // factor 100 if it was not accepted (wrong active set: weakly active or degenerate rows).
-            if (mu <= polmu_next && rpn <= 1e-6 * nh && npolish < MPCQP_POLISH_BUDGET && !(d.flags & 16u)) {
+            if (mu <= polmu_next && rpn <= MPCQP_POLISH_RP * nh && npolish < MPCQP_POLISH_BUDGET && !(d.flags & 16u)) {
                 polmu_next = 1e-2 * mu;
-                if (polish(npolish)) { polished = true; status = ST_OPTIMAL; break; }
+                const long long tic14_ = clock64_();
+                const bool pol_ok = polish(npolish);
+                prof_[14] += (double)(clock64_() - tic14_);
+                if (pol_ok) { polished = true; status = ST_OPTIMAL; break; }
                 exact = true;                      // Phi, rd, gt were used: start over from exact residuals
                 continue;
             }
@@ -2701,6 +2714,7 @@ struct Step {
             // neighbourhood min_i s_i lam_i >= 0.01 mu, otherwise 0.99.  (An unguarded 0.999 jams
             // about one instance in 20000; with the guard no instance of 65536 needs more
             // iterations than with 0.99 throughout and the mean drops by about 0.9.)
+            const long long tic13_ = clock64_();
             amin = rcp(w.maxv(tmax));
             const double ahi = fmin(1.0, 0.9999 * amin);
             double pmin = 1e300, psum = 0.0;
@@ -2732,6 +2746,7 @@ struct Step {
                 rd[k] *= (1.0 - alpha);
             }
             w.sync();
+            prof_[13] += (double)(clock64_() - tic13_);
             ++it;
         }
         // never primal-feasible (or NaN) => the reference's error branch (execute.jl:484-489)

@@ -16,7 +16,8 @@ out = np.empty((B, 16));
 import ctypes as C
 mpcqp.api._chk(lib, lib.mpcqp_get(mpc.hd.h, 99, out.ctypes.data_as(C.c_void_p)))
 names = ["apply_G", "apply_Gt", "loadH+Hz", "GtDG rows", "EtDE(mfma)", "GtDG struct", "cholesky", "solve", "", "", "", "", "", "", "", "run total"]
-sub = {8: "  Gt: rows+reduce", 9: "  Gt: box/U/eps part", 10: "  Gt: Et_apply", 11: "  G: ucum", 12: "  G: E_apply"}
+sub = {8: "  Gt: rows+reduce", 9: "  Gt: box/U/eps part", 10: "  Gt: Et_apply", 11: "  G: ucum", 12: "  G: E_apply",
+       13: "  step rule + update pass", 14: "  polish (all of it)"}
 it = mpc.iters.mean() + 1
 tot = out[:, 15].mean()
 print(f"{name} B={B} kernel {mpc.hd.last_step_ms():.2f} ms, mean iters {mpc.iters.mean():.2f}; mean cycles per wave: {tot:.0f} ({tot/it:.0f} per iteration)")
