@@ -22,6 +22,8 @@
 #pragma once
 #include <math.h>
 
+#include <type_traits>
+
 #include "mpcqp_types.h"
 
 #if defined(MPCQP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -192,6 +194,14 @@ struct Carve {
     int total;                 // doubles
 };
 
+// compile-time dims with one Newton-system row per lane (nZ~ <= 64): the register / DPP-row forms of the factorisation,
+// the solves and the polish apply; larger compile-time problems share the several-rows-per-lane code of the runtime dims
+template <class DM>
+MPCQP_HD constexpr bool one_row_per_lane() {
+    if constexpr (DM::is_static) return DM::nZ <= WAVE;
+    else return false;
+}
+
 template <class DM>
 MPCQP_HD inline int stride_S(const DM& d) {
     if constexpr (DM::is_static) return DM::sp;
@@ -223,7 +233,7 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     c.gt = take(d.nZ); c.rd = take(d.nZ);
     c.dinv = take(d.nZ > WAVE ? d.nZ : 0);        // 1/L[k][k] of the several-rows-per-lane factorisation
     c.xh = take(d.nxh);                           // x̂0 of this period (corrected in place by the fused Kalman step)
-    c.zb = take(DM::is_static ? 0 : d.nZ);        // iterate kept while the polish runs (a register with compile-time dims)
+    c.zb = take((DM::is_static && d.nZ <= WAVE) ? 0 : d.nZ);   // iterate kept while the polish runs (a register with compile-time dims, nZ~ <= 64)
     c.zlo = c.dz; c.zhi = c.gt;                   // only live while the rows are being set up
     c.F = -1;                                     // placed below (aliases the Ŷ-row scratch when it exists)
     MPCQP_UNROLL
@@ -546,6 +556,14 @@ struct Qp {
     // Hg != nullptr: P is OVERWRITTEN with Hg (packed H̃ in global memory) + scale * E'DE on the whole stored
     // triangle (ϵ row and its diagonal included) instead of being updated in place -- no staging of H̃ in LDS and
     // no read-modify-write of the tiles; the H̃ entries are fetched in the accumulator layout before the K loop.
+    // passes of EtDE_add_mfma over the tile rows: {0, 1} together, then one row per pass
+    template <int I0, int NT, class F>
+    static __device__ __forceinline__ void etde_passes(F& f) {
+        if constexpr (I0 < NT) {
+            f(std::integral_constant<int, I0>{});
+            etde_passes<(I0 == 0 ? 2 : I0 + 1), NT>(f);
+        }
+    }
     __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb,
                                                  const double* Hg = nullptr) {
         MPCQP_RELANE(2);
@@ -571,10 +589,12 @@ struct Qp {
         // first block column (E is block lower triangular).
         constexpr int IE = NDU / 16, LE = NDU % 16;     // tile row / lane column of the ϵ row
         int eps_t0 = -1;
-        MPCQP_UNROLL
-        for (int I0 = 0; I0 < NT; I0 += (I0 == 0 ? 2 : 1)) {
+        // (one instantiation per pass: with the pass index a run-time value -- a loop the compiler declines to unroll at
+        // seven tile rows -- the accumulator arrays are indexed dynamically and end up in scratch memory)
+        auto pass = [&](auto I0c) {
+            constexpr int I0 = decltype(I0c)::value;
             constexpr int MAXT = NT + 1;
-            const int I1 = (I0 == 0 && NT > 1) ? 1 : I0;              // last tile row of the pass
+            constexpr int I1 = (I0 == 0 && NT > 1) ? 1 : I0;          // last tile row of the pass
             v4d acc[2][MAXT];
             MPCQP_UNROLL
             for (int x = 0; x < 2; ++x) {
@@ -693,7 +713,7 @@ struct Qp {
                                 P[entry_idx(I, J, reg)] = fma(scale, acc[I - I0][J][reg], hreg[I - I0][J][reg]);
                     }
                 }
-                continue;
+                return;
             }
             // write-back: every lane does an unconditional read-modify-write; entries outside the
             // stored triangle go to the trash slot (no exec-masked region per entry, so the reads of
@@ -714,7 +734,8 @@ struct Qp {
                     for (int reg = 0; reg < 4; ++reg) *pp_[reg] = fma(scale, acc[I - I0][J][reg], old_[reg]);
                 }
             }
-        }
+        };
+        etde_passes<0, NT>(pass);
         if (Hg && DM::neps && w.lane == 0) P[pk(NDU, NDU)] = Hg[pk(NDU, NDU)];     // Ñ's slack weight (construct.jl:842)
         return eps_t0;
     }
@@ -1906,9 +1927,7 @@ struct Step {
     // Pivot guard: a non-positive pivot (float64 breakdown of the normal equations) freezes that
     // coordinate for this Newton step (zero column, 1/L = 1e-32) instead of poisoning the factor.
     MPCQP_HD void cholesky() {
-        if constexpr (!DM::is_static) {
-            if (d.nZ > WAVE) { cholesky_big(); return; }
-        }
+        if (d.nZ > WAVE) { cholesky_big(); return; }      // (a compile-time branch with compile-time dims)
         MPCQP_RELANE(8);
         MPCQP_TIC();
         const int n = d.nZ;
@@ -1921,7 +1940,7 @@ struct Step {
         myinvd = 0.0;
         constexpr int CB = 4;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (DM::is_static) {
+        if constexpr (one_row_per_lane<DM>()) {
 #if MPCQP_CHOL_REDUNDANT
             if (act) dz[i] = thr;                 // read back four at a time by chol_static (dz is free here)
             w.sync();
@@ -1942,7 +1961,7 @@ struct Step {
             const bool mine = act && i >= k0;
             int j0 = 0;                                  // first column the sweep below has to cover
 #if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (DM::is_static) {
+            if constexpr (one_row_per_lane<DM>()) {
                 if (k0 == 16) chol_panel_update<1>();
                 else if (k0 == 32) chol_panel_update<2>();
                 else if (k0 == 48) chol_panel_update<3>();
@@ -2128,12 +2147,10 @@ struct Step {
     // v_mul -> v_readlane -> v_fma per column.
     MPCQP_HD void solve_into_dz() {
         MPCQP_RELANE(4);
-        if constexpr (!DM::is_static) {
-            if (d.nZ > WAVE) { solve_big(); return; }
-        }
+        if (d.nZ > WAVE) { solve_big(); return; }
         MPCQP_TIC();
 #if defined(__HIP_DEVICE_COMPILE__) && MPCQP_SOLVE_DPP
-        if constexpr (DM::is_static) {
+        if constexpr (one_row_per_lane<DM>()) {
             solve_static();
             MPCQP_TOC(7);
             return;
@@ -2222,19 +2239,20 @@ struct Step {
     // chain) and stores Phi[i][k] - dot; the owner of row k turns its entry into 1/L[k][k] (LDS vector
     // dinv, same pivot guard as cholesky()), then the column is scaled.  The factor is stored
     // strictly below the diagonal.
-    MPCQP_HD void cholesky_big() {
-        MPCQP_TIC();
+    // columns kb .. ke-1, the dot products over the columns j0 .. k-1 (j0 a multiple of four; the columns before j0 have
+    // been accounted for by chol_panel_update)
+    MPCQP_HD void chol_big_columns(int kb, int ke, int j0, bool& broke) {
         const int n = d.nZ;
         double* dinv = sm + c.dinv;
-        bool broke = false;
         MPCQP_NOUNROLL
-        for (int k = 0; k < n; ++k) {
+        for (int k = kb; k < ke; ++k) {
             const double* Lk = Phi + pk(k, 0);
             const int k4 = k & ~3;
             for (int i = w.lane + ((k - w.lane + WAVE - 1) / WAVE) * WAVE; i < n; i += WAVE) {   // first owned row >= k
                 const double* Li = Phi + pk(i, 0);
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                for (int j = 0; j < k4; j += 4) {
+                MPCQP_UNROLL4
+                for (int j = j0; j < k4; j += 4) {
                     double x[4], y[4];
                     load4(Li + j, x); load4(Lk + j, y);
                     a0 = fma(x[0], y[0], a0); a1 = fma(x[1], y[1], a1);
@@ -2246,7 +2264,7 @@ struct Step {
                 if (i == k) {
                     const bool ok = v > 1e-14 * fabs(orig);
                     broke = broke || !ok;
-                    dinv[k] = ok ? 1.0 / sqrt(v) : 0.0;
+                    dinv[k] = ok ? rsqrt_(v) : 0.0;
                 } else {
                     Phi[pk(i, k)] = v;
                 }
@@ -2257,6 +2275,30 @@ struct Step {
             w.sync();
             if (w.lane == 0) dinv[k] = fmax(idl, 1e-32);
         }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // compile-time dims: 16-column panels; the contribution of the finished panels to a panel's columns is removed on the
+    // matrix cores (chol_panel_update: every row tile below, one v_mfma_f64_16x16x4 per four finished columns), the
+    // left-looking dot products then only run inside the panel (at most 15 terms instead of up to nZ~)
+    template <int P>
+    __device__ __forceinline__ void chol_big_panels(bool& broke) {
+        constexpr int n = DM::nZ, K0 = 16 * P, K1 = (K0 + 16 < n) ? K0 + 16 : n;
+        if constexpr (K0 < n) {
+            if constexpr (P > 0) chol_panel_update<P>();
+            chol_big_columns(K0, K1, K0, broke);
+            chol_big_panels<P + 1>(broke);
+        }
+    }
+#endif
+    MPCQP_HD void cholesky_big() {
+        MPCQP_TIC();
+        bool broke = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) chol_big_panels<0>(broke);
+        else chol_big_columns(0, d.nZ, 0, broke);
+#else
+        chol_big_columns(0, d.nZ, 0, broke);
+#endif
         w.sync();
         chol_broke = w.any(broke);
         MPCQP_TOC(6);
@@ -2366,7 +2408,8 @@ struct Step {
         const double rho = 1e10;
         double zkeep = 0.0;                       // compile-time dims: nZ <= 64, one entry per lane
         double* const zb = sm + c.zb;
-        if constexpr (DM::is_static) zkeep = (w.lane < n) ? z[w.lane] : 0.0;
+        constexpr bool ZREG = one_row_per_lane<DM>();      // one entry per lane: the kept iterate is a register
+        if constexpr (ZREG) zkeep = (w.lane < n) ? z[w.lane] : 0.0;
         else
             for (int k = w.lane; k < n; k += WAVE) zb[k] = z[k];
         for_rows([&](int, int, Row& r) {
@@ -2468,7 +2511,7 @@ struct Step {
                     if (r.gd < -1e-13 * nh) { r.rp = 0.0; r.pp = 0.0; chg = true; }
                     else r.pp = r.lam;
                 });
-                if constexpr (DM::is_static) { if (w.lane < n) z[w.lane] = zkeep; }
+                if constexpr (ZREG) { if (w.lane < n) z[w.lane] = zkeep; }
                 else
                     for (int k = w.lane; k < n; k += WAVE) z[k] = zb[k];
                 w.sync();
@@ -2487,7 +2530,7 @@ struct Step {
             if (!changed) break;              // converged (ok) or failed without a new working set
         }
         if (!ok) {
-            if constexpr (DM::is_static) { if (w.lane < n) z[w.lane] = zkeep; }
+            if constexpr (ZREG) { if (w.lane < n) z[w.lane] = zkeep; }
             else
                 for (int k = w.lane; k < n; k += WAVE) z[k] = zb[k];
             w.sync();

@@ -166,8 +166,14 @@ static bool jit_enabled() {
     return on;
 }
 
-static bool spec_eligible(const Dims& d) {     // (custom linear constraints and nZ~ > 64 run on the runtime-dims kernel)
-    return d.nw == 0 && d.nZ <= WAVE && !d.dense_w;
+// (custom linear constraints and dense weights run on the runtime-dims kernel; compile-time dims up to MPCQP_SPEC_NZMAX:
+// beyond one row per lane the specialisation keeps the several-rows-per-lane factorisation of the runtime dims but has
+// the matrix-core E'DE, register rows and constant trip counts)
+#ifndef MPCQP_SPEC_NZMAX
+#define MPCQP_SPEC_NZMAX 128
+#endif
+static bool spec_eligible(const Dims& d) {
+    return d.nw == 0 && d.nZ <= MPCQP_SPEC_NZMAX && !d.dense_w;
 }
 
 // run `argv` (argv[0] = binary), stdout+stderr appended to `log`; returns the exit status, -1 on failure to start
@@ -211,6 +217,9 @@ static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
     const std::string tmp = so + ".tmp" + std::to_string((long)getpid());   // (ranks of one job may build the same object)
     std::vector<std::string> argv = {hipcc_path(), "--offload-arch=gfx950", "-O3",
                                      "-std=c++17", "-shared", "-fPIC", "-w", "-I" + src, dims};
+    // beyond one row per lane the LDS footprint (Phi alone is 47 KB at nZ~ = 106) leaves at most one wavefront per SIMD:
+    // the kernel may as well use the whole register file (row state of several rows per lane in registers, no spills)
+    if (d.nZ > WAVE) argv.push_back("-DMPCQP_STEP_WAVES=1");
     if (const char* extra = getenv("MPCQP_JIT_FLAGS")) {
         std::string tok;
         for (const char* c = extra;; ++c) {
