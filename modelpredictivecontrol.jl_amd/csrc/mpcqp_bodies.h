@@ -2265,6 +2265,7 @@ struct Step {
                     const bool ok = v > 1e-14 * fabs(orig);
                     broke = broke || !ok;
                     dinv[k] = ok ? rsqrt_(v) : 0.0;
+                    Phi[pk(i, k)] = 0.0;         // (zero diagonal slot, like the one-row-per-lane factor: solve_big_static)
                 } else {
                     Phi[pk(i, k)] = v;
                 }
@@ -2280,13 +2281,70 @@ struct Step {
     // compile-time dims: 16-column panels; the contribution of the finished panels to a panel's columns is removed on the
     // matrix cores (chol_panel_update: every row tile below, one v_mfma_f64_16x16x4 per four finished columns), the
     // left-looking dot products then only run inside the panel (at most 15 terms instead of up to nZ~)
-    template <int P>
-    __device__ __forceinline__ void chol_big_panels(bool& broke) {
-        constexpr int n = DM::nZ, K0 = 16 * P, K1 = (K0 + 16 < n) ? K0 + 16 : n;
+    // The 16 columns of a panel, factored in registers: lane l holds the panel entries of its rows l, l + 64, .. (16
+    // doubles per row); the pivot row of column k = 16P + c lives in slot (16P)/64, lane (16P)%64 + c -- compile-time
+    // constants -- so the column step is chol_static's: reciprocal square root of the lane's own entry, v_readlane
+    // broadcasts of the pivot lane's, one multiply-add per later column and row slot.  No LDS round trip and no fence
+    // inside the panel (the column-at-a-time loop of the runtime dims needs two fences and several dependent LDS reads
+    // per column).  thr: pivot thresholds of the lane's rows (1e-14 of the original diagonal).
+    template <int P, int NS>
+    __device__ __forceinline__ void chol_big_panel_reg(const double (&thr)[NS], bool& broke) {
+        constexpr int n = DM::nZ, K0 = 16 * P, KC = (n - K0 < 16) ? n - K0 : 16, NCH = (KC + 3) / 4;
+        constexpr int so = K0 / WAVE, lb = K0 % WAVE;
+        const double* zero4 = sm + c.zero;
+        double* dinv = sm + c.dinv;
+        double v[NS][16];
+        bool mine[NS];
+        int rowo[NS];
+        MPCQP_UNROLL
+        for (int s_ = so; s_ < NS; ++s_) {
+            const int i = w.lane + WAVE * s_;
+            mine[s_] = i < n && i >= K0;
+            rowo[s_] = pk(mine[s_] ? i : 0, 0) + K0;
+            MPCQP_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                if (u < NCH) load4((mine[s_] && i >= K0 + 4 * u) ? Phi + rowo[s_] + 4 * u : zero4, &v[s_][4 * u]);
+                else { v[s_][4 * u] = v[s_][4 * u + 1] = v[s_][4 * u + 2] = v[s_][4 * u + 3] = 0.0; }
+            }
+        }
+        double mydinv = 0.0;
+        MPCQP_UNROLL
+        for (int cc = 0; cc < KC; ++cc) {
+            const double piv = v[so][cc];
+            const double idl = (piv > thr[so]) ? rsqrt_(piv) : 0.0;       // lane lb + cc: 1/sqrt(pivot), 0 if bad
+            const double idb = w.bcast(idl, lb + cc);
+            mydinv = (w.lane == lb + cc) ? idl : mydinv;
+            MPCQP_UNROLL
+            for (int s_ = so; s_ < NS; ++s_) v[s_][cc] *= idb;            // rows below the pivot: L[i][k]
+            MPCQP_UNROLL
+            for (int c2 = cc + 1; c2 < KC; ++c2) {
+                const double bv = w.bcast(v[so][cc], lb + c2);            // L[K0 + c2][k]
+                MPCQP_UNROLL
+                for (int s_ = so; s_ < NS; ++s_) v[s_][c2] = fma(-v[s_][cc], bv, v[s_][c2]);
+            }
+        }
+        // rows of the panel itself keep zeros on and right of the diagonal; stores only where the row is that long
+        MPCQP_UNROLL
+        for (int cc = 0; cc < KC; ++cc) v[so][cc] = (w.lane > lb + cc) ? v[so][cc] : 0.0;
+        MPCQP_UNROLL
+        for (int s_ = so; s_ < NS; ++s_) {
+            const int i = w.lane + WAVE * s_;
+            MPCQP_UNROLL
+            for (int u = 0; u < NCH; ++u)
+                if (mine[s_] && i >= K0 + 4 * u) store4(Phi + rowo[s_] + 4 * u, &v[s_][4 * u]);
+        }
+        const bool own = w.lane >= lb && w.lane < lb + KC;
+        if (own) dinv[K0 + w.lane - lb] = fmx(mydinv, 1e-32);
+        broke = broke || (own && mydinv <= 1e-32);
+        w.sync();
+    }
+    template <int P, int NS>
+    __device__ __forceinline__ void chol_big_panels(const double (&thr)[NS], bool& broke) {
+        constexpr int n = DM::nZ, K0 = 16 * P;
         if constexpr (K0 < n) {
             if constexpr (P > 0) chol_panel_update<P>();
-            chol_big_columns(K0, K1, K0, broke);
-            chol_big_panels<P + 1>(broke);
+            chol_big_panel_reg<P, NS>(thr, broke);
+            chol_big_panels<P + 1, NS>(thr, broke);
         }
     }
 #endif
@@ -2294,8 +2352,18 @@ struct Step {
         MPCQP_TIC();
         bool broke = false;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (DM::is_static) chol_big_panels<0>(broke);
-        else chol_big_columns(0, d.nZ, 0, broke);
+        if constexpr (DM::is_static) {
+            constexpr int NS = (DM::nZ + WAVE - 1) / WAVE;
+            double thr[NS];
+            MPCQP_UNROLL
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const int i = w.lane + WAVE * s_;
+                thr[s_] = i < DM::nZ ? 1e-14 * fabs(Phi[pk(i, i)]) : 1.0;
+            }
+            chol_big_panels<0, NS>(thr, broke);
+        } else {
+            chol_big_columns(0, d.nZ, 0, broke);
+        }
 #else
         chol_big_columns(0, d.nZ, 0, broke);
 #endif
@@ -2305,8 +2373,92 @@ struct Step {
     }
 
     // dz <- Phi^{-1} gt with the factor of cholesky_big(): column sweeps on the LDS vector dz
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Compile-time dims, nZ~ > 64: the rows lane, lane + 64, .. of the right-hand side stay in registers and the
+    // substitutions run like solve_into_dz's -- chunks of four columns, the lane's own factor entries (forward: its row,
+    // backward: the column read along the rows of a four-row group) scaled by its 1/L_ii, v_readlane broadcasts of the
+    // four unknowns -- instead of one LDS round trip (vector dz) and two fences per column.
+    __device__ __forceinline__ void solve_big_static() {
+        constexpr int n = DM::nZ, NS = (n + WAVE - 1) / WAVE;
+        const double* dinv = sm + c.dinv;
+        const double* zero4 = sm + c.zero;
+        double r[NS], di[NS];
+        int rowo[NS];
+        bool act[NS];
+        MPCQP_UNROLL
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int i = w.lane + WAVE * s_;
+            act[s_] = i < n;
+            rowo[s_] = pk(act[s_] ? i : 0, 0);
+            di[s_] = act[s_] ? dinv[i] : 0.0;
+            r[s_] = (act[s_] ? gt[i] : 0.0) * di[s_];
+        }
+        // L y = r in the variable scaled by 1/L_ii
+        MPCQP_UNROLL
+        for (int so = 0; so < NS; ++so) {
+            const int nch = (((n - WAVE * so < WAVE) ? n - WAVE * so : WAVE) + 3) / 4;
+            _Pragma("unroll 2")
+            for (int g = 0; g < nch; ++g) {
+                const int k0 = WAVE * so + 4 * g;
+                double x[NS][4];
+                MPCQP_UNROLL
+                for (int s_ = so; s_ < NS; ++s_) {
+                    const int i = w.lane + WAVE * s_;
+                    load4((act[s_] && i >= k0) ? Phi + rowo[s_] + k0 : zero4, x[s_]);
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 4; ++u) x[s_][u] *= di[s_];
+                }
+                MPCQP_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const double bv = w.bcast(r[so], 4 * g + u);
+                    MPCQP_UNROLL
+                    for (int s_ = so; s_ < NS; ++s_) r[s_] = fma(-x[s_][u], bv, r[s_]);
+                }
+            }
+        }
+        // L'x = y
+        MPCQP_UNROLL
+        for (int s_ = 0; s_ < NS; ++s_) r[s_] *= di[s_];
+        MPCQP_UNROLL
+        for (int so = NS - 1; so >= 0; --so) {
+            const int nch = (((n - WAVE * so < WAVE) ? n - WAVE * so : WAVE) + 3) / 4;
+            _Pragma("unroll 2")
+            for (int g = nch - 1; g >= 0; --g) {
+                const int k0 = WAVE * so + 4 * g;
+                const double* pg = Phi + pk(k0, 0);
+                double x[NS][4];
+                MPCQP_UNROLL
+                for (int s_ = 0; s_ <= so; ++s_) {
+                    const int i = w.lane + WAVE * s_;
+                    const bool on = act[s_] && i < k0 + 4;        // (beyond the stored rows: column 0, scaled by zero)
+                    const double sc = on ? di[s_] : 0.0;
+                    const double* p_ = pg + (i < k0 + 4 ? i : 0);
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 4; ++u) x[s_][u] = (k0 + u < n) ? p_[u * (k0 + 4)] * sc : 0.0;
+                }
+                MPCQP_UNROLL
+                for (int u = 3; u >= 0; --u) {
+                    const double bv = w.bcast(r[so], 4 * g + u);
+                    MPCQP_UNROLL
+                    for (int s_ = 0; s_ <= so; ++s_) r[s_] = fma(-x[s_][u], bv, r[s_]);
+                }
+            }
+        }
+        MPCQP_UNROLL
+        for (int s_ = 0; s_ < NS; ++s_)
+            if (act[s_]) dz[w.lane + WAVE * s_] = r[s_];
+        w.sync();
+    }
+#endif
     MPCQP_HD void solve_big() {
         MPCQP_TIC();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) {
+            solve_big_static();
+            MPCQP_TOC(7);
+            return;
+        }
+#endif
         const int n = d.nZ;
         const double* dinv = sm + c.dinv;
         for (int i = w.lane; i < n; i += WAVE) dz[i] = gt[i];

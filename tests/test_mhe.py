@@ -72,8 +72,10 @@ def test_batchmhe_argument_checks(emulib):
         bm.setconstraint(c_x̂min=np.ones(4))
     with pytest.raises(ValueError, match="non-negative"):
         pm.BatchMHE(*args, He=3, Cwt=1e3, lib=emulib).setconstraint(c_v̂max=[-1.0, 0.0])
-    with pytest.raises(mpcqp.MpcqpError, match="window-long"):
-        bm.setconstraint(X̂min=np.zeros(16))
+    with pytest.raises(mpcqp.MpcqpError, match="window-long softness"):
+        bm.setconstraint(C_x̂min=np.zeros(16))
+    with pytest.raises(ValueError, match="size"):
+        bm.setconstraint(X̂min=np.zeros(12))                     # nx̂ (He + 1) = 16
     with pytest.raises(ValueError, match="ym size"):
         bm.preparestate(np.zeros(3))
     # more than 16 augmented states: one estimator no longer fits a DPP row
