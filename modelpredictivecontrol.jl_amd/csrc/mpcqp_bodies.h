@@ -65,6 +65,9 @@
 #ifndef MPCQP_POLISH_RP
 #define MPCQP_POLISH_RP 1e-6      // ... and the relative primal residual it needs
 #endif
+#ifndef MPCQP_EAPPLY44_HCMAX
+#define MPCQP_EAPPLY44_HCMAX 10   // longer control horizons take the general form of E v (the row-load form spills there)
+#endif
 #ifndef MPCQP_ETAPPLY_NB
 #define MPCQP_ETAPPLY_NB 3        // steps per (double-buffered) batch of E'w
 #endif
@@ -426,7 +429,7 @@ struct Qp {
         MPCQP_RELANE(0);
         const int ny = d.ny, nu = d.nu;
         if constexpr (DM::is_static) {
-            if (DM::nu == 4 && DM::nY <= 2 * WAVE && d.default_nb) {
+            if (DM::nu == 4 && DM::nY <= 2 * WAVE && DM::Hc <= MPCQP_EAPPLY44_HCMAX && d.default_nb) {
                 // every lane owns rows r0 = lane and r1 = lane + 64: the (wave-uniform) v[j,:]
                 // loads are shared by both rows; a block column j > t reads a zero block (zpad)
                 const int r0 = w.lane, r1 = w.lane + WAVE;
@@ -453,6 +456,39 @@ struct Qp {
                 return;
             }
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) {
+            if (DM::zpad > 0 && d.default_nb) {
+                // any nu, ny with the zero-padded table: every block column for every row (no lane-dependent trip
+                // count), the wave-uniform v[j,:] loads shared by the lane's rows r = lane, lane + 64, ..
+                constexpr int NR = (DM::nY + WAVE - 1) / WAVE;
+                const double* Sa[NR];
+                double acc[NR][2];
+                MPCQP_UNROLL
+                for (int q_ = 0; q_ < NR; ++q_) {
+                    const int r = w.lane + WAVE * q_;
+                    const int rr = r < DM::nY ? r : 0;
+                    Sa[q_] = S + (rr / DM::ny) * DM::sp + (rr % DM::ny) * DM::rs;
+                    acc[q_][0] = acc[q_][1] = 0.0;
+                }
+                _Pragma("unroll 4")
+                for (int j = 0; j < DM::Hc; ++j) {
+                    MPCQP_UNROLL
+                    for (int cc = 0; cc < DM::nu; ++cc) {
+                        const double vv = v[j * DM::nu + cc];
+                        MPCQP_UNROLL
+                        for (int q_ = 0; q_ < NR; ++q_) acc[q_][cc & 1] = fma(Sa[q_][cc - j * DM::sp], vv, acc[q_][cc & 1]);
+                    }
+                }
+                MPCQP_UNROLL
+                for (int q_ = 0; q_ < NR; ++q_) {
+                    const int r = w.lane + WAVE * q_;
+                    if (r < DM::nY) out[r] = acc[q_][0] + acc[q_][1];
+                }
+                return;
+            }
+        }
+#endif
         for (int r = w.lane; r < d.nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
             double acc0 = 0.0;
@@ -517,6 +553,40 @@ struct Qp {
                 return;
             }
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DM::is_static) {
+            if (DM::zpad > 0 && d.default_nb) {
+                // any nu, ny with the zero-padded table: no select on t >= j, the wave-uniform w[t,:] loads shared by the
+                // lane's columns k = lane, lane + 64, ..
+                constexpr int NQ = (DM::nDU + WAVE - 1) / WAVE;
+                const double* Sk[NQ];
+                double acc[NQ][2];
+                MPCQP_UNROLL
+                for (int q_ = 0; q_ < NQ; ++q_) {
+                    const int k = w.lane + WAVE * q_;
+                    const int kk = k < DM::nDU ? k : 0;
+                    Sk[q_] = S - (kk / DM::nu) * DM::sp + (kk % DM::nu);
+                    acc[q_][0] = acc[q_][1] = 0.0;
+                }
+                _Pragma("unroll 4")
+                for (int t = 0; t < DM::Hp; ++t) {
+                    if (t >= t_hi) break;
+                    MPCQP_UNROLL
+                    for (int a = 0; a < DM::ny; ++a) {
+                        const double wt = wv[t * DM::ny + a];
+                        MPCQP_UNROLL
+                        for (int q_ = 0; q_ < NQ; ++q_) acc[q_][a & 1] = fma(Sk[q_][t * DM::sp + a * DM::rs], wt, acc[q_][a & 1]);
+                    }
+                }
+                MPCQP_UNROLL
+                for (int q_ = 0; q_ < NQ; ++q_) {
+                    const int k = w.lane + WAVE * q_;
+                    if (k < DM::nDU) out[k] += scale * (acc[q_][0] + acc[q_][1]);
+                }
+                return;
+            }
+        }
+#endif
         for (int k = w.lane; k < d.nDU; k += WAVE) {
             const int j = k / nu, cc = k - j * nu, t0 = jl(j);
             const double* Sk = S + cc;
