@@ -73,6 +73,29 @@ class MpcqpError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so.7 /
+    libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm/lib, RPATH $ORIGIN); the dynamic loader keeps
+    whichever copy is mapped first.  If this library pulls in /opt/rocm's copy first, a later
+    `import torch` binds to it and reports "No HIP GPUs are available" (torch 2.10+rocm7.0 against
+    the 7.2 runtime).  When torch is installed but not imported yet, map its copy first so that both
+    orders of import give the same process image as `import torch; import mpcqp`.
+    MPCQP_SYSTEM_HIP=1 keeps the system runtime (a process that never imports torch)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("MPCQP_SYSTEM_HIP") == "1":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
 def load_library(path: str | None = None):
     """Load (once) the HIP shared library.  `path` is for tests only."""
     global _lib
@@ -84,6 +107,7 @@ def load_library(path: str | None = None):
             f"{path} not found: the HIP extension is not built (run `python -c 'import "
             f"__graft_entry__ as g; g.build()'` or `make -C modelpredictivecontrol.jl_amd/csrc`). "
             "There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     lib.mpcqp_version.restype = C.c_char_p
     lib.mpcqp_strerror.restype = C.c_char_p
