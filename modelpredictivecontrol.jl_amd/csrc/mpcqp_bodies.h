@@ -68,6 +68,11 @@
 #ifndef MPCQP_EAPPLY44_HCMAX
 #define MPCQP_EAPPLY44_HCMAX 10   // longer control horizons take the general form of E v (the row-load form spills there)
 #endif
+#ifndef MPCQP_EV_UNROLL
+#define MPCQP_EV_UNROLL 4         // block columns / steps per unrolled pass of the general E v and E'w forms
+#endif
+#define MPCQP_PRAGMA_(x) _Pragma(#x)
+#define MPCQP_PRAGMA(x) MPCQP_PRAGMA_(x)
 #ifndef MPCQP_ETAPPLY_NB
 #define MPCQP_ETAPPLY_NB 3        // steps per (double-buffered) batch of E'w
 #endif
@@ -471,7 +476,7 @@ struct Qp {
                     Sa[q_] = S + (rr / DM::ny) * DM::sp + (rr % DM::ny) * DM::rs;
                     acc[q_][0] = acc[q_][1] = 0.0;
                 }
-                _Pragma("unroll 4")
+                MPCQP_PRAGMA(unroll MPCQP_EV_UNROLL)
                 for (int j = 0; j < DM::Hc; ++j) {
                     MPCQP_UNROLL
                     for (int cc = 0; cc < DM::nu; ++cc) {
@@ -568,7 +573,7 @@ struct Qp {
                     Sk[q_] = S - (kk / DM::nu) * DM::sp + (kk % DM::nu);
                     acc[q_][0] = acc[q_][1] = 0.0;
                 }
-                _Pragma("unroll 4")
+                MPCQP_PRAGMA(unroll MPCQP_EV_UNROLL)
                 for (int t = 0; t < DM::Hp; ++t) {
                     if (t >= t_hi) break;
                     MPCQP_UNROLL
