@@ -269,7 +269,11 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
  *   mpcqp_row_groups   the handle's pattern of constraint groups (bit g: group g may hold finite rows;
  *                      0 box lower [eps >= 0, hard dUmin], 1 box upper, 2 Umin, 3 Umax, 4 soft dUmin,
  *                      5 soft dUmax, 6 Ymin, 7 Ymax, 8 xhat-min, 9 xhat-max, 10 Wmin, 11 Wmax).
- *   mpcqp_prebuild     compile-only (no GPU, no handle): for build pipelines; dims->batch is ignored.
+ *   mpcqp_prebuild     compile-only (no GPU, no handle): for build pipelines; dims->batch is ignored.  Returns the
+ *                      MPCQP_KERNEL_* kind of the shape (>= 0) or a negative error code.  The package ships a manifest
+ *                      of shapes (spec_manifest.txt: `nu ny nxhat Hp Hc neps row_groups`) that its build and
+ *                      `python -m mpcqp.prebuild [manifest]` turn into cached objects, so that a machine without
+ *                      hipcc still runs a declared set of shapes on specialised kernels.
  *   mpcqp_last_build_error  text of the last failed build of this thread.
  * Environment: MPCQP_CACHE_DIR (default: <library dir>/spec_cache if writable, else
  * $XDG_CACHE_HOME/mpcqp or ~/.cache/mpcqp), HIPCC (compiler binary), MPCQP_JIT=0 (never specialise). */

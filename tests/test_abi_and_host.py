@@ -358,3 +358,26 @@ def test_small_problem_kernel_on_cpu_emulator(emulib):
     worst, kinds = small_kernel_cases(lib=emulib, B=4)          # one wavefront per case
     assert worst <= 1e-6, worst
     assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
+
+
+def test_prebuild_manifest_is_read_and_built_without_a_gpu(tmp_path):
+    """spec_manifest.txt -> mpcqp_prebuild: the objects a machine without hipcc would load (the smallest shape is
+    compiled here; hipcc cross-compiles without a GPU), under the file name mpcqp_prepare looks for."""
+    from mpcqp import prebuild as pb
+    shapes = pb.read_manifest()
+    assert (3, 2, 7, 12, 4, 1, 0xCF) in shapes and all(len(s) == 7 for s in shapes)
+    bad = tmp_path / "m.txt"
+    bad.write_text("3 2 7 12 4 1\n")
+    with pytest.raises(ValueError):
+        pb.read_manifest(str(bad))
+    cache = tmp_path / "cache"
+    cache.mkdir(mode=0o700)
+    env = dict(os.environ, MPCQP_CACHE_DIR=str(cache))
+    one = tmp_path / "one.txt"
+    one.write_text("# smallest line of the shipped manifest\n3 2 7 12 4 1 cf\n")
+    out = subprocess.run([os.sys.executable, "-m", "mpcqp.prebuild", str(one)], env=env, capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "specialisation in the cache" in out.stdout
+    objs = [f for f in os.listdir(cache) if f.endswith("_3_2_7_12_4_1_cf_1.so")]
+    assert len(objs) == 1 and re.match(r"spec_r\d+_c[0-9a-f]+_", objs[0])
