@@ -233,6 +233,9 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     Carve c{};
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };   // keep 16-B alignment
+#ifdef MPCQP_LDS_FRONT_PAD
+    (void)take(MPCQP_LDS_FRONT_PAD);      // (experiment of DESIGN 4 "out-of-line members": nothing within 4 KB of LDS offset 0)
+#endif
     c.S = take((d.Hp + zpad_S(d)) * stride_S(d));   // zero blocks first (StaticDims::zpad)
     c.Phi = take(d.npk);
     c.zero = take(6);                             // four zeros: where masked lanes of a chunk read point; [4]: trash slot
@@ -819,7 +822,7 @@ struct Qp {
     // P[pk(i,i')] += scale * sum_r E[r,i] dd[r] E[r,i']   (i >= i' < nDU).  When `tb` is given
     // and the matrix-core path runs, the ϵ row P[pk(nDU, i')] += sum_r tb[r] E[r,i'] is added for the
     // rows of the steps t >= the returned value; the caller adds the rest (Et_apply_add; -1: all of it).
-    MPCQP_HD int EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr,
+    MPCQP_HD_ETDE int EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr,
                           const double* Hg = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (DM::is_static) return EtDE_add_mfma(dd, P, scale, tb, Hg);
@@ -2001,7 +2004,7 @@ struct Step {
     // a row are (re)written as zeros and 1/L[k][k] stays in a register of lane k (myinvd).
     // Pivot guard: a non-positive pivot (float64 breakdown of the normal equations) freezes that
     // coordinate for this Newton step (zero column, 1/L = 1e-32) instead of poisoning the factor.
-    MPCQP_HD void cholesky() {
+    MPCQP_HD_CHOL void cholesky() {
         if (d.nZ > WAVE) { cholesky_big(); return; }      // (a compile-time branch with compile-time dims)
         MPCQP_RELANE(8);
         MPCQP_TIC();

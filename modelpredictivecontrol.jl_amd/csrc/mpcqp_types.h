@@ -14,14 +14,25 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-// always_inline: a real call inside the one-wave kernels puts the solver state (the Step / Qp objects
-// the callee reaches through `this`) into scratch memory, and the inliner's size heuristics left
-// cholesky() / EtDE_add() out of line in the larger specialisations (nZ~ > 48).  Those out-of-line
-// builds also returned wrong results on gfx950 (register state of the lanes >= nx^ corrupted from
-// the first iteration on; not root-caused further -- the callee keeps its MFMA accumulators in AGPRs,
-// which the kernel's two-waves-per-SIMD register budget may not cover) -- see
-// tests/test_gpu_parity.py::test_families_near_wave_limit.
+// always_inline: a real call inside the one-wave kernels makes `this` escape: the solver state (the Step / Qp objects)
+// then lives in scratch memory and its LDS pointer members come back from memory as GENERIC pointers, so every LDS access
+// turns into flat_load / flat_store.  The backend folds constant displacements into the flat instruction's offset field
+// and the hardware selects the aperture from the 64-bit BASE: for the zero blocks in front of the Sigma table (LDS offset
+// 0) the base lies below the LDS aperture and the access leaves it -- wrong data or a memory aperture violation (DESIGN 4,
+// profiles/r3/outline_rocgdb.txt; tests/test_gpu_parity.py::test_families_near_wave_limit).  The inliner's size
+// heuristics had left cholesky() / EtDE_add() out of line in the larger specialisations (nZ~ > 48).
 #define MPCQP_HD __host__ __device__ __attribute__((always_inline))
+// (investigation of that miscompilation only: -DMPCQP_OUTLINE=1 puts cholesky(), =2 EtDE_add(), =3 both out of line)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_OUTLINE) && (MPCQP_OUTLINE & 1)
+#define MPCQP_HD_CHOL __host__ __device__ __attribute__((noinline))
+#else
+#define MPCQP_HD_CHOL MPCQP_HD
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_OUTLINE) && (MPCQP_OUTLINE & 2)
+#define MPCQP_HD_ETDE __host__ __device__ __attribute__((noinline))
+#else
+#define MPCQP_HD_ETDE MPCQP_HD
+#endif
 #define MPCQP_UNROLL _Pragma("unroll")
 #define MPCQP_UNROLL4 _Pragma("unroll 4")
 #define MPCQP_NOUNROLL _Pragma("nounroll")
@@ -35,6 +46,8 @@
 #else
 #define MPCQP_SCHED_FENCE() ((void)0)
 #define MPCQP_HD
+#define MPCQP_HD_CHOL
+#define MPCQP_HD_ETDE
 #define MPCQP_UNROLL
 #define MPCQP_UNROLL4
 #define MPCQP_NOUNROLL
