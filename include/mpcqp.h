@@ -139,8 +139,9 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk);
  * prediction steps, N_Hc (nDU,nDU,B) different moves, L_Hp (nU,nU,B) different inputs/steps.  Each replaces the
  * corresponding diagonal of mpcqp_set_weights (NULL: keep the diagonal / block form); call after
  * mpcqp_set_weights.  H~ is rebuilt (K2, runtime-dimension kernel).  With a dense M_Hp or L_Hp the step
- * evaluates M (F - R^y) and L (Tu lastu0 - R^u) densely and runs on the runtime-dimension kernel; a dense N_Hc
- * only changes H~ and keeps the specialised step kernels.                                           */
+ * evaluates M (F - R^y) and L (Tu lastu0 - R^u) densely: on an on-demand specialisation that carries these products
+ * (mpcqp_prepare AFTER this call; the kernels compiled into the library do not) or on the runtime-dimension kernel; a
+ * dense N_Hc only changes H~ and keeps every specialised step kernel.                                           */
 int mpcqp_set_dense_weights(mpcqp_handle h, const double* M_Hp, const double* N_Hc, const double* L_Hp);
 
 /* Custom linear inequality constraints over k .. k+Hp (keywords Wy, Wu, Wd, Wr of LinMPC,

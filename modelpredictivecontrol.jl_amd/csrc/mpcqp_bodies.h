@@ -73,6 +73,9 @@
 #endif
 #define MPCQP_PRAGMA_(x) _Pragma(#x)
 #define MPCQP_PRAGMA(x) MPCQP_PRAGMA_(x)
+#ifndef MPCQP_SPEC_DENSE
+#define MPCQP_SPEC_DENSE 0        // 1: this specialisation carries the dense M_Hp / L_Hp products of the gradient
+#endif
 #ifndef MPCQP_ETAPPLY_NB
 #define MPCQP_ETAPPLY_NB 3        // steps per (double-buffered) batch of E'w
 #endif
@@ -1378,7 +1381,7 @@ struct Step {
         auto cy = [&](int r) {
             return F[r] - (rconst ? io.Ry[(size_t)b * ny + (r % ny)] : io.Ry[(size_t)b * nY + r]);
         };
-        if (!DM::is_static && m.Mfull) {      // dense M_Hp: M (F - R̂y), column-major symmetric (coalesced over r)
+        if ((!DM::is_static || MPCQP_SPEC_DENSE) && m.Mfull) {      // dense M_Hp: M (F - R̂y), column-major symmetric (coalesced over r)
             const double* Mf = m.Mfull + (size_t)b * nY * nY;
             for (int r = w.lane; r < nY; r += WAVE) {
                 double acc = 0.0;
@@ -1403,7 +1406,7 @@ struct Step {
         for (int k = w.lane; k < d.nDU; k += WAVE) {
             const int j = k / nu, cc = k - j * nu;
             double acc = 0.0;
-            if (!DM::is_static && m.Ldense) {    // dense L_Hp: (Pu' L (Tu lastu0 - R̂u))[k]
+            if ((!DM::is_static || MPCQP_SPEC_DENSE) && m.Ldense) {    // dense L_Hp: (Pu' L (Tu lastu0 - R̂u))[k]
                 const double* Lf = m.Ldense + (size_t)b * d.nU * d.nU;
                 for (int t = qp.jl(j); t < d.Hp; ++t)
                     for (int r2 = 0; r2 < d.nU; ++r2) {

@@ -93,6 +93,9 @@ struct SpecLib {
     bool verified = false;        // compared with the runtime-dimension kernel on this machine (marker <object>.ok)
 };
 using SpecKey = std::tuple<int, int, int, int, int, int, unsigned, int>;
+// last field (also the last field of the object name): bit 0 default move blocking, bit 1 dense M_Hp / L_Hp in the gradient
+static int spec_variant(const Dims& d) { return d.default_nb | (d.dense_w ? 2 : 0); }
+static SpecKey spec_key(const Dims& d) { return SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, spec_variant(d)}; }
 static std::mutex g_spec_mu;
 static std::map<SpecKey, SpecLib> g_spec;        // failed loads are cached as empty entries
 static const SpecLib* find_verified_spec(const Dims& d);
@@ -157,7 +160,7 @@ static unsigned compiler_id() {
 static std::string spec_name(const Dims& d) {
     char name[224];
     snprintf(name, sizeof name, "spec_r%d_c%08x_%d_%d_%d_%d_%d_%d_%x_%d.so", MPCQP_KERNEL_REV, compiler_id(), d.nu, d.ny,
-             d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb);
+             d.nxh, d.Hp, d.Hc, d.neps, d.gmask, spec_variant(d));
     return name;
 }
 
@@ -166,14 +169,15 @@ static bool jit_enabled() {
     return on;
 }
 
-// (custom linear constraints and dense weights run on the runtime-dims kernel; compile-time dims up to MPCQP_SPEC_NZMAX:
+// (custom linear constraints run on the runtime-dims kernel; dense M_Hp / L_Hp get an on-demand variant of their own
+// (-DMPCQP_SPEC_DENSE: the dense products of the gradient); compile-time dims up to MPCQP_SPEC_NZMAX:
 // beyond one row per lane the specialisation keeps the several-rows-per-lane factorisation of the runtime dims but has
 // the matrix-core E'DE, register rows and constant trip counts)
 #ifndef MPCQP_SPEC_NZMAX
 #define MPCQP_SPEC_NZMAX 128
 #endif
 static bool spec_eligible(const Dims& d) {
-    return d.nw == 0 && d.nZ <= MPCQP_SPEC_NZMAX && !d.dense_w;
+    return d.nw == 0 && d.nZ <= MPCQP_SPEC_NZMAX;
 }
 
 // run `argv` (argv[0] = binary), stdout+stderr appended to `log`; returns the exit status, -1 on failure to start
@@ -220,6 +224,7 @@ static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
     // beyond one row per lane the LDS footprint (Phi alone is 47 KB at nZ~ = 106) leaves at most one wavefront per SIMD:
     // the kernel may as well use the whole register file (row state of several rows per lane in registers, no spills)
     if (d.nZ > WAVE) argv.push_back("-DMPCQP_STEP_WAVES=1");
+    if (d.dense_w) argv.push_back("-DMPCQP_SPEC_DENSE=1");
     if (const char* extra = getenv("MPCQP_JIT_FLAGS")) {
         std::string tok;
         for (const char* c = extra;; ++c) {
@@ -246,7 +251,7 @@ static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
 // the loaded specialisation of `d`, or nullptr; loads a cached object, never compiles
 static const SpecLib* find_spec(const Dims& d, bool load) {
     if (!jit_enabled() || !spec_eligible(d)) return nullptr;
-    const SpecKey key{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb};
+    const SpecKey key = spec_key(d);
     std::lock_guard<std::mutex> lock(g_spec_mu);
     auto it = g_spec.find(key);
     if (it != g_spec.end()) return it->second.step ? &it->second : nullptr;
@@ -288,22 +293,22 @@ int step_kernel_kind(const Dims& d, const Model& m) {
 
 // the kernel of the steps the small-problem kernel does not take (Ŷ requested, fused Kalman steps)
 int step_kernel_kind_other(const Dims& d) {
-    if (force_generic() || d.dense_w) return 0;
-    if (aot_matches(d)) return 1;
+    if (force_generic()) return 0;
+    if (!d.dense_w && aot_matches(d)) return 1;     // (the kernels compiled into the library have no dense-weight products)
     return find_verified_spec(d) ? 2 : 0;
 }
 
 // Make the specialised kernel of `d` available (compile if needed, load).  Returns the kernel kind
 // as step_kernel_kind(); `err` receives the reason when an eligible specialisation could not be built.
 static int prepare_step_other(const Dims& d, std::string* err) {
-    if (force_generic() || d.dense_w) return 0;
-    if (aot_matches(d)) return 1;
+    if (force_generic()) return 0;
+    if (!d.dense_w && aot_matches(d)) return 1;
     if (!jit_enabled() || !spec_eligible(d)) return 0;
     if (find_spec(d, true)) return 2;
     if (build_spec(d, nullptr, err) != 0) return 0;
     {
         std::lock_guard<std::mutex> lock(g_spec_mu);            // forget a remembered failure of an earlier load
-        g_spec.erase(SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb});
+        g_spec.erase(spec_key(d));
     }
     if (find_spec(d, true)) return 2;
     if (err) *err = "the specialisation was built but could not be loaded";
@@ -342,7 +347,7 @@ static const SpecLib* find_verified_spec(const Dims& d) {
     if (sl->verified) return sl;
     if (!spec_verified(d)) return nullptr;
     std::lock_guard<std::mutex> lock(g_spec_mu);
-    auto it = g_spec.find(SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb});
+    auto it = g_spec.find(spec_key(d));
     if (it == g_spec.end() || !it->second.step) return nullptr;
     it->second.verified = true;
     return &it->second;
@@ -352,7 +357,7 @@ void reject_spec(const Dims& d) {
     const std::string so = cache_dir() + "/" + spec_name(d);
     (void)rename(so.c_str(), (so + ".bad").c_str());
     std::lock_guard<std::mutex> lock(g_spec_mu);
-    g_spec[SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, d.default_nb}] = SpecLib{};
+    g_spec[spec_key(d)] = SpecLib{};
 }
 
 hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
@@ -389,7 +394,8 @@ hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStrea
 
 // the one-QP-per-wavefront kernels: ahead-of-time specialisation, on-demand specialisation, runtime dimensions
 hipError_t launch_step_spec_or_aot(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
-    if (!force_generic() && !d.dense_w) {      // (dense M_Hp / L_Hp: runtime-dimension kernel, like custom constraints)
+    if (!force_generic()) {
+        if (!d.dense_w) {      // (dense M_Hp / L_Hp: on-demand variant or the runtime-dimension kernel)
 #define X(NU, NY, NXH, HP, HC, NEPS, GM)                                            \
         {                                                                           \
             using SD = StaticDims<NU, NY, NXH, HP, HC, NEPS, GM>;                   \
@@ -397,6 +403,7 @@ hipError_t launch_step_spec_or_aot(const Dims& d, const Model& m, const StepIO& 
         }
         MPCQP_SPECIALIZATIONS(X)
 #undef X
+        }
         if (const SpecLib* sl = find_verified_spec(d)) return (hipError_t)sl->step(&d, &m, &io, (void*)st);
     }
     size_t lds = (size_t)make_carve(d).total * sizeof(double);

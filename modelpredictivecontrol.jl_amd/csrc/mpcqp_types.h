@@ -75,7 +75,7 @@ struct Dims {
     int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
     int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh, nW
     int default_nb;          // 1 iff nb = [1,..,1,Hp-Hc+1]
-    int dense_w;             // 1 iff a dense M_Hp or L_Hp is set: the step runs on the runtime-dimension kernel
+    int dense_w;             // 1 iff a dense M_Hp or L_Hp is set: the step runs on an on-demand variant with the dense products or on the runtime-dimension kernel
     int max_iter;
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
@@ -104,7 +104,8 @@ struct Model {
     // weights
     const double *Mdiag, *Ndiag, *Ldiag, *Cwt;
     const double* Mblk;   // optional [B][Hp][ny][ny]: block-diagonal M_Hp (symmetric blocks), replaces Mdiag
-    // optional dense (symmetric) weights, column-major per problem; they replace the diagonals (runtime-dimension kernels only)
+    // optional dense (symmetric) weights, column-major per problem; they replace the diagonals (runtime-dimension kernels and
+    // on-demand specialisations built with MPCQP_SPEC_DENSE)
     const double* Mfull;  // [B][nY][nY]    M_Hp coupling different prediction steps
     const double* Ndense; // [B][nDU][nDU]  N_Hc
     const double* Ldense; // [B][nU][nU]    L_Hp
