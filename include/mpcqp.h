@@ -153,7 +153,8 @@ int mpcqp_set_dense_weights(mpcqp_handle h, const double* M_Hp, const double* N_
  * Wy yop + Wu uop + Wd dop + Wr yop (NULL = 0) carries the operating points.  r̂e(k): see
  * mpcqp_set_current_setpoint.  nw = 0 removes them.
  * Bounds and softness (default 1, like c_wmin/c_wmax): Wmin, Wmax, C_wmin, C_wmax (nw (Hp+1), B),
- * NULL = absent (±Inf).  Problems with custom constraints run on the runtime-dimension kernel.   */
+ * NULL = absent (±Inf).  Problems with custom constraints run on an on-demand specialisation that has the rows
+ * compiled in (mpcqp_prepare after this call) or on the runtime-dimension kernel.                   */
 int mpcqp_set_custom_constraints(mpcqp_handle h, int nw, const double* Wy, const double* Wu,
                                  const double* Wd, const double* Wr, const double* w_op);
 int mpcqp_set_custom_bounds(mpcqp_handle h, const double* Wmin, const double* Wmax,
@@ -253,7 +254,7 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
  * specialised on demand for these dimensions and this pattern of constraint groups, compiled with
  * the installation's hipcc and cached (csrc/mpcqp_kernels.hip), or (MPCQP_KERNEL_GENERIC) the
  * runtime-dimension kernel (same source and numerics, about 4x slower; also the kernel of problems
- * with custom linear constraints or nZ > 64).  mpcqp_step NEVER compiles: without a call of
+ * with nZ > 128).  mpcqp_step NEVER compiles: without a call of
  * mpcqp_prepare (or a cached object from an earlier run / from mpcqp_prebuild) it uses the generic
  * kernel.  The JuMP analogue is the one-time model build of init_optimization!
  * (src/controller/linmpc.jl:303-339), which also happens before the control loop.

@@ -76,6 +76,9 @@
 #ifndef MPCQP_SPEC_DENSE
 #define MPCQP_SPEC_DENSE 0        // 1: this specialisation carries the dense M_Hp / L_Hp products of the gradient
 #endif
+#ifndef MPCQP_SPEC_NW
+#define MPCQP_SPEC_NW 0           // custom linear constraint rows per step of this specialisation (mpcqp_set_custom_constraints)
+#endif
 #ifndef MPCQP_ETAPPLY_NB
 #define MPCQP_ETAPPLY_NB 3        // steps per (double-buffered) batch of E'w
 #endif
@@ -154,7 +157,7 @@ struct StaticDims {
     static constexpr int nu = NU, ny = NY, nxh = NXH, Hp = HP, Hc = HC, neps = NEPS;
     static constexpr int nDU = NU * HC, nZ = NU * HC + NEPS, nU = NU * HP, nY = NY * HP;
     static constexpr int npk = pk_size(nZ);
-    static constexpr int nw = 0, nW = 0;            // custom constraints run on the runtime-dims kernel only
+    static constexpr int nw = MPCQP_SPEC_NW, nW = MPCQP_SPEC_NW * (HP + 1);   // custom rows: on-demand variants only (0 in the library's own kernels)
     // LDS stride of one Σ_m block: padded so the MFMA operand reads of E'DE (64 lanes = 4 block
     // columns x NY*NU entries) fall in distinct bank groups (see DESIGN.md "LDS layout")
     static constexpr int sp = (NY * NU) % 16 == 0 ? NY * NU + 8 : NY * NU;
@@ -173,7 +176,7 @@ struct StaticDims {
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
     MPCQP_HD static constexpr int cnt(int p) {
-        return p == P_BOX ? nZ : p == P_U ? nDU : p == P_DU ? nDU : p == P_Y ? nY : p == P_X ? nxh : 0;
+        return p == P_BOX ? nZ : p == P_U ? nDU : p == P_DU ? nDU : p == P_Y ? nY : p == P_X ? nxh : p == P_W ? nW : 0;
     }
     MPCQP_HD static constexpr int rowoff(int g) {
         int o = 0;
@@ -187,7 +190,7 @@ struct StaticDims {
           dual_reg(d.dual_reg), flags(d.flags) {}
     static bool matches_dims(const Dims& d) {
         return d.nu == NU && d.ny == NY && d.nxh == NXH && d.Hp == HP && d.Hc == HC &&
-               d.neps == NEPS && d.default_nb == DNB && d.nw == 0;
+               d.neps == NEPS && d.default_nb == DNB && d.nw == MPCQP_SPEC_NW;
     }
     static bool matches(const Dims& d) { return matches_dims(d) && d.gmask == GMASK; }
 };
@@ -196,6 +199,13 @@ struct StaticDims {
 // LDS carve-up of one problem (all doubles unless stated).  Same function on host (to size the
 // dynamic LDS) and device.  Row arrays exist only for runtime dims (registers otherwise).
 // ------------------------------------------------------------------------------------------
+// custom linear constraint rows exist in this instantiation (runtime dims, or an on-demand variant built for nw > 0)
+template <class DM>
+constexpr bool has_w() {
+    if constexpr (DM::is_static) return DM::nw > 0;
+    else return true;
+}
+
 constexpr int NROWARR = 7;     // h, s, lam, rp, gd, pp, cs (cs only stored with runtime dims)
 
 struct Carve {
@@ -331,7 +341,7 @@ struct Qp {
             const double* e = m.exT + (size_t)b * ne;
             for (int i = w.lane; i < ne; i += WAVE) sm[c.exT + i] = e[i];
         }
-        if constexpr (!DM::is_static) {
+        if constexpr (has_w<DM>()) {
             if (pair_on(P_W)) {
                 const int n1 = d.nw * d.ny, n2 = d.nw * d.nu;
                 for (int i = w.lane; i < n1; i += WAVE) sm[c.Wm + i] = m.Wy[(size_t)b * n1 + i];
@@ -1553,7 +1563,7 @@ struct Step {
             case P_DU: return v[k];
             case P_Y: return sm[c.tA[P_Y] + k];
             case P_W: {
-                if constexpr (DM::is_static) return 0.0;
+                if constexpr (!has_w<DM>()) return 0.0;
                 else {
                     const int t = k / d.nw, i = k - t * d.nw;
                     double acc = 0.0;
@@ -1602,7 +1612,7 @@ struct Step {
         eacc = w.sum(eacc);
         w.sync();
         bool useY = qp.pair_on(P_Y), useU = qp.pair_on(P_U);
-        if constexpr (!DM::is_static) {
+        if constexpr (has_w<DM>()) {
             if (qp.pair_on(P_W)) {          // custom rows reach z through the Y and U primitives
                 qp.W_fold(sm + c.tA[P_W], sm + c.tA[P_Y], !useY, sm + c.tA[P_U], !useU);
                 useY = useU = true;
@@ -1678,7 +1688,7 @@ struct Step {
         ee = w.sum(ee);
         w.sync();
         bool epsY = qp.pair_on(P_Y), epsU = qp.pair_on(P_U);     // who feeds the ϵ row below
-        if constexpr (!DM::is_static) {
+        if constexpr (has_w<DM>()) {
             if (qp.pair_on(P_W) && d.neps) {      // ϵ row of the custom rows: E_w' tB_W through Y and U
                 qp.W_fold(sm + c.tB[P_W], sm + c.tB[P_Y], !epsY, sm + c.tB[P_U], !epsU);
                 epsY = epsU = true;
@@ -1742,7 +1752,7 @@ struct Step {
                 Phi[pk(i, ip)] += acc;
             }
         }
-        if constexpr (!DM::is_static) {
+        if constexpr (has_w<DM>()) {
             if (qp.pair_on(P_W)) {        // E_w' dW E_w, rows formed on the fly (set-up-grade path)
                 w.sync();
                 const int ntri = nDU * (nDU + 1) / 2, nw = d.nw;

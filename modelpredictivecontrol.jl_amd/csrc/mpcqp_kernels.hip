@@ -93,8 +93,9 @@ struct SpecLib {
     bool verified = false;        // compared with the runtime-dimension kernel on this machine (marker <object>.ok)
 };
 using SpecKey = std::tuple<int, int, int, int, int, int, unsigned, int>;
-// last field (also the last field of the object name): bit 0 default move blocking, bit 1 dense M_Hp / L_Hp in the gradient
-static int spec_variant(const Dims& d) { return d.default_nb | (d.dense_w ? 2 : 0); }
+// last field (also the last field of the object name): bit 0 default move blocking, bit 1 dense M_Hp / L_Hp in the gradient,
+// bits 2.. the number of custom linear constraint rows per step
+static int spec_variant(const Dims& d) { return d.default_nb | (d.dense_w ? 2 : 0) | (d.nw << 2); }
 static SpecKey spec_key(const Dims& d) { return SpecKey{d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, spec_variant(d)}; }
 static std::mutex g_spec_mu;
 static std::map<SpecKey, SpecLib> g_spec;        // failed loads are cached as empty entries
@@ -169,15 +170,16 @@ static bool jit_enabled() {
     return on;
 }
 
-// (custom linear constraints run on the runtime-dims kernel; dense M_Hp / L_Hp get an on-demand variant of their own
-// (-DMPCQP_SPEC_DENSE: the dense products of the gradient); compile-time dims up to MPCQP_SPEC_NZMAX:
+// (custom linear constraints and dense M_Hp / L_Hp get on-demand variants of their own: -DMPCQP_SPEC_NW=nw compiles the
+// custom rows in (row state in registers like every other group), -DMPCQP_SPEC_DENSE the dense products of the gradient;
+// compile-time dims up to MPCQP_SPEC_NZMAX:
 // beyond one row per lane the specialisation keeps the several-rows-per-lane factorisation of the runtime dims but has
 // the matrix-core E'DE, register rows and constant trip counts)
 #ifndef MPCQP_SPEC_NZMAX
 #define MPCQP_SPEC_NZMAX 128
 #endif
 static bool spec_eligible(const Dims& d) {
-    return d.nw == 0 && d.nZ <= MPCQP_SPEC_NZMAX;
+    return d.nZ <= MPCQP_SPEC_NZMAX;
 }
 
 // run `argv` (argv[0] = binary), stdout+stderr appended to `log`; returns the exit status, -1 on failure to start
@@ -225,6 +227,7 @@ static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
     // the kernel may as well use the whole register file (row state of several rows per lane in registers, no spills)
     if (d.nZ > WAVE) argv.push_back("-DMPCQP_STEP_WAVES=1");
     if (d.dense_w) argv.push_back("-DMPCQP_SPEC_DENSE=1");
+    if (d.nw > 0) argv.push_back("-DMPCQP_SPEC_NW=" + std::to_string(d.nw));
     if (const char* extra = getenv("MPCQP_JIT_FLAGS")) {
         std::string tok;
         for (const char* c = extra;; ++c) {

@@ -236,7 +236,7 @@ def run_custom_constraint_cases(lib=None, B=2, Hp=50, which=(0, 1, 2, 3)):
     return worst
 
 
-def run_soft_custom_constraints(lib=None, B=2, seed=4):
+def run_soft_custom_constraints(lib=None, B=2, seed=4, kinds=None):
     """Two soft custom rows mixing outputs, inputs, a measured disturbance and the set point, on top
     of ordinary u / y constraints, against the oracle (exercises the ϵ row of the custom block)."""
     from oracle import estim as es
@@ -267,6 +267,8 @@ def run_soft_custom_constraints(lib=None, B=2, seed=4):
         worst = max(worst, np.abs(gpu.Z[B - 1] - orc.Zt).max() / max(1.0, np.abs(orc.Zt).max()),
                     np.abs(ug[B - 1] - uo).max(), np.abs(ig["W"][B - 1] - io["W"]).max())
         x0 = kf.Ah @ x0 + kf.Bhu @ (uo - model.uop) * 0.5
+    if kinds is not None:
+        kinds.append(gpu.hd.kernel_kind())
     return worst
 
 

@@ -516,7 +516,11 @@ def test_custom_linear_constraints_on_gpu(hiplib):
     mpcqp_set_custom_bounds): the reference's four known answers
     (test/3_test_predictive_control.jl:466-495) and a soft, mixed case against the oracle."""
     from tests.parity_util import run_custom_constraint_cases, run_soft_custom_constraints
-    assert run_soft_custom_constraints(B=33) <= 1e-6
+    kinds = []
+    assert run_soft_custom_constraints(B=33, kinds=kinds) <= 1e-6
+    # (round 3: handles with custom rows get an on-demand specialisation with the rows compiled in, -DMPCQP_SPEC_NW,
+    #  accepted by the comparison with the runtime-dimension kernel like every on-demand kernel)
+    assert kinds == [mpcqp.api.KERNEL_ONDEMAND]
     assert run_custom_constraint_cases(B=5) <= TOL
 
 
