@@ -73,6 +73,26 @@
 #endif
 #define MPCQP_PRAGMA_(x) _Pragma(#x)
 #define MPCQP_PRAGMA(x) MPCQP_PRAGMA_(x)
+// Unrolled K steps (= operand loads in flight) of the matrix-core loops.  A kernel with one wavefront per SIMD
+// (MPCQP_STEP_WAVES = 1: nZ~ > 64, two wavefronts per CU by LDS) has nobody to hide an LDS round trip behind and the
+// whole register file to itself: measured on nZ~ = 106, B = 8192: panel update 2 / 8 / 16 steps 26.5 / 25.5 / 25.3 ms,
+// then E'DE 2 / 4 / 8 steps 25.5 / 24.75 / 24.75 ms.  The two-waves-per-SIMD kernels sit at their register limit: 2.
+#ifndef MPCQP_ETDE_UNROLL
+#if defined(MPCQP_STEP_WAVES) && MPCQP_STEP_WAVES == 1
+#define MPCQP_ETDE_UNROLL 4
+#else
+#define MPCQP_ETDE_UNROLL 2
+#endif
+#endif
+#ifndef MPCQP_HZ_UNROLL
+#define MPCQP_HZ_UNROLL 4         // terms per unrolled pass of the two loops of H~ z (dual_residual)
+#endif
+#ifndef MPCQP_PANEL_UNROLL
+#define MPCQP_PANEL_UNROLL 16     // (the panel update only exists beyond one row per lane)
+#endif
+#ifndef MPCQP_URMW_UNROLL
+#define MPCQP_URMW_UNROLL 4       // read-modify-writes in flight along a row of Pu'dU Pu (several rows per lane)
+#endif
 #ifndef MPCQP_SPEC_DENSE
 #define MPCQP_SPEC_DENSE 0        // 1: this specialisation carries the dense M_Hp / L_Hp products of the gradient
 #endif
@@ -780,13 +800,13 @@ struct Qp {
             constexpr bool PIPE = (NY % 4 == 0) && DM::zpad > 0;
             Ops cur, nxt;
             if (PIPE) kload(kA, cur);
-            _Pragma("unroll 2")
+            MPCQP_PRAGMA(unroll MPCQP_ETDE_UNROLL)
             for (int kk = kA; kk < kB; ++kk) {
                 if (PIPE) { kload(kk + 1, nxt); MPCQP_SCHED_FENCE(); kcomp(cur, true, false); MPCQP_SCHED_FENCE(); cur = nxt; }
                 else { kload(kk, cur); kcomp(cur, true, false); }
             }
             if (I1 > I0) {
-                _Pragma("unroll 2")
+                MPCQP_PRAGMA(unroll MPCQP_ETDE_UNROLL)
                 for (int kk = kB; kk < NK; ++kk) {
                     if (PIPE) { kload(kk + 1, nxt); MPCQP_SCHED_FENCE(); kcomp(cur, true, true); MPCQP_SCHED_FENCE(); cur = nxt; }
                     else { kload(kk, cur); kcomp(cur, true, true); }
@@ -1522,6 +1542,39 @@ struct Step {
         w.sync();
     }
 
+    // Running sums over the block columns of src[(j, c)] for nDU > 64 (several variables per lane): lane c < nu runs
+    // down (prefix) or up (suffix) its channel with the sum in a register -- Hc dependent additions on independent LDS
+    // loads, instead of a loop of up to Hc terms in EVERY lane (nZ~ = 106: 10k and 7k cycles per iteration in G'w and
+    // G v).  dst may be src.  The caller fences before (src complete) -- the fence after is here.
+    MPCQP_HD void block_scan(const double* src, double* dst, bool suffix) {
+        const int nu = d.nu, Hc = d.Hc;
+        if constexpr (DM::is_static) {
+            // compile-time Hc: every load first (dst may alias src, which would otherwise order each load behind the
+            // store before it: 160 cycles per step measured), then the additions, then the stores
+            if (w.lane < nu) {
+                double x[DM::Hc];
+                MPCQP_UNROLL
+                for (int i = 0; i < DM::Hc; ++i) x[i] = src[(suffix ? DM::Hc - 1 - i : i) * DM::nu + w.lane];
+                MPCQP_UNROLL
+                for (int i = 1; i < DM::Hc; ++i) x[i] += x[i - 1];
+                MPCQP_UNROLL
+                for (int i = 0; i < DM::Hc; ++i) dst[(suffix ? DM::Hc - 1 - i : i) * DM::nu + w.lane] = x[i];
+            }
+            w.sync();
+            return;
+        }
+        if (w.lane < nu) {
+            double acc = 0.0;
+            MPCQP_UNROLL4
+            for (int i = 0; i < Hc; ++i) {
+                const int k = (suffix ? Hc - 1 - i : i) * nu + w.lane;
+                acc += src[k];
+                dst[k] = acc;
+            }
+        }
+        w.sync();
+    }
+
     // ---- primitives of G v: ucum (held cumulative sum), tY = E v, tX = ex̂ v ------------------
     MPCQP_HD void primitives(const double* v) {
         const int nu = d.nu;
@@ -1531,13 +1584,8 @@ struct Step {
             if (d.nDU <= WAVE) {
                 const double acc = qp.block_prefix(w.lane < d.nDU ? v[w.lane] : 0.0);
                 if (w.lane < d.nDU) ucum[w.lane] = acc;
-            } else
-            for (int k = w.lane; k < d.nDU; k += WAVE) {
-                const int j = k / nu, cc = k - j * nu;
-                double acc = 0.0;
-                MPCQP_UNROLL4
-                for (int jj = 0; jj <= j; ++jj) acc += v[jj * nu + cc];
-                ucum[k] = acc;
+            } else {
+                block_scan(v, ucum, false);
             }
         }
         prof_[11] += (double)(clock64_() - tic11_);
@@ -1622,17 +1670,14 @@ struct Step {
         const long long tic9_ = clock64_();
         double sufU = 0.0;
         if (useU && d.nDU <= WAVE) sufU = qp.block_suffix(w.lane < d.nDU ? sm[c.tA[P_U] + w.lane] : 0.0);
+        else if (useU) block_scan(sm + c.tA[P_U], sm + c.tA[P_U], true);       // (tA[P_U] is consumed here: in place)
         for (int k = w.lane; k < d.nZ; k += WAVE) {
             double acc = 0.0;
             if (qp.pair_on(P_BOX)) acc += sm[c.tA[P_BOX] + k];
             if (k < d.nDU) {
                 if (qp.pair_on(P_DU)) acc += sm[c.tA[P_DU] + k];
                 if (useU && d.nDU <= WAVE) acc += sufU;
-                else if (useU) {
-                    const int j = k / nu, cc = k - j * nu;
-                    const double* tU = sm + c.tA[P_U];
-                    for (int jj = j; jj < d.Hc; ++jj) acc += tU[jj * nu + cc];
-                }
+                else if (useU) acc += sm[c.tA[P_U] + k];
                 if (qp.pair_on(P_X)) {
                     const double* tX = sm + c.tA[P_X];
                     for (int i = 0; i < d.nxh; ++i) acc += qp.Xat(i, k) * tX[i];
@@ -1730,13 +1775,13 @@ struct Step {
                 }
             }
         } else if (qp.pair_on(P_U)) {
-            const double* tU = sm + c.tA[P_U];
+            double* tU = sm + c.tA[P_U];
+            w.sync();
+            block_scan(tU, tU, true);              // (nothing reads the per-block sums after this point: in place)
             for (int k = w.lane; k < nDU; k += WAVE) {
                 const int j = k / nu, cc = k - j * nu;
-                double suf = 0.0;
-                MPCQP_UNROLL4
-                for (int jj = j; jj < d.Hc; ++jj) suf += tU[jj * nu + cc];
-                MPCQP_UNROLL4
+                const double suf = tU[k];
+                MPCQP_PRAGMA(unroll MPCQP_URMW_UNROLL)
                 for (int j2 = 0; j2 <= j; ++j2) Phi[pk(k, j2 * nu + cc)] += suf;
             }
         }
@@ -1858,7 +1903,7 @@ struct Step {
                 X[I] = Phi + pk(row, 0) + lk;
                 acc[I] = v4d_{0.0, 0.0, 0.0, 0.0};
             }
-            _Pragma("unroll 2")
+            MPCQP_PRAGMA(unroll MPCQP_PANEL_UNROLL)
             for (int kk = 0; kk < 4 * P; ++kk) {
                 const double bb = X[P][4 * kk];
                 acc[P] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb, bb, acc[P], 0, 0, 0);
@@ -2433,8 +2478,8 @@ struct Step {
     __device__ __forceinline__ void chol_big_panels(const double (&thr)[NS], bool& broke) {
         constexpr int n = DM::nZ, K0 = 16 * P;
         if constexpr (K0 < n) {
-            if constexpr (P > 0) chol_panel_update<P>();
-            chol_big_panel_reg<P, NS>(thr, broke);
+            if constexpr (P > 0) { if (!(MPCQP_ABLATE & 256)) chol_panel_update<P>(); }
+            if (!(MPCQP_ABLATE & 512)) chol_big_panel_reg<P, NS>(thr, broke);
             chol_big_panels<P + 1, NS>(thr, broke);
         }
     }
@@ -2589,10 +2634,10 @@ struct Step {
             double h0 = 0.0, h1 = 0.0;
             const double* Hk = Hp_ + pk(k, 0);
             int j = 0;
-            MPCQP_UNROLL4
+            MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
             for (; j + 1 <= k; j += 2) { h0 += Hk[j] * z[j]; h1 += Hk[j + 1] * z[j + 1]; }
             if (j <= k) h0 += Hk[j] * z[j];
-            MPCQP_UNROLL4
+            MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
             for (int jj = k + 1; jj < n; ++jj) h1 += Hp_[pk(jj, k)] * z[jj];
             const double hz = h0 + h1;
             const double r = hz + q[k] + gt[k];
