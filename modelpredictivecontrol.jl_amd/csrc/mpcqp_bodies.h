@@ -847,7 +847,18 @@ struct Qp {
             }
         };
         etde_passes<0, NT>(pass);
-        if (Hg && DM::neps && w.lane == 0) P[pk(NDU, NDU)] = Hg[pk(NDU, NDU)];     // Ñ's slack weight (construct.jl:842)
+        if constexpr (DM::neps != 0) {
+            if (Hg) {
+                // nDU a multiple of 16: the ϵ row (index nDU) starts a tile row of its own that no pass covers -- in
+                // the overwrite mode nothing else initialises it (the caller adds E'tb to it: eps_t0 stays -1), and the
+                // row would keep the previous factor's entries: a wrong Newton matrix, twice the iterations and
+                // failed solves on every shape with nu Hc = 16, 32, 48, .. (found at nZ~ = 81, round 3)
+                if constexpr (IE >= NT) {
+                    for (int k = w.lane; k < NDU; k += WAVE) P[pk(NDU, k)] = Hg[pk(NDU, k)];
+                }
+                if (w.lane == 0) P[pk(NDU, NDU)] = Hg[pk(NDU, NDU)];     // Ñ's slack weight (construct.jl:842)
+            }
+        }
         return eps_t0;
     }
 #endif

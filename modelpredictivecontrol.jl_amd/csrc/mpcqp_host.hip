@@ -813,8 +813,13 @@ static int self_test_spec_impl(mpcqp_handle h, double* worst, DBuf& yh, DBuf& in
         diff = std::fmax(diff, std::fabs(z[i] - z[cnt[5] + i]));
         if (!(z[i] == z[i])) diff = INFINITY;
     }
-    for (size_t i = 0; i < n; ++i)
+    for (size_t i = 0; i < n; ++i) {
         if (s[i] != s[2 * n + i]) diff = INFINITY;
+        // same algorithm, same data: the iteration counts agree up to rounding.  A kernel whose Newton matrix is wrong
+        // still converges -- on exact residuals -- but slowly (round 3: an uninitialised ϵ row doubled the count and
+        // passed the comparison of the optima)
+        if (std::abs(s[n + i] - s[3 * n + i]) > 3) diff = INFINITY;
+    }
     *worst = diff / scale;
     return MPCQP_OK;
 }

@@ -60,6 +60,28 @@ def test_step_matches_oracle(name, B, seed, hiplib):
     assert np.abs(got["u"] - ref["u"]).max() <= TOL * max(1.0, np.abs(ref["u"]).max())
 
 
+@pytest.mark.parametrize("name", ["4,2,2,12,8", "6,4,4,12,8", "6,4,3,20,12", "8,4,4,24,20"])
+def test_slack_row_of_shapes_with_nDU_a_multiple_of_16(name, hiplib):
+    """nu Hc = 16, 32, 48, 80: the ϵ row of the Newton matrix starts a 16-row tile of its own that the matrix-core
+    passes of E'DE do not cover.  Round 3's overwrite mode left it uninitialised (twice the iterations, 5 % failed
+    solves; the eight controllers of mpcqp_prepare's comparison did not show it): every instance against the oracle, on
+    the specialised kernel, with the iteration count of the oracle's C port."""
+    cfg = synth.get_config(name)
+    assert (cfg.nu * cfg.Hc) % 16 == 0
+    bt = synth.make_batch(cfg, 192, seed=3)
+    got = run_batch(cfg, bt)
+    assert got["mpc"].hd.kernel_kind() == mpcqp.api.KERNEL_ONDEMAND
+    assert np.all(got["status"] == mpcqp.STATUS_OPTIMAL), np.unique(got["status"], return_counts=True)
+    ref = oracle_batch(cfg, bt)
+    err = rel_err(got["Z"], ref["Z"], cfg.nu * cfg.Hc)
+    assert err.max() <= TOL, f"max rel ΔU err {err.max():.3e}"
+    # the C port runs the same interior-point iteration on a dense Newton matrix: with a correct matrix the counts agree
+    from oracle import cport
+    _, _, st_c, it_c = cport.from_synth(cfg, bt).step(bt["xhat0"], bt["lastu0"], bt["ry"])
+    assert np.all(st_c == 0)
+    assert abs(got["iters"].mean() - it_c.mean()) <= 1.0, (got["iters"].mean(), it_c.mean())
+
+
 def test_full_size_properties_C3(hiplib):
     """BASELINE configs[2] at full size (B = 65536): size-independent properties."""
     cfg = synth.C3
