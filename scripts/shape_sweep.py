@@ -2,7 +2,7 @@
 instances on its on-demand specialisation against the oracle's C port (same interior-point iteration on a dense Newton
 matrix, all host cores): statuses, optimum, iteration count.  A specialisation with a wrong Newton matrix still converges
 on its exact residuals -- slowly, with a few per cent of failed solves -- which a handful of instances per family does
-not show (round 3: shapes with nu*Hc a multiple of 16).   python scripts/shape_sweep.py [B] [shape ...]"""
+not show (round 3: shapes with nu*Hc a multiple of 16).   python scripts/shape_sweep.py [B] [pattern ...] [shape ...]  (patterns: c3 box yband all)"""
 import sys
 import numpy as np
 sys.path.insert(0, '.')
@@ -13,26 +13,38 @@ from oracle import cport
 SHAPES = ["4,1,1,16,16", "4,1,2,40,31", "4,1,1,64,63", "4,2,2,12,8", "6,2,2,30,15", "6,2,3,32,31", "6,2,2,40,32", "8,2,2,60,40",
           "6,3,2,20,5", "6,3,3,21,21", "8,3,3,30,16", "8,3,2,45,42", "6,4,4,12,4", "6,4,4,12,8", "6,4,3,20,12", "12,4,4,30,15",
           "12,4,4,30,16", "8,4,4,24,20", "12,4,4,32,31", "6,5,3,15,12", "8,5,4,20,16", "8,6,2,12,10", "8,7,3,12,9", "8,8,4,10,8"]
+# constraint patterns (a pattern is part of the specialisation's key): C3-style; C2-style hard u / du box without slack;
+# soft ymin + ymax with the du box; everything
+import dataclasses
+PATTERNS = {"c3": {}, "box": dict(ymax=np.inf, dumin=-0.2, dumax=0.2, Cwt=np.inf),
+            "yband": dict(ymin=-1.0, ymax=1.0, umin=-np.inf, umax=np.inf, dumin=-0.3, dumax=0.3),
+            "all": dict(ymin=-1.2, ymax=1.0, dumin=-0.4, dumax=0.4)}
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-shapes = sys.argv[2:] or SHAPES
+args = sys.argv[2:]
+pats = [a for a in args if a in PATTERNS] or ["c3"]
+shapes = [a for a in args if a not in PATTERNS] or SHAPES
 bad = 0
-for name in shapes:
-    cfg = synth.get_config(name)
-    bt = synth.make_batch(cfg, B, seed=11)
-    hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=1, flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START)
-    hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
-    hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt))
-    hd.set_bounds(U0min=np.full((B, hd.nU), cfg.umin), U0max=np.full((B, hd.nU), cfg.umax), Y0max=np.full((B, hd.nY), cfg.ymax))
-    kind = hd.prepare()
-    Z = np.zeros((B, hd.nZ))
-    u0, st, it = hd.step(bt["xhat0"], bt["lastu0"], bt["ry"], Z)
-    Zc, _, stc, itc = cport.from_synth(cfg, bt).step(bt["xhat0"], bt["lastu0"], bt["ry"])
-    nDU = hd.nDU
-    err = np.max(np.abs(Z[:, :nDU] - Zc[:, :nDU]), axis=1) / np.maximum(1.0, np.max(np.abs(Zc[:, :nDU]), axis=1))
-    # (a single ill-conditioned instance may sit 1e-4 from the C port at equal objective: the 99 % quantile decides, the maximum is printed)
-    ok = kind in (1, 2, 3) and np.all(st == 0) and np.all(stc == 0) and np.quantile(err, 0.99) <= 1e-5 and abs(it.mean() - itc.mean()) <= 1.0
-    bad += not ok
-    print(f"{name:>14} nZ {hd.nZ:3d} kind {kind} ms {hd.last_step_ms():7.2f} optimal {np.mean(st == 0):.4f} (C port {np.mean(stc == 0):.4f}) "
-          f"iters {it.mean():5.2f} (C port {itc.mean():5.2f}) rel dU diff 99 % {np.quantile(err, 0.99):.1e} max {err.max():.1e} {'ok' if ok else 'FAIL'}", flush=True)
-    hd.close()
-print("shapes", len(shapes), "failed", bad)
+for pat in pats:
+    for name in shapes:
+        cfg = dataclasses.replace(synth.get_config(name), **PATTERNS[pat])
+        name = f"{pat}:{name}"
+        bt = synth.make_batch(cfg, B, seed=11)
+        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=0 if np.isinf(cfg.Cwt) else 1, flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START)
+        hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
+        hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt) if np.isfinite(cfg.Cwt) else None)
+        full = lambda v, n: None if not np.isfinite(v) else np.full((B, n), float(v))
+        hd.set_bounds(U0min=full(cfg.umin, hd.nU), U0max=full(cfg.umax, hd.nU), DUmin=full(cfg.dumin, hd.nDU), DUmax=full(cfg.dumax, hd.nDU),
+                      Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY))
+        kind = hd.prepare()
+        Z = np.zeros((B, hd.nZ))
+        u0, st, it = hd.step(bt["xhat0"], bt["lastu0"], bt["ry"], Z)
+        Zc, _, stc, itc = cport.from_synth(cfg, bt).step(bt["xhat0"], bt["lastu0"], bt["ry"])
+        nDU = hd.nDU
+        err = np.max(np.abs(Z[:, :nDU] - Zc[:, :nDU]), axis=1) / np.maximum(1.0, np.max(np.abs(Zc[:, :nDU]), axis=1))
+        # (a single ill-conditioned instance may sit 1e-4 from the C port at equal objective: the 99 % quantile decides, the maximum is printed)
+        ok = kind in (1, 2, 3) and np.all(st == 0) and np.all(stc == 0) and np.quantile(err, 0.99) <= 1e-5 and abs(it.mean() - itc.mean()) <= (1.5 if kind == 3 else 1.0)   # (the small-problem kernel has no polish: about one iteration more)
+        bad += not ok
+        print(f"{name:>14} nZ {hd.nZ:3d} kind {kind} ms {hd.last_step_ms():7.2f} optimal {np.mean(st == 0):.4f} (C port {np.mean(stc == 0):.4f}) "
+              f"iters {it.mean():5.2f} (C port {itc.mean():5.2f}) rel dU diff 99 % {np.quantile(err, 0.99):.1e} max {err.max():.1e} {'ok' if ok else 'FAIL'}", flush=True)
+        hd.close()
+print("patterns", pats, "shapes", len(shapes), "failed", bad)
