@@ -263,8 +263,8 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
  *                      MPCQP_KERNEL_* kind the steps will run on (>= 0) or a negative error code.
  *                      An on-demand kernel that has not been checked on this machine is first compared
  *                      with the runtime-dimension kernel on a few controllers of the handle (one cold
- *                      step, pseudo-random states and set points); it is used only if the two agree -- optimum,
- *                      status and iteration count --
+ *                      step, pseudo-random states and set points); it is used only if the two agree -- optimum and
+ *                      status, and the specialisation does not need half as many iterations again --
  *                      (marker <object>.ok), otherwise it is renamed <object>.bad, the generic kernel
  *                      is used and mpcqp_last_build_error says why.  Objects are keyed by the kernel
  *                      revision AND the identity of the compiler binary that built them.
