@@ -28,23 +28,13 @@ for pat in pats:
     for name in shapes:
         cfg = dataclasses.replace(synth.get_config(name), **PATTERNS[pat])
         name = f"{pat}:{name}"
-        bt = synth.make_batch(cfg, B, seed=11)
-        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=0 if np.isinf(cfg.Cwt) else 1, flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START)
-        hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
-        hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt) if np.isfinite(cfg.Cwt) else None)
-        full = lambda v, n: None if not np.isfinite(v) else np.full((B, n), float(v))
-        hd.set_bounds(U0min=full(cfg.umin, hd.nU), U0max=full(cfg.umax, hd.nU), DUmin=full(cfg.dumin, hd.nDU), DUmax=full(cfg.dumax, hd.nDU),
-                      Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY))
-        kind = hd.prepare()
-        Z = np.zeros((B, hd.nZ))
-        u0, st, it = hd.step(bt["xhat0"], bt["lastu0"], bt["ry"], Z)
-        Zc, _, stc, itc = cport.from_synth(cfg, bt).step(bt["xhat0"], bt["lastu0"], bt["ry"])
-        nDU = hd.nDU
-        err = np.max(np.abs(Z[:, :nDU] - Zc[:, :nDU]), axis=1) / np.maximum(1.0, np.max(np.abs(Zc[:, :nDU]), axis=1))
-        # (a single ill-conditioned instance may sit 1e-4 from the C port at equal objective: the 99 % quantile decides, the maximum is printed)
-        ok = kind in (1, 2, 3) and np.all(st == 0) and np.all(stc == 0) and np.quantile(err, 0.99) <= 1e-5 and abs(it.mean() - itc.mean()) <= (1.5 if kind == 3 else 1.0)   # (the small-problem kernel has no polish: about one iteration more)
+        from tests.parity_util import shape_vs_cport
+        r = shape_vs_cport(cfg, B)
+        # (a single ill-conditioned instance may sit 1e-4 from the C port at equal objective: the 99 % quantile decides, the
+        #  maximum is printed; the small-problem kernel has no polish: about one iteration more)
+        ok = (r["kind"] in (1, 2, 3) and r["optimal"] == 1.0 and r["optimal_cport"] == 1.0 and r["err99"] <= 1e-5 and
+              abs(r["iters"] - r["iters_cport"]) <= (1.5 if r["kind"] == 3 else 1.0))
         bad += not ok
-        print(f"{name:>14} nZ {hd.nZ:3d} kind {kind} ms {hd.last_step_ms():7.2f} optimal {np.mean(st == 0):.4f} (C port {np.mean(stc == 0):.4f}) "
-              f"iters {it.mean():5.2f} (C port {itc.mean():5.2f}) rel dU diff 99 % {np.quantile(err, 0.99):.1e} max {err.max():.1e} {'ok' if ok else 'FAIL'}", flush=True)
-        hd.close()
+        print(f"{name:>20} nZ {r['nZ']:3d} kind {r['kind']} ms {r['ms']:7.2f} optimal {r['optimal']:.4f} (C port {r['optimal_cport']:.4f}) "
+              f"iters {r['iters']:5.2f} (C port {r['iters_cport']:5.2f}) rel dU diff 99 % {r['err99']:.1e} max {r['errmax']:.1e} {'ok' if ok else 'FAIL'}", flush=True)
 print("patterns", pats, "shapes", len(shapes), "failed", bad)

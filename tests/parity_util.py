@@ -690,3 +690,31 @@ def small_kernel_cases(lib=None, B=6):
             lu = mpc.lastu0.copy()
         kinds.append(mpc.hd.kernel_kind())
     return worst, kinds
+
+
+def shape_vs_cport(cfg, B=256, seed=11, lib=None):
+    """One synthetic workload (modelpredictivecontrol.jl_amd/synth.Config: dimensions + constraint pattern) at B
+    controllers through the C-ABI against the oracle's C port (same interior-point iteration on a dense Newton matrix):
+    returns dict(kind, optimal fraction of both, iteration means, relative dU differences).  A step kernel with a wrong
+    Newton matrix converges on its exact residuals -- slowly and with a few per cent of failed solves -- which is what
+    the iteration means and the optimal fraction over a few hundred instances show (scripts/shape_sweep.py)."""
+    from oracle import cport
+    bt = synth.make_batch(cfg, B, seed=seed)
+    hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=0 if np.isinf(cfg.Cwt) else 1,
+                      flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START, lib=lib)
+    hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
+    hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt),
+                   np.full(B, cfg.Cwt) if np.isfinite(cfg.Cwt) else None)
+    full = lambda v, n: None if not np.isfinite(v) else np.full((B, n), float(v))
+    hd.set_bounds(U0min=full(cfg.umin, hd.nU), U0max=full(cfg.umax, hd.nU), DUmin=full(cfg.dumin, hd.nDU),
+                  DUmax=full(cfg.dumax, hd.nDU), Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY))
+    kind = hd.prepare()
+    Z = np.zeros((B, hd.nZ))
+    _, st, it = hd.step(bt["xhat0"], bt["lastu0"], bt["ry"], Z)
+    Zc, _, stc, itc = cport.from_synth(cfg, bt).step(bt["xhat0"], bt["lastu0"], bt["ry"])
+    nDU = hd.nDU
+    err = np.max(np.abs(Z[:, :nDU] - Zc[:, :nDU]), axis=1) / np.maximum(1.0, np.max(np.abs(Zc[:, :nDU]), axis=1))
+    out = dict(kind=kind, nZ=hd.nZ, ms=hd.last_step_ms(), optimal=float(np.mean(st == 0)), optimal_cport=float(np.mean(stc == 0)),
+               iters=float(it.mean()), iters_cport=float(itc.mean()), err99=float(np.quantile(err, 0.99)), errmax=float(err.max()))
+    hd.close()
+    return out

@@ -82,6 +82,25 @@ def test_slack_row_of_shapes_with_nDU_a_multiple_of_16(name, hiplib):
     assert abs(got["iters"].mean() - it_c.mean()) <= 1.0, (got["iters"].mean(), it_c.mean())
 
 
+@pytest.mark.parametrize("name,pattern", [("4,1,1,16,16", "c3"), ("6,2,3,32,31", "c3"), ("6,3,3,21,21", "all"), ("6,2,2,40,32", "yband"),
+                                          ("8,4,4,24,20", "c3"), ("8,3,2,45,42", "all"), ("8,5,4,20,16", "box")])
+def test_shapes_and_constraint_patterns_against_the_c_port(name, pattern, hiplib):
+    """A few hundred instances per shape on its on-demand specialisation (nZ~ = 17 .. 127, around the one-row-per-lane
+    limit, 16-multiples of nu*Hc, four constraint patterns) against the oracle's C port: every instance optimal, the
+    same optimum (99 % quantile; a single ill-conditioned instance may sit further at equal objective), the same number
+    of iterations -- what a handful of instances per family cannot show (scripts/shape_sweep.py, profiles/r3/)."""
+    import dataclasses
+    from tests.parity_util import shape_vs_cport
+    pats = {"c3": {}, "box": dict(ymax=np.inf, dumin=-0.2, dumax=0.2, Cwt=np.inf),
+            "yband": dict(ymin=-1.0, ymax=1.0, umin=-np.inf, umax=np.inf, dumin=-0.3, dumax=0.3),
+            "all": dict(ymin=-1.2, ymax=1.0, dumin=-0.4, dumax=0.4)}
+    r = shape_vs_cport(dataclasses.replace(synth.get_config(name), **pats[pattern]), B=256)
+    assert r["kind"] == mpcqp.api.KERNEL_ONDEMAND, r
+    assert r["optimal"] == 1.0 and r["optimal_cport"] == 1.0, r
+    assert r["err99"] <= TOL and r["errmax"] <= 1e-3, r
+    assert abs(r["iters"] - r["iters_cport"]) <= 1.0, r
+
+
 def test_full_size_properties_C3(hiplib):
     """BASELINE configs[2] at full size (B = 65536): size-independent properties."""
     cfg = synth.C3
