@@ -303,11 +303,14 @@ def main():
         soft_on = Zr[:, -1] > 1e-9 if neps else np.zeros(B, bool)
         active = {"controllers_with_an_active_row": float((act_u.any(axis=(1, 2)) | soft_on).mean()),
                   "input_rows_on_a_bound": float(act_u.mean()), "controllers_with_slack": float(soft_on.mean())}
-        traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/
+        # HBM bytes per launch: counters need rocprofv3 around the process (separate --pmc passes), so this is NOT a
+        # measurement of this run but the figure of the committed passes over the same command (scripts/profile_round.sh);
+        # traffic_source says which
+        traffic, traffic_source = None, None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_k_step.json")))
             if tr["config"] == args.config and tr["batch"] == B:
-                traffic = tr["hbm_bytes_per_launch"]
+                traffic, traffic_source = tr["hbm_bytes_per_launch"], tr.get("source")
         except Exception:
             pass
         out = {
@@ -332,7 +335,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_step", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kms, "flops_per_solve": flops,
+                         "traffic_source": traffic_source, "kernel_ms": kms, "flops_per_solve": flops,
                          "hbm_algorithmic_GBps": algorithmic_bytes(cfg) * B / (kms * 1e-3) / 1e9,
                          "note": "FP64 peak shared by v_fma_f64 and v_mfma_f64 (one datapath: measured, "
                                  "scripts/ubench/mfma_valu_overlap.hip): half the 157.3 TF FP32 rate; flops = "
