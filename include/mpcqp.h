@@ -73,6 +73,11 @@ typedef struct mpcqp_handle_s* mpcqp_handle;
                                             /* start the next solve around them (and the shifted Z̃) */
 #define MPCQP_FLAG_NO_POLISH     (1u << 4)  /* skip the active-set polish of the interior-point iterate */
                                             /* (measurements only: the polish is what bounds the error) */
+#define MPCQP_FLAG_KEEP_ITERATE  (1u << 5)  /* diagnostics: a solve that stops at max_iter returns its iterate as it is  */
+                                            /* (status ITERATION_LIMIT) instead of taking the error branch -- with       */
+                                            /* mpcqp_set_iteration_limit(k) this exposes the k-th interior-point iterate; */
+                                            /* mpcqp_prepare compares the first iterates of an on-demand kernel with the  */
+                                            /* runtime-dimension kernel's this way                                        */
 
 typedef struct {
     int32_t  batch;     /* B: number of independent controllers                              */
@@ -120,6 +125,11 @@ int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const 
  * is set.  Block-diagonal M_Hp: mpcqp_set_output_weight_blocks; dense M_Hp / N_Hc / L_Hp: mpcqp_set_dense_weights. */
 int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
                       const double* Ldiag, const double* Cwt);
+
+/* Interior-point iteration cap of the following steps (0 = default, 80); the analogue of the solver time limit the
+ * reference sets from Ts (src/controller/linmpc.jl:329, src/general.jl:110-121).  With MPCQP_FLAG_KEEP_ITERATE a capped
+ * solve returns its iterate (diagnostics). */
+int mpcqp_set_iteration_limit(mpcqp_handle h, int32_t max_iter);
 
 /* Replace the MPCQP_FLAG_* set of the handle (they are read at every step): e.g. switch between a
  * set point held over the horizon (Ry (ny,B), MPCQP_FLAG_RY_CONSTANT) and a full R̂y (nY,B), or

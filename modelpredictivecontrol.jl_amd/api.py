@@ -26,7 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libmpcqp.so")
 
 # flags / codes of include/mpcqp.h
-FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL, FLAG_NO_POLISH = 1, 2, 4, 8, 16
+FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL, FLAG_NO_POLISH, FLAG_KEEP_ITERATE = 1, 2, 4, 8, 16, 32
 KERNEL_GENERIC, KERNEL_AOT, KERNEL_ONDEMAND, KERNEL_SMALL = 0, 1, 2, 3
 STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
 GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC, GET_AUDIT = 1, 2, 3, 4, 5, 6, 7
@@ -36,7 +36,7 @@ EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_cre
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_last_predmat_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
            "mpcqp_set_output_weight_blocks", "mpcqp_set_dense_weights", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
-           "mpcqp_set_flags", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_lds_bytes", "mpcqp_row_groups", "mpcqp_prebuild",
+           "mpcqp_set_flags", "mpcqp_set_iteration_limit", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_lds_bytes", "mpcqp_row_groups", "mpcqp_prebuild",
            "mpcqp_last_build_error", "mpcqp_multi_create", "mpcqp_multi_destroy", "mpcqp_multi_ndev",
            "mpcqp_multi_handle", "mpcqp_multi_shard", "mpcqp_multi_set_model", "mpcqp_multi_set_weights",
            "mpcqp_multi_set_bounds", "mpcqp_multi_prepare", "mpcqp_multi_step", "mpcqp_multi_gather_device",
@@ -122,6 +122,7 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_output_weight_blocks.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpcqp_set_dense_weights.argtypes = [C.c_void_p] * 4
     lib.mpcqp_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+    lib.mpcqp_set_iteration_limit.argtypes = [C.c_void_p, C.c_int32]
     lib.mpcqp_set_custom_constraints.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     lib.mpcqp_set_custom_bounds.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
@@ -238,6 +239,9 @@ class Handle:
     def set_flags(self, flags):
         _chk(self.lib, self.lib.mpcqp_set_flags(self.h, int(flags)))
         self.flags = int(flags)
+
+    def set_iteration_limit(self, max_iter):
+        _chk(self.lib, self.lib.mpcqp_set_iteration_limit(self.h, int(max_iter)))
 
     def set_current_setpoint(self, ry_now):
         a = None if ry_now is None else _f64(ry_now)

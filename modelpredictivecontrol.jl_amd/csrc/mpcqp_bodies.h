@@ -3092,7 +3092,8 @@ struct Step {
             ++it;
         }
         // never primal-feasible (or NaN) => the reference's error branch (execute.jl:484-489)
-        if (status == ST_ITERATION_LIMIT && !(rpn <= 1e-6 * nh)) status = ST_ERROR;
+        // (MPCQP_FLAG_KEEP_ITERATE: diagnostics -- the iterate after exactly max_iter iterations is what the caller wants)
+        if (status == ST_ITERATION_LIMIT && !(rpn <= 1e-6 * nh) && !(d.flags & 32u)) status = ST_ERROR;
         if (status == ST_ERROR) {
             if (w.lane < n) z[w.lane] = zws;          // mpc.Z̃ .= Z̃s   execute.jl:499-500
             for (int k = w.lane + WAVE; k < n; k += WAVE)

@@ -5,6 +5,7 @@
 
 #include <cstdlib>
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
@@ -91,6 +92,8 @@ struct SpecLib {
     int (*step)(const Dims*, const Model*, const StepIO*, void*) = nullptr;
     int (*hessian)(const Dims*, const Model*, void*) = nullptr;
     bool verified = false;        // compared with the runtime-dimension kernel on this machine (marker <object>.ok)
+    bool no_marker = false;       // the marker was looked for and not found: steps do not stat() again (mpcqp_prepare does)
+    std::string path;             // the object this entry was loaded from
 };
 using SpecKey = std::tuple<int, int, int, int, int, int, unsigned, int>;
 // last field (also the last field of the object name): bit 0 default move blocking, bit 1 dense M_Hp / L_Hp in the gradient,
@@ -117,17 +120,12 @@ static bool dir_writable(const std::string& d) {
     return access(d.c_str(), W_OK | X_OK) == 0;
 }
 
-static std::string cache_dir() {
-    if (const char* e = getenv("MPCQP_CACHE_DIR")) {
-        if (e[0]) { (void)dir_writable(e); return e; }
-    }
-    const std::string local = lib_dir() + "/spec_cache";
-    if (dir_writable(local)) return local;
+static std::string user_cache_dir() {
     std::string base;
     if (const char* x = getenv("XDG_CACHE_HOME")) base = x;
     if (base.empty()) {
         const char* home = getenv("HOME");
-        if (!home || !home[0]) return "";        // no private place to keep shared objects: no on-demand kernels
+        if (!home || !home[0]) return "";        // no private place to keep shared objects
         base = std::string(home) + "/.cache";
         (void)dir_writable(base);
     }
@@ -136,10 +134,50 @@ static std::string cache_dir() {
     return d;
 }
 
+// where NEW files go (objects built here, the .ok / .rejected markers of objects in a read-only directory)
+static std::string cache_dir() {
+    if (const char* e = getenv("MPCQP_CACHE_DIR")) {
+        if (e[0]) { (void)dir_writable(e); return e; }
+    }
+    const std::string local = lib_dir() + "/spec_cache";
+    if (dir_writable(local)) return local;
+    return user_cache_dir();
+}
+
+// where objects are LOOKED UP: the installation's own <library dir>/spec_cache is searched even when it is read-only
+// (the normal deployment: objects shipped by `python -m mpcqp.prebuild` / mpcqp_prebuild on a build host), then the
+// user's cache.  MPCQP_CACHE_DIR replaces both.
+static std::vector<std::string> search_dirs() {
+    std::vector<std::string> v;
+    if (const char* e = getenv("MPCQP_CACHE_DIR")) {
+        if (e[0]) { v.push_back(e); return v; }
+    }
+    v.push_back(lib_dir() + "/spec_cache");
+    const std::string u = user_cache_dir();
+    if (!u.empty() && u != v[0]) v.push_back(u);
+    return v;
+}
+
 // Shared objects are only loaded from a directory that belongs to this user (or root) and that others cannot write.
 static bool cache_dir_trusted(const std::string& d) {
     struct stat sb;
     if (d.empty() || stat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) return false;
+    if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
+    const bool ok = (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+    if (!ok) {
+        static bool told = false;
+        if (!told) {
+            told = true;
+            fprintf(stderr, "[mpcqp] specialisation cache %s is writable by group / others: not used (chmod go-w, or set MPCQP_CACHE_DIR)\n", d.c_str());
+        }
+    }
+    return ok;
+}
+
+// ... and only files that belong to this user (or root) and that others cannot write
+static bool object_trusted(const std::string& so) {
+    struct stat sb;
+    if (stat(so.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
     if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
     return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
@@ -150,19 +188,79 @@ static std::string hipcc_path() {
 }
 
 // identity of the compiler the on-demand kernels are built with (size and mtime of the binary): part of the
-// object name, so that a cache filled by another hipcc is not reused (the same 32-bit value as
-// __graft_entry__.py computes for the objects it pre-builds)
+// object name, so that a cache filled by another hipcc is not reused WHEN THIS MACHINE CAN BUILD ITS OWN (the same
+// 32-bit value as __graft_entry__.py computes for the objects it pre-builds).  0: no compiler here.
 static unsigned compiler_id() {
     struct stat sb;
     if (stat(hipcc_path().c_str(), &sb) != 0) return 0u;
     return (unsigned)(((unsigned long long)sb.st_size * 1000003ull) ^ (unsigned long long)sb.st_mtime);
 }
 
-static std::string spec_name(const Dims& d) {
-    char name[224];
-    snprintf(name, sizeof name, "spec_r%d_c%08x_%d_%d_%d_%d_%d_%d_%x_%d.so", MPCQP_KERNEL_REV, compiler_id(), d.nu, d.ny,
-             d.nxh, d.Hp, d.Hc, d.neps, d.gmask, spec_variant(d));
+static std::string spec_dims_suffix(const Dims& d) {
+    char name[160];
+    snprintf(name, sizeof name, "_%d_%d_%d_%d_%d_%d_%x_%d.so", d.nu, d.ny, d.nxh, d.Hp, d.Hc, d.neps, d.gmask, spec_variant(d));
     return name;
+}
+static std::string spec_rev_prefix() { return "spec_r" + std::to_string(MPCQP_KERNEL_REV) + "_c"; }
+
+// name of the object this machine's compiler builds
+static std::string spec_name(const Dims& d) {
+    char cid[16];
+    snprintf(cid, sizeof cid, "%08x", compiler_id());
+    return spec_rev_prefix() + cid + spec_dims_suffix(d);
+}
+
+// objects rejected by this process whose file could not be renamed (read-only cache)
+static std::mutex g_rej_mu;
+static std::vector<std::string> g_rejected;
+static bool rejected_here(const std::string& so) {
+    std::lock_guard<std::mutex> lock(g_rej_mu);
+    for (const std::string& r : g_rejected) if (r == so) return true;
+    struct stat sb;
+    const size_t sl = so.rfind('/');
+    return stat((cache_dir() + "/" + so.substr(sl + 1) + ".rejected").c_str(), &sb) == 0;
+}
+
+// The object of `d` a step may load: the one this machine's compiler builds (exact name) in any search directory, else
+// -- no compiler here, or a cache filled by a build host with another hipcc -- any object of the same kernel revision and
+// dimensions, `spec_r<rev>_c*_<dims>.so`.  Safe because no object runs before mpcqp_prepare has compared it with the
+// runtime-dimension kernel ON THIS MACHINE (marker .ok); with a local compiler the exact name wins and a foreign object
+// is only used while the local one does not exist (prepare builds it).  "" if there is none.
+static std::string locate_spec(const Dims& d, bool foreign_ok) {
+    const std::string exact = spec_name(d), pre = spec_rev_prefix(), suf = spec_dims_suffix(d);
+    const std::vector<std::string> dirs = search_dirs();
+    for (const std::string& dir : dirs) {
+        if (!cache_dir_trusted(dir)) continue;
+        const std::string so = dir + "/" + exact;
+        if (object_trusted(so) && !rejected_here(so)) return so;
+    }
+    if (!foreign_ok) return "";
+    for (const std::string& dir : dirs) {
+        if (!cache_dir_trusted(dir)) continue;
+        DIR* dp = opendir(dir.c_str());
+        if (!dp) continue;
+        std::string best;
+        while (struct dirent* e = readdir(dp)) {
+            const std::string f = e->d_name;
+            if (f.size() != exact.size() || f.compare(0, pre.size(), pre) != 0 ||
+                f.compare(f.size() - suf.size(), suf.size(), suf) != 0)
+                continue;
+            const std::string so = dir + "/" + f;
+            if (object_trusted(so) && !rejected_here(so) && (best.empty() || so < best)) best = so;
+        }
+        closedir(dp);
+        if (!best.empty()) return best;
+    }
+    return "";
+}
+static std::string locate_spec(const Dims& d) { return locate_spec(d, compiler_id() == 0u || !env_flag("MPCQP_CACHE_STRICT", false)); }
+
+// marker <object>.ok next to the object when its directory is writable, else under the same name in cache_dir()
+static std::string marker_path(const std::string& so, const char* ext) {
+    const size_t sl = so.rfind('/');
+    const std::string dir = so.substr(0, sl);
+    if (access(dir.c_str(), W_OK | X_OK) == 0) return so + ext;
+    return cache_dir() + "/" + so.substr(sl + 1) + ext;
 }
 
 static bool jit_enabled() {
@@ -210,8 +308,16 @@ static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
         if (err) *err = "specialisation cache directory '" + cache + "' is missing, not owned by this user or writable by others (set MPCQP_CACHE_DIR)";
         return -1;
     }
-    struct stat sb;
-    if (stat(so.c_str(), &sb) == 0) return 0;
+    {
+        // an object of this shape that may be loaded exists already (this machine's own, or -- without a compiler here --
+        // one a build host shipped)
+        const std::string have = locate_spec(d, compiler_id() == 0u);
+        if (!have.empty()) { if (path_out) *path_out = have; return 0; }
+    }
+    if (compiler_id() == 0u) {
+        if (err) *err = "no compiler (" + hipcc_path() + ") and no prebuilt object of this shape in the specialisation cache";
+        return -1;
+    }
     if (access(cache.c_str(), W_OK | X_OK) != 0) {
         if (err) *err = "specialisation cache directory " + cache + " is not writable (set MPCQP_CACHE_DIR)";
         return -1;
@@ -259,11 +365,8 @@ static const SpecLib* find_spec(const Dims& d, bool load) {
     auto it = g_spec.find(key);
     if (it != g_spec.end()) return it->second.step ? &it->second : nullptr;
     if (!load) return nullptr;
-    const std::string cdir = cache_dir();
-    if (!cache_dir_trusted(cdir)) return nullptr;
-    const std::string so = cdir + "/" + spec_name(d);
-    struct stat sb;
-    if (stat(so.c_str(), &sb) != 0) return nullptr;              // not built (yet): nothing is remembered
+    const std::string so = locate_spec(d);
+    if (so.empty()) return nullptr;                              // not built (yet): nothing is remembered
     SpecLib sl;
     void* hdl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (hdl) {
@@ -272,6 +375,7 @@ static const SpecLib* find_spec(const Dims& d, bool load) {
         sl.step = (int (*)(const Dims*, const Model*, const StepIO*, void*))dlsym(hdl, "mpcqp_spec_launch_step");
         sl.hessian = (int (*)(const Dims*, const Model*, void*))dlsym(hdl, "mpcqp_spec_launch_hessian");
         if (!sl.matches || !sl.step || !sl.hessian || !sl.matches(&d)) sl = SpecLib{};
+        else sl.path = so;
     } else {
         fprintf(stderr, "[mpcqp] dlopen(%s) failed: %s\n", so.c_str(), dlerror());
     }
@@ -335,30 +439,46 @@ int prebuild_step(const Dims& d, std::string* err) {
 // before it is trusted: `<object>.ok` records that it passed, a failing object is renamed `<object>.bad` and never
 // loaded again (the local hipcc builds these kernels: a compiler that miscompiles them must not go unnoticed).
 bool spec_verified(const Dims& d) {
+    const SpecLib* sl = find_spec(d, true);
+    if (!sl) return false;
+    if (sl->verified) return true;
     struct stat sb;
-    return stat((cache_dir() + "/" + spec_name(d) + ".ok").c_str(), &sb) == 0;
+    const bool ok = stat((sl->path + ".ok").c_str(), &sb) == 0 || stat(marker_path(sl->path, ".ok").c_str(), &sb) == 0;
+    std::lock_guard<std::mutex> lock(g_spec_mu);
+    auto it = g_spec.find(spec_key(d));
+    if (it != g_spec.end() && it->second.step) { it->second.verified = ok; it->second.no_marker = !ok; }
+    return ok;
 }
 void mark_spec_verified(const Dims& d) {
-    if (FILE* f = fopen((cache_dir() + "/" + spec_name(d) + ".ok").c_str(), "w")) fclose(f);
+    const SpecLib* sl = find_spec(d, true);
+    if (!sl) return;
+    // (a marker that cannot be written -- read-only cache and no user cache -- only costs the comparison again in the
+    //  next process: this process remembers)
+    if (FILE* f = fopen(marker_path(sl->path, ".ok").c_str(), "w")) fclose(f);
+    std::lock_guard<std::mutex> lock(g_spec_mu);
+    auto it = g_spec.find(spec_key(d));
+    if (it != g_spec.end() && it->second.step) { it->second.verified = true; it->second.no_marker = false; }
 }
 // the specialisation a STEP may run: loaded AND verified (mpcqp_prepare's self-test, or the marker of an earlier one);
 // an object that some other process, a build pipeline (mpcqp_prebuild) or a prepare without a model put into the cache
-// runs only after this machine has compared it with the runtime-dimension kernel
+// runs only after this machine has compared it with the runtime-dimension kernel.  The marker is looked for once per
+// loaded object (and again by every mpcqp_prepare): a step does no file-system work.
 static const SpecLib* find_verified_spec(const Dims& d) {
     const SpecLib* sl = find_spec(d, true);
     if (!sl) return nullptr;
     if (sl->verified) return sl;
-    if (!spec_verified(d)) return nullptr;
-    std::lock_guard<std::mutex> lock(g_spec_mu);
-    auto it = g_spec.find(spec_key(d));
-    if (it == g_spec.end() || !it->second.step) return nullptr;
-    it->second.verified = true;
-    return &it->second;
+    if (sl->no_marker) return nullptr;
+    return spec_verified(d) ? sl : nullptr;
 }
 
 void reject_spec(const Dims& d) {
-    const std::string so = cache_dir() + "/" + spec_name(d);
-    (void)rename(so.c_str(), (so + ".bad").c_str());
+    std::string so;
+    if (const SpecLib* sl = find_spec(d, true)) so = sl->path;
+    if (!so.empty() && rename(so.c_str(), (so + ".bad").c_str()) != 0) {
+        // read-only cache: remember the rejection in this process and, when there is a writable cache, for the next ones
+        { std::lock_guard<std::mutex> lock(g_rej_mu); g_rejected.push_back(so); }
+        if (FILE* f = fopen(marker_path(so, ".rejected").c_str(), "w")) fclose(f);
+    }
     std::lock_guard<std::mutex> lock(g_spec_mu);
     g_spec[spec_key(d)] = SpecLib{};
 }

@@ -55,7 +55,7 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 7        // 7: ϵ row of shapes with nu Hc a multiple of 16 (objects of revision 6 must not be reused)
+#define MPCQP_KERNEL_REV 8        // 8: MPCQP_FLAG_KEEP_ITERATE (the first-iterates comparison of mpcqp_prepare needs it in both kernels)
 
 namespace mpcqp {
 

@@ -1,0 +1,900 @@
+// ms_bodies.h -- one control period of a LinMPC with the MultipleShooting transcription, one controller per
+// wavefront, stage-structured: the condensed matrices E, H~ are NEVER formed.
+//
+//   decision vector Z = [dU; X^0(k+1..k+Hp)] (+ eps)          /root/reference/src/controller/transcription.jl:5-7
+//   prediction matrices E = [0 diag(C^)], J = diag(D^d)       src/controller/transcription.jl:196-240
+//   the model as equality constraints  E_S Z + F_S = 0         src/controller/transcription.jl:303-414, 913-928
+//   same objective, bounds, softness, slack as SingleShooting  src/controller/construct.jl:837-845, 999-1234
+//   recommended when cond(H~) is large (unstable plants, long horizons)   src/controller/construct.jl:855-866
+//
+// The QP is solved in its stage form.  With xi_t = [x^0(k+t); u0(k+t-1)] (ns = nx^ + nu) the model is
+//     xi_{t+1} = Abar xi_t + Bbar du_t + g_t,   Abar = [A^ B^u; 0 I],  Bbar = [B^u; I],   g_t = [B^d d0(k+t) + f^op - x^op; 0]
+// with a free move du_t only at the first step of a move-blocking interval (construct.jl:597-660); every inequality row
+// touches ONE stage (input bounds: the u part of xi_{t+1}; output bounds: C^ x^0(k+t+1); terminal bounds: x^0(k+Hp);
+// increment bounds: du_t) plus the slack eps.  Interior-point method: the dual-regularised Mehrotra predictor-corrector
+// of the condensed kernels (mpcqp_bodies.h: Step::run -- same starting point, row algebra with one reciprocal per row,
+// step-length rules and termination test) on the iterate (Z, nu, s, lam) with nu the multipliers of the model equations.
+// Every Newton system
+//     [Phi A_eq'; A_eq 0] [dZ; nu+] = -[g^; c],   Phi = blkdiag_t(Q_t, R_t) + arrow border of eps
+// is solved by a RICCATI recursion over the horizon (block elimination of the KKT matrix in stage order):
+//     S = Abar' P_{t+1} Abar,  Lam = R_t + S_uu,  K_t = -Lam^-1 S_u.,  P_t = Q_t + S + S_.u K_t          (backward, matrices)
+//     w = P_{t+1} c_t + p_{t+1},  k_t = -Lam^-1 (r_t + (Abar'w)_u),  p_t = q_t + Abar'w + K_t'(...)        (backward, vectors)
+//     du_t = K_t dxi_t + k_t,  dxi_{t+1} = Abar dxi_t + Bbar du_t + c_t,  nu+_{t+1} = P_{t+1} dxi_{t+1} + p_{t+1}   (forward)
+// (Bbar is the u-column block of Abar, so Bbar'P Abar = S_u. and Bbar'P Bbar = S_uu: one congruence per stage.)  The
+// forward sweep runs on the CLOSED-LOOP dynamics Abar + Bbar K_t, which is what keeps the recursion accurate for unstable
+// plants where powers of A^ (the entries of the condensed E) overflow float64's digits; the defects c_t of the model
+// equations are part of every Newton step, so rounding in X^0 does not accumulate.  The slack couples all soft rows: its
+// column phi of Phi goes through the same recursion once per factorisation (psi = -Phi^-1 phi) and deps follows from the
+// scalar Schur complement, like the arrow border of the MHE kernel (mhe_bodies.h).
+//
+// Written against the wave interface W of mpcqp_bodies.h (gfx950: DevWave; tests/emu: 64 host threads).
+#pragma once
+#include <math.h>
+
+#include "mpcqp_bodies.h"
+#include "mpcqp_types.h"
+
+namespace mpcqp {
+
+// optional outputs of the MultipleShooting step
+struct MsIO {
+    double* Xhat;     // [B][Hp][nxh]  X^0(k+1..k+Hp) at the optimum (the second block of Z), may be null
+    double* defect;   // [B]           max |E_S Z + F_S| at the returned point, may be null
+};
+
+enum { MS_UMIN = 0, MS_UMAX, MS_DUMIN, MS_DUMAX, MS_YMIN, MS_YMAX, MS_XMIN, MS_XMAX, MS_EPS, MS_NGROUP };
+constexpr int MS_NROWARR = 8;     // h, s, lam, rp, gd, pp, cs, wi
+
+struct MsCarve {
+    int A, Bu, C;                       // model: A^ (nx,nx) col-major, B^u (nx,nu) col-major, C^ (ny,nx) col-major
+    int X, V, DU;                       // iterate: x^0(k+t+1), u0(k+t) for t = 0..Hp-1; free moves
+    int NX, NV;                         // multipliers of the model equations (costates nu_{t+1})
+    int dX, dV, dDU, nX, nV;            // Newton direction and its nu+
+    int pX, pV, pDU, qX, qV;            // psi = -Phi^-1 phi and its nu
+    int gX, gV, gDU;                    // gradient of the current solve
+    int fX, fV, fDU;                    // border column phi
+    int cX, cV;                         // defects c_t
+    int gv;                             // g_t (x part), [Hp][nx]
+    int ry, ru;                         // targets: C^ x - ry[t] with ry = R^y - D^d d^ (nY); u - ru (nU)
+    int QY, QV, RD;                     // stage Hessian diagonals: output weight 2M + D_Y (nY), 2L + D_U (nU), 2N + D_dU (nDU)
+    int CX, CD;                         // C^ x of the iterate / of a direction (nY)
+    int P, K, Li, pv, kk;               // factor: P_t packed lower [Hp][npk], K_t [Hc][nu][ns], Lam^-1 [Hc][nu][nu], p_t [Hp][ns], k_t [nDU]
+    int S, T, wv, av;                   // stage work: S, T (ns x ns), w, a (ns)
+    int x0, lu;                         // x^0(k), u0(k-1)
+    int rows[MS_NROWARR];
+    int rowoff[MS_NGROUP + 1];
+    int jl, ctrl;                       // int tables: first step of block j [Hc+1]; block that starts at step t or -1 [Hp]
+    int nrows, total;
+};
+
+MPCQP_HD inline int ms_group_count(const Dims& d, int g) {
+    switch (g) {
+        case MS_UMIN: case MS_UMAX: return d.nU;
+        case MS_DUMIN: case MS_DUMAX: return d.nDU;
+        case MS_YMIN: case MS_YMAX: return d.nY;
+        case MS_XMIN: case MS_XMAX: return d.nxh;
+        default: return 1;
+    }
+}
+MPCQP_HD inline bool ms_group_on(const Dims& d, const Model& m, int g) {
+    switch (g) {
+        case MS_UMIN: return m.U0min != nullptr;
+        case MS_UMAX: return m.U0max != nullptr;
+        case MS_DUMIN: return m.DUmin != nullptr;
+        case MS_DUMAX: return m.DUmax != nullptr;
+        case MS_YMIN: return m.Y0min != nullptr;
+        case MS_YMAX: return m.Y0max != nullptr;
+        case MS_XMIN: return m.x0min != nullptr;
+        case MS_XMAX: return m.x0max != nullptr;
+        default: return d.neps != 0;
+    }
+}
+
+MPCQP_HD inline MsCarve make_ms_carve(const Dims& d, const Model& m) {
+    MsCarve c{};
+    const int nx = d.nxh, nu = d.nu, ny = d.ny, ns = nx + nu, Hp = d.Hp, Hc = d.Hc;
+    const int nX = nx * Hp, nV = nu * Hp, nDU = d.nDU, nY = d.nY, npk = ns * (ns + 1) / 2;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };
+    c.A = take(nx * nx); c.Bu = take(nx * nu); c.C = take(ny * nx);
+    c.X = take(nX); c.V = take(nV); c.DU = take(nDU);
+    c.NX = take(nX); c.NV = take(nV);
+    c.dX = take(nX); c.dV = take(nV); c.dDU = take(nDU); c.nX = take(nX); c.nV = take(nV);
+    c.pX = take(nX); c.pV = take(nV); c.pDU = take(nDU); c.qX = take(nX); c.qV = take(nV);
+    c.gX = take(nX); c.gV = take(nV); c.gDU = take(nDU);
+    c.fX = take(nX); c.fV = take(nV); c.fDU = take(nDU);
+    c.cX = take(nX); c.cV = take(nV);
+    c.gv = take(nX);
+    c.ry = take(nY); c.ru = take(nV);
+    c.QY = take(nY); c.QV = take(nV); c.RD = take(nDU);
+    c.CX = take(nY); c.CD = take(nY);
+    c.P = take(Hp * npk); c.K = take(Hc * nu * ns); c.Li = take(Hc * nu * nu); c.pv = take(Hp * ns); c.kk = take(nDU);
+    c.S = take(ns * ns); c.T = take(ns * ns); c.wv = take(ns); c.av = take(ns);
+    c.x0 = take(nx); c.lu = take(nu);
+    int r = 0;
+    for (int g = 0; g < MS_NGROUP; ++g) {
+        c.rowoff[g] = r;
+        if (ms_group_on(d, m, g)) r += ms_group_count(d, g);
+    }
+    c.rowoff[MS_NGROUP] = r;
+    c.nrows = r;
+    for (int a = 0; a < MS_NROWARR; ++a) c.rows[a] = take(r);
+    c.jl = take((Hc + 2) / 2 + 1);
+    c.ctrl = take((Hp + 1) / 2 + 1);
+    c.total = o;
+    return c;
+}
+
+template <class W>
+struct MsStep {
+    W& w;
+    const Dims& d;
+    const Model& m;
+    const StepIO& io;
+    const int b;
+    double* sm;
+    const MsCarve c;
+    const int nx, nu, ny, nd, ns, Hp, Hc, nDU, nY, nXt, nVt, npk;
+    int *jlt, *ctrl;
+    double *A, *Bu, *Cm;
+    double *rh, *rs, *rl, *rrp, *rgd, *rpp, *rcs, *rwi;
+    double eps = 0.0, deps = 0.0, delta, nh = 1.0, wsum = 0.0;
+    int mact = 0;
+
+    MPCQP_HD MsStep(W& w_, const Dims& d_, const Model& m_, const StepIO& io_, int b_, double* sm_)
+        : w(w_), d(d_), m(m_), io(io_), b(b_), sm(sm_), c(make_ms_carve(d_, m_)), nx(d_.nxh), nu(d_.nu), ny(d_.ny), nd(d_.nd),
+          ns(d_.nxh + d_.nu), Hp(d_.Hp), Hc(d_.Hc), nDU(d_.nDU), nY(d_.nY), nXt(d_.nxh * d_.Hp), nVt(d_.nu * d_.Hp),
+          npk((d_.nxh + d_.nu) * (d_.nxh + d_.nu + 1) / 2) {
+        jlt = reinterpret_cast<int*>(sm + c.jl);
+        ctrl = reinterpret_cast<int*>(sm + c.ctrl);
+        A = sm + c.A; Bu = sm + c.Bu; Cm = sm + c.C;
+        rh = sm + c.rows[0]; rs = sm + c.rows[1]; rl = sm + c.rows[2]; rrp = sm + c.rows[3];
+        rgd = sm + c.rows[4]; rpp = sm + c.rows[5]; rcs = sm + c.rows[6]; rwi = sm + c.rows[7];
+        delta = d.dual_reg;
+    }
+
+    MPCQP_HD bool on(int g) const { return c.rowoff[g + 1] > c.rowoff[g]; }
+    MPCQP_HD static int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+    MPCQP_HD bool fin(int r) const { return rh[r] < BIG; }
+
+    // softness of row k of group g (reference defaults: 0 for u and du, 1 for y and x^end; construct.jl:909-913)
+    MPCQP_HD double softness(int g, int k) const {
+        if (!d.neps) return 0.0;
+        const double* p = nullptr;
+        double def = 0.0;
+        size_t n = 0;
+        switch (g) {
+            case MS_UMIN: p = m.C_umin; n = d.nU; break;
+            case MS_UMAX: p = m.C_umax; n = d.nU; break;
+            case MS_DUMIN: p = m.C_dumin; n = d.nDU; break;
+            case MS_DUMAX: p = m.C_dumax; n = d.nDU; break;
+            case MS_YMIN: p = m.C_ymin; n = d.nY; def = 1.0; break;
+            case MS_YMAX: p = m.C_ymax; n = d.nY; def = 1.0; break;
+            case MS_XMIN: p = m.c_x0min; n = d.nxh; def = 1.0; break;
+            case MS_XMAX: p = m.c_x0max; n = d.nxh; def = 1.0; break;
+            default: return 0.0;
+        }
+        return p ? p[(size_t)b * n + k] : def;
+    }
+
+    // fn(group, k, row index) for every row slot owned by this lane
+    template <class Fn>
+    MPCQP_HD void for_rows(Fn fn) {
+        for (int g = 0; g < MS_NGROUP; ++g) {
+            const int r0 = c.rowoff[g], n = c.rowoff[g + 1] - r0;
+            for (int k = w.lane; k < n; k += WAVE) fn(g, k, r0 + k);
+        }
+    }
+
+    // ---- set-up: model, tables, references, bounds ---------------------------------------------------
+    MPCQP_HD void load() {
+        const double* gA = m.Ahat + (size_t)b * nx * nx;
+        const double* gB = m.Bu + (size_t)b * nx * nu;
+        const double* gC = m.C + (size_t)b * ny * nx;
+        for (int i = w.lane; i < nx * nx; i += WAVE) A[i] = gA[i];
+        for (int i = w.lane; i < nx * nu; i += WAVE) Bu[i] = gB[i];
+        for (int i = w.lane; i < ny * nx; i += WAVE) Cm[i] = gC[i];
+        for (int i = w.lane; i <= Hc; i += WAVE) jlt[i] = d.default_nb ? (i < Hc ? i : Hp) : (i < Hc ? m.jl[i] : Hp);
+        for (int t = w.lane; t < Hp; t += WAVE) ctrl[t] = -1;
+        for (int i = w.lane; i < nx; i += WAVE) sm[c.x0 + i] = io.xhat0[(size_t)b * nx + i];
+        for (int i = w.lane; i < nu; i += WAVE) sm[c.lu + i] = io.lastu0[(size_t)b * nu + i];
+        w.sync();
+        for (int j = w.lane; j < Hc; j += WAVE) ctrl[jlt[j]] = j;
+        // g_t = B^d d0(k+t) + (f^op - x^op): d0(k) for t = 0, D^0 block t-1 after (transcription.jl:386-389)
+        for (int i = w.lane; i < nXt; i += WAVE) {
+            const int t = i / nx, r = i - t * nx;
+            double acc = m.dop ? m.dop[(size_t)b * nx + r] : 0.0;
+            for (int e = 0; e < nd; ++e) {
+                const double de = t == 0 ? io.d0[(size_t)b * nd + e] : io.Dhat0[(size_t)b * d.nD + (t - 1) * nd + e];
+                acc += m.Bd[(size_t)b * nx * nd + r + nx * e] * de;
+            }
+            sm[c.gv + i] = acc;
+        }
+        // output target of stage t: R^y - Yop - D^d d^0(k+t+1)  (F = J D^0, transcription.jl:232; execute.jl:262-266)
+        const bool rconst = d.flags & 1u;
+        for (int r = w.lane; r < nY; r += WAVE) {
+            const int t = r / ny, a = r - t * ny;
+            double acc = rconst ? io.Ry[(size_t)b * ny + a] : io.Ry[(size_t)b * nY + r];
+            for (int e = 0; e < nd; ++e) acc -= m.Dd[(size_t)b * ny * nd + a + ny * e] * io.Dhat0[(size_t)b * d.nD + t * nd + e];
+            sm[c.ry + r] = acc;
+        }
+        for (int r = w.lane; r < nVt; r += WAVE) sm[c.ru + r] = io.Ru ? io.Ru[(size_t)b * d.nU + r] : 0.0;
+        w.sync();
+    }
+
+    // bounds of the rows.  A row acts on the stage variable itself, so (unlike the condensed form) its right-hand side
+    // is the bound: U0min/U0max on u0(k+t); Y0min/Y0max - D^d d^0 on C^ x^0(k+t+1); x^0min/x^0max on x^0(k+Hp).
+    MPCQP_HD void build_rows() {
+        int cnt = 0;
+        double hmax = 0.0;
+        for_rows([&](int g, int k, int r) {
+            double bound = INFINITY;
+            switch (g) {
+                case MS_UMIN: bound = -m.U0min[(size_t)b * d.nU + k]; break;
+                case MS_UMAX: bound = m.U0max[(size_t)b * d.nU + k]; break;
+                case MS_DUMIN: bound = -m.DUmin[(size_t)b * nDU + k]; break;
+                case MS_DUMAX: bound = m.DUmax[(size_t)b * nDU + k]; break;
+                case MS_YMIN:
+                case MS_YMAX: {
+                    const int t = k / ny, a = k - t * ny;
+                    double dterm = 0.0;
+                    for (int e = 0; e < nd; ++e) dterm += m.Dd[(size_t)b * ny * nd + a + ny * e] * io.Dhat0[(size_t)b * d.nD + t * nd + e];
+                    bound = g == MS_YMIN ? -(m.Y0min[(size_t)b * nY + k] - dterm) : m.Y0max[(size_t)b * nY + k] - dterm;
+                    break;
+                }
+                case MS_XMIN: bound = -m.x0min[(size_t)b * nx + k]; break;
+                case MS_XMAX: bound = m.x0max[(size_t)b * nx + k]; break;
+                default: bound = 0.0; break;          // -eps <= 0
+            }
+            const bool ok = fabs(bound) < BIG && bound == bound;
+            rh[r] = ok ? bound : 2.0 * BIG;
+            rs[r] = 1.0; rl[r] = ok ? 1.0 : 0.0; rrp[r] = 0.0; rgd[r] = 0.0; rpp[r] = 0.0; rwi[r] = 0.0;
+            rcs[r] = softness(g, k);
+            if (ok) { ++cnt; hmax = fmax(hmax, fabs(bound)); }
+        });
+        mact = w.isum(cnt);
+        wsum = (double)mact;
+        nh = 1.0 + w.maxv(hmax);
+        w.sync();
+    }
+
+    // ---- model operators ---------------------------------------------------------------------------------
+    // state of stage t (t = -1: the given x^0(k), u0(k-1); directions: zero)
+    MPCQP_HD double xat(const double* Xv, int t, int i, bool dir) const { return t >= 0 ? Xv[t * nx + i] : (dir ? 0.0 : sm[c.x0 + i]); }
+    MPCQP_HD double vat(const double* Vv, int t, int cc, bool dir) const { return t >= 0 ? Vv[t * nu + cc] : (dir ? 0.0 : sm[c.lu + cc]); }
+
+    // X, V <- the model rolled out from DU (sequential over the horizon, lanes over the state)
+    MPCQP_HD void rollout(const double* DU, double* Xv, double* Vv) {
+        for (int t = 0; t < Hp; ++t) {
+            const int j = ctrl[t];
+            for (int cc = w.lane; cc < nu; cc += WAVE) Vv[t * nu + cc] = vat(Vv, t - 1, cc, false) + (j >= 0 ? DU[j * nu + cc] : 0.0);
+            w.sync();
+            for (int i = w.lane; i < nx; i += WAVE) {
+                double acc = sm[c.gv + t * nx + i];
+                for (int k = 0; k < nx; ++k) acc += A[i + nx * k] * xat(Xv, t - 1, k, false);
+                for (int cc = 0; cc < nu; ++cc) acc += Bu[i + nx * cc] * Vv[t * nu + cc];
+                Xv[t * nx + i] = acc;
+            }
+            w.sync();
+        }
+    }
+
+    // out[(t,a)] = C^ Xv_t
+    MPCQP_HD void C_apply(const double* Xv, double* out) {
+        for (int r = w.lane; r < nY; r += WAVE) {
+            const int t = r / ny, a = r - t * ny;
+            double acc = 0.0;
+            for (int k = 0; k < nx; ++k) acc += Cm[a + ny * k] * Xv[t * nx + k];
+            out[r] = acc;
+        }
+        w.sync();
+    }
+
+    // (G z)[row] without the slack column, from the stage variables (CXv = C^ Xv)
+    MPCQP_HD double prim(int g, int k, const double* Xv, const double* Vv, const double* DUv, const double* CXv, double e) const {
+        switch (g) {
+            case MS_UMIN: return -Vv[k];
+            case MS_UMAX: return Vv[k];
+            case MS_DUMIN: return -DUv[k];
+            case MS_DUMAX: return DUv[k];
+            case MS_YMIN: return -CXv[k];
+            case MS_YMAX: return CXv[k];
+            case MS_XMIN: return -Xv[(Hp - 1) * nx + k];
+            case MS_XMAX: return Xv[(Hp - 1) * nx + k];
+            default: return -e;
+        }
+    }
+
+    // gX, gV, gDU (+ returned slack entry) <- G' wv(row) summed onto `base` gradients (which may be null = 0):
+    // wv evaluated on finite rows.  Output arrays are OVERWRITTEN.
+    template <class Fn>
+    MPCQP_HD double Gt_apply(Fn wv, double* oX, double* oV, double* oDU, bool with_cost) {
+        // per-row weights into rgd (scratch), slack entry accumulated
+        double eacc = 0.0;
+        for_rows([&](int g, int k, int r) {
+            double v = 0.0;
+            if (fin(r)) { v = wv(r); eacc -= (g == MS_EPS ? 1.0 : rcs[r]) * v; }
+            rgd[r] = v;
+        });
+        eacc = w.sum(eacc);
+        w.sync();
+        auto rowv = [&](int g, int k) { return on(g) ? rgd[c.rowoff[g] + k] : 0.0; };
+        // outputs: C^'(tYmax - tYmin) (+ cost gradient 2 M (C^ x - ry))
+        for (int i = w.lane; i < nXt; i += WAVE) {
+            const int t = i / nx, k = i - t * nx;
+            double acc = 0.0;
+            for (int a = 0; a < ny; ++a) {
+                const int r = t * ny + a;
+                double ty = rowv(MS_YMAX, r) - rowv(MS_YMIN, r);
+                if (with_cost) ty += 2.0 * m.Mdiag[(size_t)b * nY + r] * (sm[c.CX + r] - sm[c.ry + r]);
+                acc += Cm[a + ny * k] * ty;
+            }
+            if (t == Hp - 1) acc += rowv(MS_XMAX, k) - rowv(MS_XMIN, k);
+            oX[i] = acc;
+        }
+        for (int i = w.lane; i < nVt; i += WAVE) {
+            double acc = rowv(MS_UMAX, i) - rowv(MS_UMIN, i);
+            if (with_cost) acc += 2.0 * m.Ldiag[(size_t)b * d.nU + i] * (sm[c.V + i] - sm[c.ru + i]);
+            oV[i] = acc;
+        }
+        for (int i = w.lane; i < nDU; i += WAVE) {
+            double acc = rowv(MS_DUMAX, i) - rowv(MS_DUMIN, i);
+            if (with_cost) acc += 2.0 * m.Ndiag[(size_t)b * nDU + i] * sm[c.DU + i];
+            oDU[i] = acc;
+        }
+        w.sync();
+        return eacc;
+    }
+
+    // ---- Riccati factorisation of the current Phi (QY, QV, RD hold the stage diagonals) --------------------
+    // Abar'-congruence of the packed symmetric Pn (cost-to-go of stage t+1) into S (full ns x ns)
+    MPCQP_HD void congruence(const double* Pn) {
+        double* S = sm + c.S;
+        double* T = sm + c.T;
+        // T = Pn Abar : T[i][j<nx] = sum_k Pn[i][k] A[k][j];  T[i][nx+cc] = sum_k Pn[i][k] Bu[k][cc] + Pn[i][nx+cc]
+        for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
+            const int i = idx / ns, j = idx - i * ns;
+            double acc = 0.0;
+            if (j < nx) {
+                for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * A[k + nx * j];
+            } else {
+                const int cc = j - nx;
+                for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * Bu[k + nx * cc];
+                acc += Pn[pidx(i, j)];
+            }
+            T[idx] = acc;
+        }
+        w.sync();
+        // S = Abar' T (lower triangle computed, mirrored)
+        for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
+            const int i = idx / ns, j = idx - i * ns;
+            if (j > i) continue;
+            double acc = 0.0;
+            if (i < nx) {
+                for (int k = 0; k < nx; ++k) acc += A[k + nx * i] * T[k * ns + j];
+            } else {
+                const int cc = i - nx;
+                for (int k = 0; k < nx; ++k) acc += Bu[k + nx * cc] * T[k * ns + j];
+                acc += T[i * ns + j];
+            }
+            S[i * ns + j] = acc;
+            S[j * ns + i] = acc;
+        }
+        w.sync();
+    }
+
+    // Q_t of stage t (0-based: the stage that holds x^0(k+t+1), u0(k+t)) added to the packed Pt
+    MPCQP_HD void add_Q(double* Pt, int t) {
+        for (int idx = w.lane; idx < npk; idx += WAVE) {
+            // (i, j), i >= j, from the packed index
+            int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+            while (i * (i + 1) / 2 > idx) --i;
+            while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+            const int j = idx - i * (i + 1) / 2;
+            double acc = 0.0;
+            if (i < nx) {           // C^' diag(QY_t) C^  (+ terminal rows on the last stage)
+                for (int a = 0; a < ny; ++a) acc += Cm[a + ny * i] * sm[c.QY + t * ny + a] * Cm[a + ny * j];
+                if (t == Hp - 1 && i == j) acc += xterm(i);
+            } else if (i == j) {
+                acc = sm[c.QV + t * nu + (i - nx)];
+            }
+            Pt[idx] += acc;
+        }
+    }
+    // D~ of the terminal rows of state i (registers of whoever asks: the rows are in LDS)
+    MPCQP_HD double xterm(int i) const {
+        double acc = 0.0;
+        if (on(MS_XMIN) && fin(c.rowoff[MS_XMIN] + i)) acc += rl[c.rowoff[MS_XMIN] + i] * rwi[c.rowoff[MS_XMIN] + i];
+        if (on(MS_XMAX) && fin(c.rowoff[MS_XMAX] + i)) acc += rl[c.rowoff[MS_XMAX] + i] * rwi[c.rowoff[MS_XMAX] + i];
+        return acc;
+    }
+
+    // in-place inverse of the symmetric positive definite nu x nu matrix M (Gauss-Jordan, lanes over the entries);
+    // returns false on a non-positive pivot (wave-uniform)
+    MPCQP_HD bool invert_spd(double* M) {
+        bool ok = true;
+        for (int p = 0; p < nu; ++p) {
+            const double piv = M[p * nu + p];
+            w.sync();
+            if (!(piv > 0.0)) ok = false;
+            const double ip = 1.0 / (piv > 0.0 ? piv : 1.0);
+            // row p scaled, others eliminated; the pivot column becomes the inverse's column
+            double upd[1];
+            (void)upd;
+            for (int idx = w.lane; idx < nu * nu; idx += WAVE) {
+                const int i = idx / nu, j = idx - i * nu;
+                const double mip = M[i * nu + p], mpj = M[p * nu + j];
+                double v;
+                if (i == p && j == p) v = ip;
+                else if (i == p) v = mpj * ip;
+                else if (j == p) v = -mip * ip;
+                else v = M[idx] - mip * mpj * ip;
+                sm[c.T + idx] = v;
+            }
+            w.sync();
+            for (int idx = w.lane; idx < nu * nu; idx += WAVE) M[idx] = sm[c.T + idx];
+            w.sync();
+        }
+        return ok;
+    }
+
+    MPCQP_HD bool factor() {
+        double* P = sm + c.P;
+        double* S = sm + c.S;
+        bool ok = true;
+        // terminal stage: P_{Hp} = Q_{Hp}
+        double* PT = P + (size_t)(Hp - 1) * npk;
+        for (int i = w.lane; i < npk; i += WAVE) PT[i] = 0.0;
+        w.sync();
+        add_Q(PT, Hp - 1);
+        w.sync();
+        for (int t = Hp - 1; t >= 0; --t) {
+            // stage t maps xi_t (stored at t-1; given for t = 0) to xi_{t+1} (stored at t)
+            congruence(P + (size_t)t * npk);
+            const int j = ctrl[t];
+            double* K = sm + c.K + (size_t)(j >= 0 ? j : 0) * nu * ns;
+            double* Li = sm + c.Li + (size_t)(j >= 0 ? j : 0) * nu * nu;
+            if (j >= 0) {
+                for (int idx = w.lane; idx < nu * nu; idx += WAVE) {
+                    const int a = idx / nu, e = idx - a * nu;
+                    Li[idx] = S[(nx + a) * ns + nx + e] + (a == e ? sm[c.RD + j * nu + a] : 0.0);
+                }
+                w.sync();
+                ok = invert_spd(Li) && ok;
+                // K = -Lam^-1 S_u.
+                for (int idx = w.lane; idx < nu * ns; idx += WAVE) {
+                    const int a = idx / ns, col = idx - a * ns;
+                    double acc = 0.0;
+                    for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * S[(nx + e) * ns + col];
+                    K[idx] = -acc;
+                }
+                w.sync();
+            }
+            if (t == 0) break;                     // xi_0 is data: no cost-to-go needed
+            double* Pt = P + (size_t)(t - 1) * npk;
+            for (int idx = w.lane; idx < npk; idx += WAVE) {
+                int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+                while (i * (i + 1) / 2 > idx) --i;
+                while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+                const int jj = idx - i * (i + 1) / 2;
+                double acc = S[i * ns + jj];
+                if (j >= 0)
+                    for (int e = 0; e < nu; ++e) acc += S[i * ns + nx + e] * K[e * ns + jj];
+                Pt[idx] = acc;
+            }
+            w.sync();
+            add_Q(Pt, t - 1);
+            w.sync();
+        }
+        return ok;
+    }
+
+    // ---- one solve with the current factor -----------------------------------------------------------------
+    // minimise 1/2 dz'Phi dz + g'dz  s.t.  dxi_{t+1} = Abar dxi_t + Bbar du_t + c_t   (c = 0 when !defect)
+    // in: gX, gV (stage gradients), gDU; out: oX, oV, oDU (the step), nuX, nuV (multipliers nu+)
+    MPCQP_HD void sweep(const double* gX, const double* gV, const double* gDU, bool defect,
+                        double* oX, double* oV, double* oDU, double* nuX, double* nuV) {
+        double* P = sm + c.P;
+        double* pv = sm + c.pv;
+        double* wv = sm + c.wv;
+        double* av = sm + c.av;
+        double* kk = sm + c.kk;
+        // backward: p_t for t = Hp..1 (stored at t-1), k_j
+        for (int i = w.lane; i < ns; i += WAVE) pv[(Hp - 1) * ns + i] = i < nx ? gX[(Hp - 1) * nx + i] : gV[(Hp - 1) * nu + i - nx];
+        w.sync();
+        for (int t = Hp - 1; t >= 0; --t) {
+            const double* Pn = P + (size_t)t * npk;
+            const double* pn = pv + t * ns;
+            // w = P_{t+1} c_t + p_{t+1}
+            for (int i = w.lane; i < ns; i += WAVE) {
+                double acc = pn[i];
+                if (defect) {
+                    for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * sm[c.cX + t * nx + k];
+                    for (int cc = 0; cc < nu; ++cc) acc += Pn[pidx(i, nx + cc)] * sm[c.cV + t * nu + cc];
+                }
+                wv[i] = acc;
+            }
+            w.sync();
+            // a = Abar' w
+            for (int i = w.lane; i < ns; i += WAVE) {
+                double acc = 0.0;
+                if (i < nx) {
+                    for (int k = 0; k < nx; ++k) acc += A[k + nx * i] * wv[k];
+                } else {
+                    for (int k = 0; k < nx; ++k) acc += Bu[k + nx * (i - nx)] * wv[k];
+                    acc += wv[i];
+                }
+                av[i] = acc;
+            }
+            w.sync();
+            const int j = ctrl[t];
+            if (j >= 0) {
+                const double* Li = sm + c.Li + (size_t)j * nu * nu;
+                // k_j = -Lam^-1 (g_u + (Abar'w)_u)
+                for (int a = w.lane; a < nu; a += WAVE) {
+                    double acc = 0.0;
+                    for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * (gDU[j * nu + e] + av[nx + e]);
+                    kk[j * nu + a] = -acc;
+                }
+                w.sync();
+            }
+            if (t == 0) break;
+            const double* K = sm + c.K + (size_t)(j >= 0 ? j : 0) * nu * ns;
+            // p_t = g_xi[t] + a + K'(g_u + a_u)   and -K' Lam k = K'(g_u + a_u)  =>  use  K'(g_u + a_u)
+            for (int i = w.lane; i < ns; i += WAVE) {
+                double acc = (i < nx ? gX[(t - 1) * nx + i] : gV[(t - 1) * nu + i - nx]) + av[i];
+                if (j >= 0)
+                    for (int e = 0; e < nu; ++e) acc += K[e * ns + i] * (gDU[j * nu + e] + av[nx + e]);
+                pv[(t - 1) * ns + i] = acc;
+            }
+            w.sync();
+        }
+        // forward
+        for (int t = 0; t < Hp; ++t) {
+            const int j = ctrl[t];
+            if (j >= 0) {
+                const double* K = sm + c.K + (size_t)j * nu * ns;
+                for (int a = w.lane; a < nu; a += WAVE) {
+                    double acc = kk[j * nu + a];
+                    if (t > 0) {
+                        for (int k = 0; k < nx; ++k) acc += K[a * ns + k] * oX[(t - 1) * nx + k];
+                        for (int cc = 0; cc < nu; ++cc) acc += K[a * ns + nx + cc] * oV[(t - 1) * nu + cc];
+                    }
+                    oDU[j * nu + a] = acc;
+                }
+                w.sync();
+            }
+            for (int cc = w.lane; cc < nu; cc += WAVE)
+                oV[t * nu + cc] = vat(oV, t - 1, cc, true) + (j >= 0 ? oDU[j * nu + cc] : 0.0) + (defect ? sm[c.cV + t * nu + cc] : 0.0);
+            w.sync();
+            // dx_{t+1} = A^ dx_t + B^u (dv_t + du_t) + c_x  (dv_t + du_t = dv_{t+1} - c_v)
+            for (int i = w.lane; i < nx; i += WAVE) {
+                double acc = defect ? sm[c.cX + t * nx + i] : 0.0;
+                for (int k = 0; k < nx; ++k) acc += A[i + nx * k] * xat(oX, t - 1, k, true);
+                for (int cc = 0; cc < nu; ++cc)
+                    acc += Bu[i + nx * cc] * (oV[t * nu + cc] - (defect ? sm[c.cV + t * nu + cc] : 0.0));
+                oX[t * nx + i] = acc;
+            }
+            w.sync();
+            // nu+_{t+1} = P_{t+1} dxi_{t+1} + p_{t+1}
+            const double* Pn = P + (size_t)t * npk;
+            for (int i = w.lane; i < ns; i += WAVE) {
+                double acc = pv[t * ns + i];
+                for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * oX[t * nx + k];
+                for (int cc = 0; cc < nu; ++cc) acc += Pn[pidx(i, nx + cc)] * oV[t * nu + cc];
+                if (i < nx) nuX[t * nx + i] = acc; else nuV[t * nu + i - nx] = acc;
+            }
+            w.sync();
+        }
+    }
+
+    MPCQP_HD double dot_z(const double* aX, const double* aV, const double* aDU, const double* bX, const double* bV, const double* bDU) {
+        double acc = 0.0;
+        for (int i = w.lane; i < nXt; i += WAVE) acc += aX[i] * bX[i];
+        for (int i = w.lane; i < nVt; i += WAVE) acc += aV[i] * bV[i];
+        for (int i = w.lane; i < nDU; i += WAVE) acc += aDU[i] * bDU[i];
+        return w.sum(acc);
+    }
+
+    // ---- residuals of the iterate: r_p (rows), mu, defects c, dual residual with the current nu ----------
+    MPCQP_HD void residuals(double& mu, double& rpn, double& rdn, double& ndd, double& cn, double& xs) {
+        double* X = sm + c.X; double* V = sm + c.V; double* DU = sm + c.DU;
+        C_apply(X, sm + c.CX);
+        double musum = 0.0, rpmax = 0.0;
+        for_rows([&](int g, int k, int r) {
+            if (!fin(r)) return;
+            const double gz = prim(g, k, X, V, DU, sm + c.CX, eps) - (g == MS_EPS ? 0.0 : rcs[r] * eps);
+            const double v = gz + rs[r] - rh[r];
+            rrp[r] = v;
+            rpmax = fmax(rpmax, fabs(v));
+            musum += rs[r] * rl[r];
+        });
+        mu = mact ? w.sum(musum) / wsum : 0.0;
+        rpn = w.maxv(rpmax);
+        // defects c_t = Abar xi_t + Bbar du_t + g_t - xi_{t+1}
+        double cmax = 0.0, xmax = 0.0;
+        for (int i = w.lane; i < nVt; i += WAVE) {
+            const int t = i / nu, cc = i - t * nu, j = ctrl[t];
+            const double v = vat(V, t - 1, cc, false) + (j >= 0 ? DU[j * nu + cc] : 0.0) - V[i];
+            sm[c.cV + i] = v;
+            cmax = fmax(cmax, fabs(v));
+        }
+        w.sync();
+        for (int i = w.lane; i < nXt; i += WAVE) {
+            const int t = i / nx, r = i - t * nx;
+            double acc = sm[c.gv + i] - X[i];
+            for (int k = 0; k < nx; ++k) acc += A[r + nx * k] * xat(X, t - 1, k, false);
+            for (int cc = 0; cc < nu; ++cc) acc += Bu[r + nx * cc] * (V[t * nu + cc] + sm[c.cV + t * nu + cc]);
+            sm[c.cX + i] = acc;
+            cmax = fmax(cmax, fabs(acc));
+            xmax = fmax(xmax, fabs(X[i]));
+        }
+        cn = w.maxv(cmax);
+        xs = 1.0 + w.maxv(xmax);
+        // gradient of the Lagrangian without the model multipliers: cost + G'lam  (into gX, gV, gDU)
+        const double ge = Gt_apply([&](int r) { return rl[r]; }, sm + c.gX, sm + c.gV, sm + c.gDU, true);
+        // + model multipliers: r_xi_t = g_t - nu_t + Abar' nu_{t+1};  r_u_j = g_u + (Abar' nu_{t+1})_u at t = j_l
+        double mx = 0.0, sc = 0.0;
+        const double* NX = sm + c.NX; const double* NV = sm + c.NV;
+        for (int i = w.lane; i < nXt + nVt; i += WAVE) {
+            const bool isx = i < nXt;
+            const int ii = isx ? i : i - nXt;
+            const int t = isx ? ii / nx : ii / nu, k = isx ? ii - t * nx : ii - t * nu;
+            double g0 = isx ? sm[c.gX + ii] : sm[c.gV + ii];
+            double nu_t = isx ? NX[ii] : NV[ii];
+            double an = 0.0;                     // (Abar' nu_{t+2})[component]
+            if (t + 1 < Hp) {
+                if (isx) {
+                    for (int kk2 = 0; kk2 < nx; ++kk2) an += A[kk2 + nx * k] * NX[(t + 1) * nx + kk2];
+                } else {
+                    for (int kk2 = 0; kk2 < nx; ++kk2) an += Bu[kk2 + nx * k] * NX[(t + 1) * nx + kk2];
+                    an += NV[(t + 1) * nu + k];
+                }
+            }
+            const double r = g0 - nu_t + an;
+            mx = fmax(mx, fabs(r));
+            sc = fmax(sc, fmax(fabs(g0), fmax(fabs(nu_t), fabs(an))));
+        }
+        for (int i = w.lane; i < nDU; i += WAVE) {
+            const int j = i / nu, cc = i - j * nu, t = jlt[j];
+            double an = NV[t * nu + cc];
+            for (int kk2 = 0; kk2 < nx; ++kk2) an += Bu[kk2 + nx * cc] * NX[t * nx + kk2];
+            const double g0 = sm[c.gDU + i];
+            const double r = g0 + an;
+            mx = fmax(mx, fabs(r));
+            sc = fmax(sc, fmax(fabs(g0), fabs(an)));
+        }
+        if (d.neps) {
+            const double re = 2.0 * m.Cwt[b] * eps + ge;
+            mx = fmax(mx, fabs(re));
+            sc = fmax(sc, fmax(fabs(2.0 * m.Cwt[b] * eps), fabs(ge)));
+        }
+        rdn = w.maxv(mx);
+        ndd = 1.0 + w.maxv(sc);
+        w.sync();
+    }
+
+    // row step of the dual-regularised system (mpcqp_bodies.h: Step::row_step)
+    MPCQP_HD void row_step(int r, double rc, double& ds, double& dl) const {
+        const double wi = rwi[r], a = rrp[r] + rgd[r];
+        dl = wi * fma(rl[r], a, -rc);
+        ds = -wi * fma(rs[r], a, delta * rc);
+    }
+
+    // One Newton solve with the current factor: rc(row) given; on return dX, dV, dDU, deps hold the step, nX, nV the
+    // multipliers nu+, rgd[row] = (G dz)[row].
+    template <class Fn>
+    MPCQP_HD void newton(Fn rc, double phipsi, double phiee) {
+        // g^ = cost gradient + G'(lam + D~ rp - wi rc)
+        const double ge0 = Gt_apply([&](int r) { return rl[r] + rwi[r] * (rl[r] * rrp[r] - rc(r)); }, sm + c.gX, sm + c.gV, sm + c.gDU, true);
+        sweep(sm + c.gX, sm + c.gV, sm + c.gDU, true, sm + c.dX, sm + c.dV, sm + c.dDU, sm + c.nX, sm + c.nV);
+        deps = 0.0;
+        if (d.neps) {
+            const double ge = 2.0 * m.Cwt[b] * eps + ge0;
+            const double fy = dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.dX, sm + c.dV, sm + c.dDU);
+            deps = -(ge + fy) / (phiee + phipsi);
+            for (int i = w.lane; i < nXt; i += WAVE) { sm[c.dX + i] += deps * sm[c.pX + i]; sm[c.nX + i] += deps * sm[c.qX + i]; }
+            for (int i = w.lane; i < nVt; i += WAVE) { sm[c.dV + i] += deps * sm[c.pV + i]; sm[c.nV + i] += deps * sm[c.qV + i]; }
+            for (int i = w.lane; i < nDU; i += WAVE) sm[c.dDU + i] += deps * sm[c.pDU + i];
+            w.sync();
+        }
+        C_apply(sm + c.dX, sm + c.CD);
+        for_rows([&](int g, int k, int r) {
+            if (!fin(r)) return;
+            rgd[r] = prim(g, k, sm + c.dX, sm + c.dV, sm + c.dDU, sm + c.CD, deps) - (g == MS_EPS ? 0.0 : rcs[r] * deps);
+        });
+        w.sync();
+    }
+
+    static constexpr int ST_OPTIMAL = 0, ST_ITERATION_LIMIT = 1, ST_ERROR = 2;
+
+    MPCQP_HD int run(int& iters_out, double& defect_out) {
+        double* X = sm + c.X; double* V = sm + c.V; double* DU = sm + c.DU;
+        // warm start: dU shifted (transcription.jl:1001-1004), X^0 rolled out from it, multipliers of the model 0
+        const double* Zg = io.Z + (size_t)b * d.nZ;
+        const bool cold = d.flags & 2u;
+        for (int k = w.lane; k < nDU; k += WAVE) DU[k] = (!cold && k < nDU - nu) ? Zg[k + nu] : 0.0;
+        eps = (!cold && d.neps) ? Zg[d.nZ - 1] : 0.0;
+        for (int i = w.lane; i < nXt; i += WAVE) sm[c.NX + i] = 0.0;
+        for (int i = w.lane; i < nVt; i += WAVE) sm[c.NV + i] = 0.0;
+        w.sync();
+        rollout(DU, X, V);
+        const double eps_ws = eps;
+        double mu = 0.0, rpn = 0.0, rdn = 0.0, ndd = 1.0, cn = 0.0, xs = 1.0;
+        int status = ST_ITERATION_LIMIT, it = 0;
+        // starting point of the rows: s = max(h - G z, 1), lam = 10 / s   (Step::run)
+        C_apply(X, sm + c.CX);
+        for_rows([&](int g, int k, int r) {
+            if (!fin(r)) return;
+            const double gz = prim(g, k, X, V, DU, sm + c.CX, eps) - (g == MS_EPS ? 0.0 : rcs[r] * eps);
+            rs[r] = fmax(rh[r] - gz, 1.0);
+            rl[r] = 10.0 / rs[r];
+        });
+        w.sync();
+        double step_c = 1e300, zabs_c = 0.0;
+        const int max_iter = mact ? d.max_iter : 1;
+        while (true) {
+            if (chol_broke_ && delta < 1e-8) { delta *= 100.0; chol_broke_ = false; }
+            residuals(mu, rpn, rdn, ndd, cn, xs);
+            if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn) || !(cn == cn)) { status = ST_ERROR; break; }
+            const bool conv = mu <= d.gap_tol && rdn <= d.res_tol * ndd && rpn <= 10.0 * d.res_tol * nh && cn <= d.res_tol * xs &&
+                              step_c <= 1e-6 * fmax(1.0, zabs_c);
+            if (conv && (mact || it > 0)) { status = ST_OPTIMAL; break; }
+            if (it >= max_iter) break;
+            // D~ of the rows -> stage diagonals, border column phi, Phi_ee
+            double ee = 0.0;
+            for_rows([&](int g, int k, int r) {
+                double dt = 0.0;
+                if (fin(r)) {
+                    const double wi = 1.0 / fma(delta, rl[r], rs[r]);
+                    rwi[r] = wi;
+                    dt = rl[r] * wi;
+                    const double cs = g == MS_EPS ? 1.0 : rcs[r];
+                    ee += cs * cs * dt;
+                }
+                rpp[r] = dt;           // (scratch: D~ of the row)
+            });
+            ee = w.sum(ee);
+            w.sync();
+            auto dt_ = [&](int g, int k) { return on(g) ? rpp[c.rowoff[g] + k] : 0.0; };
+            auto cs_ = [&](int g, int k) { return on(g) ? rcs[c.rowoff[g] + k] : 0.0; };
+            for (int r = w.lane; r < nY; r += WAVE) {
+                sm[c.QY + r] = 2.0 * m.Mdiag[(size_t)b * nY + r] + dt_(MS_YMIN, r) + dt_(MS_YMAX, r);
+                sm[c.CD + r] = cs_(MS_YMIN, r) * dt_(MS_YMIN, r) - cs_(MS_YMAX, r) * dt_(MS_YMAX, r);      // tB of the output rows
+            }
+            for (int r = w.lane; r < nVt; r += WAVE) {
+                sm[c.QV + r] = 2.0 * m.Ldiag[(size_t)b * d.nU + r] + dt_(MS_UMIN, r) + dt_(MS_UMAX, r);
+                sm[c.fV + r] = cs_(MS_UMIN, r) * dt_(MS_UMIN, r) - cs_(MS_UMAX, r) * dt_(MS_UMAX, r);
+            }
+            for (int r = w.lane; r < nDU; r += WAVE) {
+                sm[c.RD + r] = 2.0 * m.Ndiag[(size_t)b * nDU + r] + dt_(MS_DUMIN, r) + dt_(MS_DUMAX, r);
+                sm[c.fDU + r] = cs_(MS_DUMIN, r) * dt_(MS_DUMIN, r) - cs_(MS_DUMAX, r) * dt_(MS_DUMAX, r);
+            }
+            w.sync();
+            for (int i = w.lane; i < nXt; i += WAVE) {
+                const int t = i / nx, k = i - t * nx;
+                double acc = 0.0;
+                for (int a = 0; a < ny; ++a) acc += Cm[a + ny * k] * sm[c.CD + t * ny + a];
+                if (t == Hp - 1) acc += cs_(MS_XMIN, k) * dt_(MS_XMIN, k) - cs_(MS_XMAX, k) * dt_(MS_XMAX, k);
+                sm[c.fX + i] = acc;
+            }
+            w.sync();
+            if (!factor()) chol_broke_ = true;
+            double phipsi = 0.0;
+            const double phiee = d.neps ? 2.0 * m.Cwt[b] + ee : 1.0;
+            if (d.neps) {
+                // psi = -Phi^-1 phi (no defects), its multipliers q
+                sweep(sm + c.fX, sm + c.fV, sm + c.fDU, false, sm + c.pX, sm + c.pV, sm + c.pDU, sm + c.qX, sm + c.qV);
+                phipsi = dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.pX, sm + c.pV, sm + c.pDU);
+            }
+            // restore rpp (it carried D~): not needed -- newton() overwrites it per pass below
+            double smu = 0.0, tmax = 1.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                const double cpp = pass ? 1.0 : 0.0;
+                if (pass == 0) for_rows([&](int, int, int r) { rpp[r] = 0.0; });
+                w.sync();
+                newton([&](int r) { return fma(cpp, rpp[r], fma(rs[r], rl[r], -smu)); }, phipsi, phiee);
+                double ppsum = 0.0;
+                tmax = pass ? 1e-300 : 1.0;
+                for_rows([&](int, int, int r) {
+                    if (!fin(r)) return;
+                    double ds, dl;
+                    row_step(r, fma(cpp, rpp[r], fma(rs[r], rl[r], -smu)), ds, dl);
+                    tmax = fmax(tmax, -ds / rs[r]);
+                    tmax = fmax(tmax, -dl / rl[r]);
+                    rpp[r] = pass ? ds : ds * dl;
+                    rgd[r] = pass ? dl : rgd[r];
+                    ppsum += ds * dl;
+                });
+                if (pass == 0) {
+                    if (!mact) break;
+                    const double aaff = 1.0 / w.maxv(tmax);
+                    const double muaff = (1.0 - aaff) * mu + aaff * aaff * w.sum(ppsum) / wsum;
+                    double sig = muaff / mu;
+                    sig = sig * sig * sig;
+                    smu = sig * mu;
+                }
+                w.sync();
+            }
+            double alpha = 1.0;
+            if (mact) {
+                const double amin = 1.0 / w.maxv(tmax);
+                const double ahi = fmin(1.0, 0.9999 * amin);
+                double pmin = 1e300, psum = 0.0;
+                for_rows([&](int, int, int r) {
+                    if (!fin(r)) return;
+                    const double p = (rs[r] + ahi * rpp[r]) * (rl[r] + ahi * rgd[r]);
+                    pmin = fmin(pmin, p);
+                    psum += p;
+                });
+                pmin = w.minv(pmin);
+                psum = w.sum(psum);
+                alpha = (pmin * wsum >= 0.01 * psum) ? ahi : fmin(1.0, 0.99 * amin);
+                for_rows([&](int, int, int r) {
+                    if (!fin(r)) return;
+                    rs[r] += alpha * rpp[r];
+                    rl[r] += alpha * rgd[r];
+                });
+            }
+            double stc = 0.0, zab = 0.0;
+            for (int k = w.lane; k < nDU; k += WAVE) {
+                const double st = alpha * sm[c.dDU + k];
+                stc = fmax(stc, fabs(st)); zab = fmax(zab, fabs(DU[k]));
+                DU[k] += st;
+            }
+            for (int i = w.lane; i < nXt; i += WAVE) { X[i] += alpha * sm[c.dX + i]; sm[c.NX + i] += alpha * (sm[c.nX + i] - sm[c.NX + i]); }
+            for (int i = w.lane; i < nVt; i += WAVE) { V[i] += alpha * sm[c.dV + i]; sm[c.NV + i] += alpha * (sm[c.nV + i] - sm[c.NV + i]); }
+            eps += alpha * deps;
+            step_c = w.maxv(stc); zabs_c = w.maxv(zab);
+            w.sync();
+            ++it;
+        }
+        if (status == ST_ITERATION_LIMIT && !(rpn <= 1e-6 * nh && cn <= 1e-6 * xs) && !(d.flags & 32u)) status = ST_ERROR;
+        if (status == ST_ERROR) {          // mpc.Z~ .= Z~s   (execute.jl:499-500)
+            for (int k = w.lane; k < nDU; k += WAVE) DU[k] = (!cold && k < nDU - nu) ? Zg[k + nu] : 0.0;
+            eps = eps_ws;
+            w.sync();
+            rollout(DU, X, V);
+        }
+        iters_out = it;
+        defect_out = cn;
+        if (io.audit && w.lane == 0) {
+            double* au = io.audit + (size_t)b * 4;
+            au[0] = mu; au[1] = rdn / ndd; au[2] = rpn / nh; au[3] = 0.0;
+        }
+        return status;
+    }
+    bool chol_broke_ = false;
+};
+
+template <class W>
+MPCQP_HD void ms_step_body(W& w, const Dims& d, const Model& m, const StepIO& io, const MsIO& ms, int b, double* sm) {
+    MsStep<W> st(w, d, m, io, b, sm);
+    st.load();
+    st.build_rows();
+    int iters = 0;
+    double defect = 0.0;
+    const int status = st.run(iters, defect);
+    const double* DU = sm + st.c.DU;
+    for (int k = w.lane; k < d.nDU; k += WAVE) io.Z[(size_t)b * d.nZ + k] = DU[k];
+    if (d.neps && w.lane == 0) io.Z[(size_t)b * d.nZ + d.nZ - 1] = st.eps;
+    for (int k = w.lane; k < d.nu; k += WAVE) io.u0[(size_t)b * d.nu + k] = DU[k] + io.lastu0[(size_t)b * d.nu + k];
+    if (io.Yhat0) {                // predict!: Y^0 = C^ X^0 + D^d D^0  (transcription.jl:1136-1145 with E = [0 diag(C^)])
+        st.C_apply(sm + st.c.X, sm + st.c.CX);
+        for (int r = w.lane; r < d.nY; r += WAVE) {
+            const int t = r / d.ny, a = r - t * d.ny;
+            double acc = sm[st.c.CX + r];
+            for (int e = 0; e < d.nd; ++e) acc += m.Dd[(size_t)b * d.ny * d.nd + a + d.ny * e] * io.Dhat0[(size_t)b * d.nD + t * d.nd + e];
+            io.Yhat0[(size_t)b * d.nY + r] = acc;
+        }
+    }
+    if (ms.Xhat)
+        for (int i = w.lane; i < d.nxh * d.Hp; i += WAVE) ms.Xhat[(size_t)b * d.nxh * d.Hp + i] = sm[st.c.X + i];
+    if (w.lane == 0) {
+        io.status[b] = status;
+        if (io.iters) io.iters[b] = iters;
+        if (ms.defect) ms.defect[b] = defect;
+    }
+}
+
+}  // namespace mpcqp

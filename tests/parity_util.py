@@ -293,7 +293,7 @@ def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
     return out
 
 
-def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False):
+def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, kinds=None):
     """One randomly drawn controller family (dimensions, move blocking, which bounds exist, hard /
     soft mix, terminal bounds, measured disturbance, Cwt finite or Inf) as a batch of B DIFFERENT
     controllers of that family -- every member has its own model, weights, operating points, bound
@@ -383,6 +383,8 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False):
     gpu.initstate(st(lambda m: m["u_prev"]))
     worst = None
     for k in range(2):
+        if kinds is not None and k == 1:          # (the first moveinput prepared the kernel of the handle)
+            kinds.append((gpu.hd.kernel_kind(), gpu.hd.nZ))
         for m in mem:
             rg, model = m["rg"], m["model"]
             m["ry"] = model.yop + rg.standard_normal(ny) * (1.5 if k == 0 else 0.5)
@@ -412,7 +414,7 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False):
     return worst
 
 
-def run_random_case2(seed, lib=None, B=2, small=False):
+def run_random_case2(seed, lib=None, B=2, small=False, kinds=None):
     """Like run_random_case, for the horizon-wide forms: time-varying Umin/Umax/Ymin/Ymax vectors
     (with ±Inf holes), R̂y / R̂u / D̂ trajectories, a block-diagonal M_Hp, and (every other seed)
     custom linear constraints Wy/Wu/Wd/Wr.  Returns the worst relative ΔU error over certified steps."""
@@ -480,6 +482,8 @@ def run_random_case2(seed, lib=None, B=2, small=False):
             worst = e if worst is None else max(worst, e)
         elif e > 1e-4:                    # uncertified oracle point that differs: nobody to compare
             break                         # with, and the two loops would part ways from here on
+        if kinds is not None and k == 0:
+            kinds.append((gpu.hd.kernel_kind(), gpu.hd.nZ))
         uo = orc.moveinput(x0, ry, d, Dhat=Dhat, Rhaty=Rhaty, Rhatu=Rhatu)
         if seed % 2 == 1:
             assert np.abs(gpu.getinfo()["W"][B - 1] - orc.getinfo()["W"]).max() <= 1e-5

@@ -20,6 +20,19 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+def assert_specialised(kinds):
+    """Every handle of a family ran on the kernel its shape is entitled to: a specialisation (ahead-of-time, on-demand
+    or the small-problem kernel) up to nZ~ = 128, the runtime-dimension kernel beyond.  An on-demand kernel that
+    mpcqp_prepare rejected would show up here as KERNEL_GENERIC (round 3: a rejected object passed its family test on
+    the fallback); conftest.py also turns the library's fallback warning into an error for every GPU test."""
+    assert kinds, "the family did not report its kernel"
+    for kind, nZ in kinds:
+        if nZ <= 128:
+            assert kind in (mpcqp.api.KERNEL_AOT, mpcqp.api.KERNEL_ONDEMAND, mpcqp.api.KERNEL_SMALL), (kind, nZ)
+        else:
+            assert kind == mpcqp.api.KERNEL_GENERIC, (kind, nZ)
+
+
 @pytest.mark.parametrize("name,B", [("C2", 256), ("C3", 192)])
 def test_condensation_tables_match_oracle(name, B, hiplib):
     """K1/K2: Σ_m, K, H̃ and per-step F, q̃ against the dense restatement (a4, a8, a11)."""
@@ -587,8 +600,10 @@ def test_random_controller_families_on_gpu(seed, hiplib):
     infinite Cwt: each family gets its own on-demand specialisation and is stepped twice (the second
     step from the shifted warm start) against the certified oracle optimum."""
     from tests.parity_util import run_random_case
-    e = run_random_case(seed, B=5)
+    kinds = []
+    e = run_random_case(seed, B=5, kinds=kinds)
     assert e is not None and e <= TOL, e
+    assert_specialised(kinds)
 
 
 @pytest.mark.parametrize("seed", [2000, 2004, 2014, 2021, 2028, 2083])
@@ -598,8 +613,10 @@ def test_families_near_wave_limit(seed, hiplib):
     Hc=21, nZ̃ = 64) are the two that exposed the out-of-line cholesky()/EtDE_add() miscompilation
     (csrc/mpcqp_types.h, MPCQP_HD)."""
     from tests.parity_util import run_random_case
-    e = run_random_case(seed, B=3, large=True)
+    kinds = []
+    e = run_random_case(seed, B=3, large=True, kinds=kinds)
     assert e is not None and e <= TOL, e
+    assert_specialised(kinds)
 
 
 @pytest.mark.parametrize("seed", [3000, 3004, 3008, 3010])
@@ -608,8 +625,10 @@ def test_families_beyond_one_row_per_lane(seed, hiplib):
     rows of the factorisation (Step::cholesky_big / solve_big); same families, same oracle, same
     tolerance as the one-row-per-lane kernels."""
     from tests.parity_util import run_random_case
-    e = run_random_case(seed, B=3, huge=True)
+    kinds = []
+    e = run_random_case(seed, B=3, huge=True, kinds=kinds)
     assert e is not None and e <= TOL, e
+    assert_specialised(kinds)
 
 
 @pytest.mark.parametrize("seed", list(range(6)))
@@ -617,8 +636,10 @@ def test_random_horizon_wide_forms_on_gpu(seed, hiplib):
     """Time-varying Umin/Umax/Ymin/Ymax vectors with ±Inf holes, R̂y / R̂u / D̂ trajectories, a
     block-diagonal M_Hp with a dense terminal block and (odd seeds) custom linear constraints."""
     from tests.parity_util import run_random_case2
-    e = run_random_case2(seed, B=4)
+    kinds = []
+    e = run_random_case2(seed, B=4, kinds=kinds)
     assert e is not None and e <= TOL, e
+    assert_specialised(kinds)
 
 
 def test_setmodel_after_first_step_on_gpu(hiplib):
@@ -637,6 +658,7 @@ def test_multiple_shooting_known_answers_on_gpu(hiplib):
     assert np.allclose(r["yend"], 15.0, atol=1e-2) and r["defect"] <= 1e-9 and r["yerr"] <= 1e-8
 
 
+@pytest.mark.expects_generic_fallback
 def test_rejected_specialisation_falls_back_to_generic_kernel(hiplib, tmp_path, monkeypatch):
     """mpcqp_prepare checks a fresh on-demand kernel against the runtime-dimension kernel; one that fails the check
     (forced here with a negative tolerance, in a private cache directory) is renamed *.bad and the handle runs --
