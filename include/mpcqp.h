@@ -126,6 +126,23 @@ int mpcqp_set_model(mpcqp_handle h, const double* Ahat, const double* Bu, const 
 int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
                       const double* Ldiag, const double* Cwt);
 
+/* Transcription of the handle (the `transcription` keyword of LinMPC, src/controller/linmpc.jl:205-216):
+ *   MPCQP_SINGLE_SHOOTING    Z = ΔU, the condensed QP (default; kernels K1-K3)
+ *   MPCQP_MULTIPLE_SHOOTING  Z = [ΔU; X̂0], the model as equality constraints (src/controller/transcription.jl:196-240,
+ *                            303-414, 913-928): solved in its stage form by a Riccati recursion inside the interior-point
+ *                            iteration -- what the reference recommends when cond(H̃) is large (unstable plants, long
+ *                            horizons; src/controller/construct.jl:855-866).  Same objective, bounds and softness, hence the
+ *                            same optimal ΔU; mpcqp_step writes Z̃ = [ΔU; ϵ] as always and X̂0 is read with
+ *                            mpcqp_get(MPCQP_GET_XHAT_MS).
+ * Not every handle can run MultipleShooting: mpcqp_transcription_supported returns 0 when it can, else a bit mask
+ * (1 block / dense weight matrices, 2 custom linear constraints, 4 stage data beyond 160 KB of LDS, 8 KEEP_QP / WARM_DUAL
+ * flags); a step of an unsupported MultipleShooting handle returns MPCQP_ERR_UNSUPPORTED (the Python mirror then keeps
+ * the SingleShooting kernels and says so). */
+#define MPCQP_SINGLE_SHOOTING    0
+#define MPCQP_MULTIPLE_SHOOTING  1
+int mpcqp_set_transcription(mpcqp_handle h, int32_t transcription);
+int mpcqp_transcription_supported(mpcqp_handle h);
+
 /* Interior-point iteration cap of the following steps (0 = default, 80); the analogue of the solver time limit the
  * reference sets from Ts (src/controller/linmpc.jl:329, src/general.jl:110-121).  With MPCQP_FLAG_KEEP_ITERATE a capped
  * solve returns its iterate (diagnostics). */
@@ -238,6 +255,9 @@ int mpcqp_recondense_device(mpcqp_handle h, void* stream);
 #define MPCQP_GET_FVEC      6
 #define MPCQP_GET_AUDIT     7   /* (4,B) of the last step: final complementarity gap mu, dual residual / its scale, primal
                                  * residual / its scale, 1.0 if the returned point passed the active-set polish's KKT check */
+#define MPCQP_GET_XHAT_MS   8   /* (nx̂,Hp,B): X̂0(k+1..k+Hp) of the last MultipleShooting step -- the second block of the
+                                 * reference's decision vector Z = [ΔU; X̂0] (src/controller/transcription.jl:5-7) */
+#define MPCQP_GET_MS_DEFECT 9   /* (B): max |E_S Z + F_S| (defect of the model equations, transcription.jl:303-327) of it */
 int mpcqp_get(mpcqp_handle h, int which, double* out);
 
 /* ---- next row: the SteadyKalmanFilter steps on both sides of moveinput! --------
@@ -296,6 +316,8 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
 #define MPCQP_KERNEL_SMALL     3   /* nZ~ <= 16 with box and input-bound rows only: four controllers per wavefront
                                     * (csrc/mpcqp_small_bodies.h); a step that fuses the Kalman steps (mpcqp_loop_device)
                                     * runs on the kernel the other rules select */
+#define MPCQP_KERNEL_MS        4   /* MultipleShooting handles (mpcqp_set_transcription): the stage-structured kernel
+                                    * (csrc/ms_bodies.h): Riccati recursion over the horizon, H̃ and E never formed */
 int mpcqp_prepare(mpcqp_handle h);
 /* LDS bytes one problem needs in the step kernel (160 KB per CU: the number of problems resident per CU follows). */
 int mpcqp_lds_bytes(mpcqp_handle h);

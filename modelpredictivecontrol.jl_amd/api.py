@@ -27,16 +27,17 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libmpcqp.so")
 
 # flags / codes of include/mpcqp.h
 FLAG_RY_CONSTANT, FLAG_COLD_START, FLAG_KEEP_QP, FLAG_WARM_DUAL, FLAG_NO_POLISH, FLAG_KEEP_ITERATE = 1, 2, 4, 8, 16, 32
-KERNEL_GENERIC, KERNEL_AOT, KERNEL_ONDEMAND, KERNEL_SMALL = 0, 1, 2, 3
+KERNEL_GENERIC, KERNEL_AOT, KERNEL_ONDEMAND, KERNEL_SMALL, KERNEL_MS = 0, 1, 2, 3, 4
+SINGLE_SHOOTING, MULTIPLE_SHOOTING = 0, 1
 STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_ERROR = 0, 1, 2
-GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC, GET_AUDIT = 1, 2, 3, 4, 5, 6, 7
+GET_HESSIAN, GET_STEPRESP, GET_KMAT, GET_BVEC, GET_QTILDE, GET_FVEC, GET_AUDIT, GET_XHAT_MS, GET_MS_DEFECT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 EXPORTS = ("mpcqp_version", "mpcqp_strerror", "mpcqp_last_hip_error", "mpcqp_create",
            "mpcqp_destroy", "mpcqp_get_sizes", "mpcqp_set_model", "mpcqp_set_weights",
            "mpcqp_set_bounds", "mpcqp_step", "mpcqp_step_device", "mpcqp_loop_device", "mpcqp_recondense_device",
            "mpcqp_get", "mpcqp_last_step_ms", "mpcqp_last_condense_ms", "mpcqp_last_predmat_ms", "mpcqp_kf_set",
            "mpcqp_kf_correct", "mpcqp_kf_predict", "mpcqp_kf_correct_device", "mpcqp_kf_predict_device",
            "mpcqp_set_output_weight_blocks", "mpcqp_set_dense_weights", "mpcqp_set_custom_constraints", "mpcqp_set_custom_bounds",
-           "mpcqp_set_flags", "mpcqp_set_iteration_limit", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_lds_bytes", "mpcqp_row_groups", "mpcqp_prebuild",
+           "mpcqp_set_flags", "mpcqp_set_iteration_limit", "mpcqp_set_transcription", "mpcqp_transcription_supported", "mpcqp_set_current_setpoint", "mpcqp_prepare", "mpcqp_kernel_kind", "mpcqp_lds_bytes", "mpcqp_row_groups", "mpcqp_prebuild",
            "mpcqp_last_build_error", "mpcqp_multi_create", "mpcqp_multi_destroy", "mpcqp_multi_ndev",
            "mpcqp_multi_handle", "mpcqp_multi_shard", "mpcqp_multi_set_model", "mpcqp_multi_set_weights",
            "mpcqp_multi_set_bounds", "mpcqp_multi_prepare", "mpcqp_multi_step", "mpcqp_multi_gather_device",
@@ -123,6 +124,8 @@ def load_library(path: str | None = None):
     lib.mpcqp_set_dense_weights.argtypes = [C.c_void_p] * 4
     lib.mpcqp_set_flags.argtypes = [C.c_void_p, C.c_uint32]
     lib.mpcqp_set_iteration_limit.argtypes = [C.c_void_p, C.c_int32]
+    lib.mpcqp_set_transcription.argtypes = [C.c_void_p, C.c_int32]
+    lib.mpcqp_transcription_supported.argtypes = [C.c_void_p]
     lib.mpcqp_set_custom_constraints.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     lib.mpcqp_set_custom_bounds.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.mpcqp_step.argtypes = [C.c_void_p] + [C.c_void_p] * 11
@@ -240,6 +243,14 @@ class Handle:
         _chk(self.lib, self.lib.mpcqp_set_flags(self.h, int(flags)))
         self.flags = int(flags)
 
+    def set_transcription(self, transcription):
+        """MPCQP_SINGLE_SHOOTING / MPCQP_MULTIPLE_SHOOTING (the stage-structured kernel, csrc/ms_bodies.h)."""
+        _chk(self.lib, self.lib.mpcqp_set_transcription(self.h, int(transcription)))
+
+    def transcription_supported(self):
+        """0 when the handle's transcription can run; else the reason mask of include/mpcqp.h."""
+        return self.lib.mpcqp_transcription_supported(self.h)
+
     def set_iteration_limit(self, max_iter):
         _chk(self.lib, self.lib.mpcqp_set_iteration_limit(self.h, int(max_iter)))
 
@@ -331,7 +342,8 @@ class Handle:
     def get(self, which):
         shape = {GET_HESSIAN: (self.B, self.nZ, self.nZ), GET_STEPRESP: (self.B, self.Hp, self.nu, self.ny),
                  GET_KMAT: (self.B, self.nxhat, self.nY), GET_BVEC: (self.B, self.nY),
-                 GET_QTILDE: (self.B, self.nZ), GET_FVEC: (self.B, self.nY), GET_AUDIT: (self.B, 4)}[which]
+                 GET_QTILDE: (self.B, self.nZ), GET_FVEC: (self.B, self.nY), GET_AUDIT: (self.B, 4),
+                 GET_XHAT_MS: (self.B, self.Hp, self.nxhat), GET_MS_DEFECT: (self.B,)}[which]
         out = np.empty(shape)
         _chk(self.lib, self.lib.mpcqp_get(self.h, which, _ptr(out)))
         return out
@@ -534,11 +546,12 @@ class BatchLinMPC:
                  Lwt=None, M_Hp=None, N_Hc=None, L_Hp=None, Cwt=1e5, Wy=None, Wu=None, Wd=None, Wr=None, uop=None, yop=None, dop=None, xhop=None, fhop=None, device=0,
                  cold_start=False, keep_qp=False, warm_dual=False, max_iter=0, gap_tol=0.0, res_tol=0.0, dual_reg=0.0,
                  transcription="SingleShooting", lib=None):
-        # `transcription` (LinMPC keyword, linmpc.jl:288-316).  For a LinModel the MultipleShooting QP
-        # (Z = [ΔU; X̂0] with the model as equality constraints, transcription.jl:217-240, 373-414) has the same
-        # optimal ΔU as the condensed one: the batch is solved by the condensed kernels either way, and getinfo
-        # returns the decision vector in the chosen transcription's layout.  The sparse structured solve that
-        # makes MultipleShooting attractive for ill-conditioned H̃ is NOT what runs here.
+        # `transcription` (LinMPC keyword, linmpc.jl:288-316).  MultipleShooting (Z = [ΔU; X̂0] with the model as
+        # equality constraints, transcription.jl:217-240, 373-414, 913-928) runs on the stage-structured kernel of
+        # csrc/ms_bodies.h (Riccati recursion inside the interior-point iteration; H̃ and E are never formed): what the
+        # reference recommends for unstable plants / long horizons, construct.jl:855-866.  Handles that kernel does not
+        # take (block / dense weight matrices, custom linear constraints, stage data beyond the LDS) keep the condensed
+        # kernels -- same optimal ΔU -- with a warning; getinfo returns Z̃ in the transcription's layout either way.
         if transcription not in ("SingleShooting", "MultipleShooting"):
             raise NotImplementedError(f"transcription {transcription!r}: only SingleShooting / MultipleShooting (LinModel)")
         self.transcription = transcription
@@ -867,7 +880,18 @@ class BatchLinMPC:
         if self.nw > 0 and not held:               # r̂e(k) = ry(k) for the Wr term (execute.jl:351)
             self.hd.set_current_setpoint(ry - self.yop)
         if not self._prepared:                     # like JuMP's model build: before the loop, not in mpcqp_step
-            self.kernel = self.hd.prepare()
+            self._ms_kernel = False
+            if self.transcription == "MultipleShooting":
+                self.hd.set_transcription(MULTIPLE_SHOOTING)
+                why = self.hd.transcription_supported()
+                if why:
+                    self.hd.set_transcription(SINGLE_SHOOTING)
+                    warnings.warn("mpcqp: MultipleShooting kernel not available for this controller (reason mask "
+                                  f"{why}: 1 block/dense weights, 2 custom constraints, 4 LDS, 8 flags): the SingleShooting "
+                                  "kernels solve the same problem", RuntimeWarning)
+                else:
+                    self._ms_kernel = True
+            self.kernel = KERNEL_MS if self._ms_kernel else self.hd.prepare()
             self._prepared = True
         out = self.hd.step(xhat0, lastu0, (ry - self.yop) if held else (Rhaty - self.Yop), self.Z,
                            Ru=None if Rhatu is None else Rhatu - self.Uop, d0=d0, Dhat0=Dh0,
@@ -934,6 +958,9 @@ class BatchLinMPC:
                 dt = d0 if t == 0 else Dh0[:, (t - 1) * nd:t * nd]
                 x = x + np.einsum("bij,bj->bi", self._Bhd, dt)
             X0[:, t] = x
+        if getattr(self, "_ms_kernel", False):     # X̂0 is part of the MultipleShooting decision vector: the kernel's own
+            X0 = self.hd.get(GET_XHAT_MS)
+            x = X0[:, -1]
         info["x̂end"] = x + self.xhop
         # decision vector in the transcription's layout: [ΔU; ϵ] or [ΔU; X̂0(k+1..k+Hp); ϵ] (get_nZ_mpc, transcription.jl:2-7)
         parts = [DU] + ([X0.reshape(self.B, -1)] if self.transcription == "MultipleShooting" else []) + ([eps[:, None]] if self.neps else [])

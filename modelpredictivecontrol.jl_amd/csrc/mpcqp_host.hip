@@ -13,6 +13,8 @@
 #include "../../include/mpcqp.h"
 #include "mpcqp_hostutil.h"
 #include "mpcqp_launch.h"
+#include "ms_bodies.h"
+#include "ms_launch.h"
 
 using namespace mpcqp;
 
@@ -45,6 +47,10 @@ struct mpcqp_handle_s {
     DBuf kf_K, kf_iym, kf_x, kf_y, kf_u, kf_d;
     KfParams kf{};
     bool have_kf = false;
+    // MultipleShooting transcription (mpcqp_set_transcription): the stage-structured kernel of ms_bodies.h
+    int transcription = MPCQP_SINGLE_SHOOTING;
+    bool dual_reg_given = false;     // mpcqp_dims.dual_reg > 0 (else each kernel's own default)
+    DBuf ms_X, ms_defect;
 };
 
 static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
@@ -166,6 +172,7 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     d.gap_tol = in->gap_tol > 0 ? in->gap_tol : 1e-12;
     d.res_tol = in->res_tol > 0 ? in->res_tol : 1e-11;
     d.dual_reg = in->dual_reg > 0 ? in->dual_reg : 1e-12;
+    h->dual_reg_given = in->dual_reg > 0;
     d.gmask = d.neps ? 1u : 0u;                        // ϵ >= 0 is always there
     layout_rows(h);
     h->device = in->device;
@@ -497,6 +504,29 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
     return MPCQP_OK;
 }
 
+// 0 when the MultipleShooting kernel takes this handle; else the reason (bit mask): 1 dense / block weights, 2 custom
+// linear constraints, 4 the stage data does not fit the 160 KB of LDS, 8 flags of the condensed kernels only
+static int ms_unsupported(mpcqp_handle h) {
+    int why = 0;
+    if (h->m.Mblk || h->m.Mfull || h->m.Ndense || h->m.Ldense) why |= 1;
+    if (h->d.nw > 0) why |= 2;
+    if (ms_lds_bytes(h->d, h->m) > 160 * 1024) why |= 4;
+    if (h->d.flags & (MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL)) why |= 8;
+    return why;
+}
+
+int mpcqp_set_transcription(mpcqp_handle h, int32_t transcription) {
+    if (!h) return MPCQP_ERR_NULL;
+    if (transcription != MPCQP_SINGLE_SHOOTING && transcription != MPCQP_MULTIPLE_SHOOTING) return MPCQP_ERR_ARG;
+    h->transcription = transcription;
+    return MPCQP_OK;
+}
+
+int mpcqp_transcription_supported(mpcqp_handle h) {
+    if (!h) return MPCQP_ERR_NULL;
+    return h->transcription == MPCQP_MULTIPLE_SHOOTING ? ms_unsupported(h) : 0;
+}
+
 // shared by mpcqp_step_device (kf = false) and mpcqp_loop_device
 static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* lastu0, const double* Ry,
                             const double* Ru, const double* d0, const double* Dhat0, double* Ztilde, double* u0,
@@ -519,7 +549,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     const Dims& d = h->d;
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
-    if (step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
+    if (h->transcription != MPCQP_MULTIPLE_SHOOTING && step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
     ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     StepIO io{};
@@ -557,7 +587,27 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     }
 #endif
     HIPCHK(hipEventRecord(h->ev_s0, st));
-    HIPCHK(launch_step(d, h->m, io, st));
+    if (h->transcription == MPCQP_MULTIPLE_SHOOTING) {
+        // the stage-structured kernel: model as equality constraints, Riccati recursion, H~ and E never formed
+        const int why = ms_unsupported(h);
+        if (why || y0m || predict) return MPCQP_ERR_UNSUPPORTED;
+        MsIO ms{};
+        int rc = dev_alloc(h, h->ms_X, (size_t)d.B * d.nxh * d.Hp * sizeof(double));
+        if (!rc) rc = dev_alloc(h, h->ms_defect, (size_t)d.B * sizeof(double));
+        if (rc) return rc;
+        ms.Xhat = (double*)h->ms_X.p; ms.defect = (double*)h->ms_defect.p;
+        // default dual regularisation of this kernel: 1e-9.  The cost-to-go matrices of the Riccati recursion keep the
+        // barrier weights D~ <= 1/delta of rows on the STATES (output bounds, input bounds) in the same entries as the O(1)
+        // curvature of the objective: at delta = 1e-12 the latter keeps 4 digits and heavily constrained controllers end
+        // 1e-4 from the optimum; at 1e-8 the primal residual delta*dlam of soft rows with 1e5-size multipliers stalls.
+        // Measured on 2048 C3 controllers against the condensed kernel (scripts/ms_c3_check.py, profiles/r4):
+        // delta 1e-10 / 1e-9 / 1e-8: 99.9 % quantile of the dU difference 4e-2 / 4e-7 / 1e-5, not OPTIMAL 23 / 2 / 3.
+        Dims dm = d;
+        if (!h->dual_reg_given) dm.dual_reg = 1e-9;
+        HIPCHK(launch_ms_step(dm, h->m, io, ms, st));
+    } else {
+        HIPCHK(launch_step(d, h->m, io, st));
+    }
     HIPCHK(hipEventRecord(h->ev_s1, st));
     h->step_timed = true;
     return MPCQP_OK;
@@ -672,6 +722,14 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
         case MPCQP_GET_FVEC:
             if (!h->keep_F.p) return MPCQP_ERR_ORDER;
             HIPCHK(hipMemcpy(out, h->keep_F.p, B * d.nY * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        case MPCQP_GET_XHAT_MS:
+            if (!h->ms_X.p) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->ms_X.p, B * d.nxh * d.Hp * sizeof(double), hipMemcpyDeviceToHost));
+            return MPCQP_OK;
+        case MPCQP_GET_MS_DEFECT:
+            if (!h->ms_defect.p) return MPCQP_ERR_ORDER;
+            HIPCHK(hipMemcpy(out, h->ms_defect.p, B * sizeof(double), hipMemcpyDeviceToHost));
             return MPCQP_OK;
         case MPCQP_GET_AUDIT:
             if (!h->audit.p) return MPCQP_ERR_ORDER;
@@ -923,6 +981,7 @@ int mpcqp_lds_bytes(mpcqp_handle h) {
 
 int mpcqp_kernel_kind(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
+    if (h->transcription == MPCQP_MULTIPLE_SHOOTING && !ms_unsupported(h)) return MPCQP_KERNEL_MS;
     return step_kernel_kind(h->d, h->m);
 }
 

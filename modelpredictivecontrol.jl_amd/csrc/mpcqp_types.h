@@ -55,7 +55,7 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 8        // 8: MPCQP_FLAG_KEEP_ITERATE (the first-iterates comparison of mpcqp_prepare needs it in both kernels)
+#define MPCQP_KERNEL_REV 9        // 9: a blocked step (alpha < 1/2) no longer passes the last-step test; 8: MPCQP_FLAG_KEEP_ITERATE
 
 namespace mpcqp {
 

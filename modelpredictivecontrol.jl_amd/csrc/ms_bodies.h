@@ -34,6 +34,10 @@
 #include "mpcqp_bodies.h"
 #include "mpcqp_types.h"
 
+#ifndef MPCQP_MS_REFINE
+#define MPCQP_MS_REFINE 0         // steps of iterative refinement per Newton solve (MsStep::newton; measured: no gain, see there)
+#endif
+
 namespace mpcqp {
 
 // optional outputs of the MultipleShooting step
@@ -54,6 +58,7 @@ struct MsCarve {
     int gX, gV, gDU;                    // gradient of the current solve
     int fX, fV, fDU;                    // border column phi
     int cX, cV;                         // defects c_t
+    int eX, eV, eDU, mX, mV, hDU;       // correction of a Newton solve (iterative refinement), its nu; the solve's own g_u
     int gv;                             // g_t (x part), [Hp][nx]
     int ry, ru;                         // targets: C^ x - ry[t] with ry = R^y - D^d d^ (nY); u - ru (nU)
     int QY, QV, RD;                     // stage Hessian diagonals: output weight 2M + D_Y (nY), 2L + D_U (nU), 2N + D_dU (nDU)
@@ -104,6 +109,7 @@ MPCQP_HD inline MsCarve make_ms_carve(const Dims& d, const Model& m) {
     c.gX = take(nX); c.gV = take(nV); c.gDU = take(nDU);
     c.fX = take(nX); c.fV = take(nV); c.fDU = take(nDU);
     c.cX = take(nX); c.cV = take(nV);
+    { const int R_ = MPCQP_MS_REFINE ? 1 : 0; c.eX = take(R_ * nX); c.eV = take(R_ * nV); c.eDU = take(R_ * nDU); c.mX = take(R_ * nX); c.mV = take(R_ * nV); c.hDU = take(R_ * nDU); }
     c.gv = take(nX);
     c.ry = take(nY); c.ru = take(nV);
     c.QY = take(nY); c.QV = take(nV); c.RD = take(nDU);
@@ -347,15 +353,16 @@ struct MsStep {
     }
 
     // ---- Riccati factorisation of the current Phi (QY, QV, RD hold the stage diagonals) --------------------
-    // Abar'-congruence of the packed symmetric Pn (cost-to-go of stage t+1) into S (full ns x ns)
-    MPCQP_HD void congruence(const double* Pn) {
-        double* S = sm + c.S;
+    // T = Pn M for the packed symmetric Pn (cost-to-go of stage t+1) and M = Abar (Mfull == nullptr: the structure
+    // Abar = [A^ B^u; 0 I] is used) or a full ns x ns matrix (the closed-loop matrix Abar + Bbar K)
+    MPCQP_HD void PtimesM(const double* Pn, const double* Mfull) {
         double* T = sm + c.T;
-        // T = Pn Abar : T[i][j<nx] = sum_k Pn[i][k] A[k][j];  T[i][nx+cc] = sum_k Pn[i][k] Bu[k][cc] + Pn[i][nx+cc]
         for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
             const int i = idx / ns, j = idx - i * ns;
             double acc = 0.0;
-            if (j < nx) {
+            if (Mfull) {
+                for (int k = 0; k < ns; ++k) acc += Pn[pidx(i, k)] * Mfull[k * ns + j];
+            } else if (j < nx) {
                 for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * A[k + nx * j];
             } else {
                 const int cc = j - nx;
@@ -365,22 +372,27 @@ struct MsStep {
             T[idx] = acc;
         }
         w.sync();
-        // S = Abar' T (lower triangle computed, mirrored)
-        for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
-            const int i = idx / ns, j = idx - i * ns;
-            if (j > i) continue;
-            double acc = 0.0;
-            if (i < nx) {
-                for (int k = 0; k < nx; ++k) acc += A[k + nx * i] * T[k * ns + j];
-            } else {
-                const int cc = i - nx;
-                for (int k = 0; k < nx; ++k) acc += Bu[k + nx * cc] * T[k * ns + j];
-                acc += T[i * ns + j];
-            }
-            S[i * ns + j] = acc;
-            S[j * ns + i] = acc;
+    }
+    // row i of Abar' T (or Mfull' T): entry (i, j)
+    MPCQP_HD double MtT(const double* Mfull, int i, int j) const {
+        const double* T = sm + c.T;
+        double acc = 0.0;
+        if (Mfull) {
+            for (int k = 0; k < ns; ++k) acc += Mfull[k * ns + i] * T[k * ns + j];
+        } else if (i < nx) {
+            for (int k = 0; k < nx; ++k) acc += A[k + nx * i] * T[k * ns + j];
+        } else {
+            const int cc = i - nx;
+            for (int k = 0; k < nx; ++k) acc += Bu[k + nx * cc] * T[k * ns + j];
+            acc += T[i * ns + j];
         }
-        w.sync();
+        return acc;
+    }
+    MPCQP_HD static void unpack_low(int idx, int& i, int& j) {
+        i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > idx) --i;
+        while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+        j = idx - i * (i + 1) / 2;
     }
 
     // Q_t of stage t (0-based: the stage that holds x^0(k+t+1), u0(k+t)) added to the packed Pt
@@ -438,11 +450,15 @@ struct MsStep {
         return ok;
     }
 
+    // Backward matrix sweep.  The cost-to-go is propagated in the SYMMETRIC (Joseph) form
+    //     P_t = Q_t + (Abar + Bbar K_t)' P_{t+1} (Abar + Bbar K_t) + K_t' R_t K_t,
+    // a sum of positive semidefinite terms: the textbook form Q + S - S_.u Lam^-1 S_u. subtracts 1e12-size numbers (rows
+    // held at D~ = 1/delta on the input part of the state) from each other and loses the definiteness of P within a few
+    // stages (met on the GPU: randomised family 1, a pivot of Lam <= 0 at mu = 3e-7).  One product more per free move.
     MPCQP_HD bool factor() {
         double* P = sm + c.P;
         double* S = sm + c.S;
         bool ok = true;
-        // terminal stage: P_{Hp} = Q_{Hp}
         double* PT = P + (size_t)(Hp - 1) * npk;
         for (int i = w.lane; i < npk; i += WAVE) PT[i] = 0.0;
         w.sync();
@@ -450,37 +466,63 @@ struct MsStep {
         w.sync();
         for (int t = Hp - 1; t >= 0; --t) {
             // stage t maps xi_t (stored at t-1; given for t = 0) to xi_{t+1} (stored at t)
-            congruence(P + (size_t)t * npk);
+            const double* Pn = P + (size_t)t * npk;
             const int j = ctrl[t];
             double* K = sm + c.K + (size_t)(j >= 0 ? j : 0) * nu * ns;
             double* Li = sm + c.Li + (size_t)(j >= 0 ? j : 0) * nu * nu;
+            PtimesM(Pn, nullptr);                               // T = P_{t+1} Abar
             if (j >= 0) {
+                // S_u. = Bbar' T (rows nx.. of Abar' T) into S[0 .. nu*ns); Lam = R + S_uu
+                for (int idx = w.lane; idx < nu * ns; idx += WAVE) {
+                    const int a = idx / ns, col = idx - a * ns;
+                    S[idx] = MtT(nullptr, nx + a, col);
+                }
+                w.sync();
                 for (int idx = w.lane; idx < nu * nu; idx += WAVE) {
                     const int a = idx / nu, e = idx - a * nu;
-                    Li[idx] = S[(nx + a) * ns + nx + e] + (a == e ? sm[c.RD + j * nu + a] : 0.0);
+                    // (symmetrised: the two triangles of Bbar'P Bbar differ by rounding)
+                    Li[idx] = 0.5 * (S[a * ns + nx + e] + S[e * ns + nx + a]) + (a == e ? sm[c.RD + j * nu + a] : 0.0);
                 }
                 w.sync();
                 ok = invert_spd(Li) && ok;
-                // K = -Lam^-1 S_u.
-                for (int idx = w.lane; idx < nu * ns; idx += WAVE) {
+                for (int idx = w.lane; idx < nu * ns; idx += WAVE) {          // K = -Lam^-1 S_u.
                     const int a = idx / ns, col = idx - a * ns;
                     double acc = 0.0;
-                    for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * S[(nx + e) * ns + col];
+                    for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * S[e * ns + col];
                     K[idx] = -acc;
                 }
                 w.sync();
             }
             if (t == 0) break;                     // xi_0 is data: no cost-to-go needed
             double* Pt = P + (size_t)(t - 1) * npk;
-            for (int idx = w.lane; idx < npk; idx += WAVE) {
-                int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                while (i * (i + 1) / 2 > idx) --i;
-                while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-                const int jj = idx - i * (i + 1) / 2;
-                double acc = S[i * ns + jj];
-                if (j >= 0)
-                    for (int e = 0; e < nu; ++e) acc += S[i * ns + nx + e] * K[e * ns + jj];
-                Pt[idx] = acc;
+            if (j >= 0) {
+                // closed-loop matrix Acl = Abar + Bbar K into S (full ns x ns), T = P_{t+1} Acl, P_t = Acl' T + K' R K
+                for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
+                    const int i = idx / ns, col = idx - i * ns;
+                    double acc;
+                    if (i < nx) {
+                        acc = col < nx ? A[i + nx * col] : Bu[i + nx * (col - nx)];
+                        for (int e = 0; e < nu; ++e) acc += Bu[i + nx * e] * K[e * ns + col];
+                    } else {
+                        acc = (col == i ? 1.0 : 0.0) + K[(i - nx) * ns + col];
+                    }
+                    S[idx] = acc;
+                }
+                w.sync();
+                PtimesM(Pn, S);
+                for (int idx = w.lane; idx < npk; idx += WAVE) {
+                    int i, jj;
+                    unpack_low(idx, i, jj);
+                    double acc = MtT(S, i, jj);
+                    for (int e = 0; e < nu; ++e) acc += K[e * ns + i] * sm[c.RD + j * nu + e] * K[e * ns + jj];
+                    Pt[idx] = acc;
+                }
+            } else {
+                for (int idx = w.lane; idx < npk; idx += WAVE) {
+                    int i, jj;
+                    unpack_low(idx, i, jj);
+                    Pt[idx] = MtT(nullptr, i, jj);
+                }
             }
             w.sync();
             add_Q(Pt, t - 1);
@@ -576,13 +618,39 @@ struct MsStep {
                 oX[t * nx + i] = acc;
             }
             w.sync();
-            // nu+_{t+1} = P_{t+1} dxi_{t+1} + p_{t+1}
-            const double* Pn = P + (size_t)t * npk;
+        }
+        // multipliers of the model equations by the ADJOINT recursion of the Newton system's state rows,
+        //     nu+_t = g_t + Phi_tt dxi_t + Abar' nu+_{t+1}            (nu+_{Hp+1} = 0),
+        // instead of nu+_t = P_t dxi_t + p_t: P carries the 1e12-size barrier weights of rows held at D~ = 1/delta, and the
+        // product with a 1e-12-size step leaves O(1) noise in nu (seen as a dual residual that GROWS as mu -> 0).  Built
+        // this way the state rows of the Newton system hold exactly and whatever error the recursion made shows up in its
+        // control rows, where the next Newton step removes it.
+        double* tmp = sm + c.wv;
+        for (int t = Hp - 1; t >= 0; --t) {
+            for (int a = w.lane; a < ny; a += WAVE) {
+                double acc = 0.0;
+                for (int k = 0; k < nx; ++k) acc += Cm[a + ny * k] * oX[t * nx + k];
+                tmp[a] = acc * sm[c.QY + t * ny + a];
+            }
+            w.sync();
             for (int i = w.lane; i < ns; i += WAVE) {
-                double acc = pv[t * ns + i];
-                for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * oX[t * nx + k];
-                for (int cc = 0; cc < nu; ++cc) acc += Pn[pidx(i, nx + cc)] * oV[t * nu + cc];
-                if (i < nx) nuX[t * nx + i] = acc; else nuV[t * nu + i - nx] = acc;
+                double acc;
+                if (i < nx) {
+                    acc = gX[t * nx + i];
+                    for (int a = 0; a < ny; ++a) acc += Cm[a + ny * i] * tmp[a];
+                    if (t == Hp - 1) acc += xterm(i) * oX[t * nx + i];
+                    if (t + 1 < Hp)
+                        for (int k = 0; k < nx; ++k) acc += A[k + nx * i] * nuX[(t + 1) * nx + k];
+                    nuX[t * nx + i] = acc;
+                } else {
+                    const int cc = i - nx;
+                    acc = gV[t * nu + cc] + sm[c.QV + t * nu + cc] * oV[t * nu + cc];
+                    if (t + 1 < Hp) {
+                        for (int k = 0; k < nx; ++k) acc += Bu[k + nx * cc] * nuX[(t + 1) * nx + k];
+                        acc += nuV[(t + 1) * nu + cc];
+                    }
+                    nuV[t * nu + cc] = acc;
+                }
             }
             w.sync();
         }
@@ -655,6 +723,9 @@ struct MsStep {
             mx = fmax(mx, fabs(r));
             sc = fmax(sc, fmax(fabs(g0), fmax(fabs(nu_t), fabs(an))));
         }
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_DEBUG_MS)
+        { const double mxs = w.maxv(mx); if (w.lane == 0 && b == MPCQP_DEBUG_MS) printf("      rd state rows %.3e", mxs); }
+#endif
         for (int i = w.lane; i < nDU; i += WAVE) {
             const int j = i / nu, cc = i - j * nu, t = jlt[j];
             double an = NV[t * nu + cc];
@@ -664,6 +735,9 @@ struct MsStep {
             mx = fmax(mx, fabs(r));
             sc = fmax(sc, fmax(fabs(g0), fabs(an)));
         }
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_DEBUG_MS)
+        { const double mxs = w.maxv(mx); if (w.lane == 0 && b == MPCQP_DEBUG_MS) printf(" +control rows %.3e\n", mxs); }
+#endif
         if (d.neps) {
             const double re = 2.0 * m.Cwt[b] * eps + ge;
             mx = fmax(mx, fabs(re));
@@ -688,14 +762,58 @@ struct MsStep {
         // g^ = cost gradient + G'(lam + D~ rp - wi rc)
         const double ge0 = Gt_apply([&](int r) { return rl[r] + rwi[r] * (rl[r] * rrp[r] - rc(r)); }, sm + c.gX, sm + c.gV, sm + c.gDU, true);
         sweep(sm + c.gX, sm + c.gV, sm + c.gDU, true, sm + c.dX, sm + c.dV, sm + c.dDU, sm + c.nX, sm + c.nV);
+        if (MPCQP_MS_REFINE) for (int i = w.lane; i < nDU; i += WAVE) sm[c.hDU + i] = sm[c.gDU + i];
         deps = 0.0;
+        const double ge_keep = d.neps ? 2.0 * m.Cwt[b] * eps + ge0 : 0.0;
         if (d.neps) {
-            const double ge = 2.0 * m.Cwt[b] * eps + ge0;
+            const double ge = ge_keep;
             const double fy = dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.dX, sm + c.dV, sm + c.dDU);
             deps = -(ge + fy) / (phiee + phipsi);
             for (int i = w.lane; i < nXt; i += WAVE) { sm[c.dX + i] += deps * sm[c.pX + i]; sm[c.nX + i] += deps * sm[c.qX + i]; }
             for (int i = w.lane; i < nVt; i += WAVE) { sm[c.dV + i] += deps * sm[c.pV + i]; sm[c.nV + i] += deps * sm[c.qV + i]; }
             for (int i = w.lane; i < nDU; i += WAVE) sm[c.dDU + i] += deps * sm[c.pDU + i];
+            w.sync();
+        }
+        // Optional iterative refinement (MPCQP_MS_REFINE, off).  As mu -> 0 the control rows of the Newton system are left
+        // with an O(1) residual (measured: 0.99 against terms of 6.6 at mu = 1e-9): the feedback form du = K dxi + k forms the
+        // 1e-12-size step of an input held at its bound as a difference of 1e-5-size numbers, and a row held at D~ = 1/delta
+        // turns that rounding into the residual.  The error lies in the stiff directions only -- the inputs agree with the
+        // oracle to 1e-11 -- and a refinement step with the same factor does not remove it (measured), so the dual residual
+        // cannot certify convergence at small mu: the termination test relies on the gap, the primal residual, the defect
+        // and the last-step criterion, with the stall rule of Step::run for r_d.  The state rows hold by construction
+        // (adjoint nu+), so the residual lives in the control rows and the slack row:
+        //     r_u = R du + g_u + Bbar' nu+ + phi_u deps,     r_e = g_e + phi'dz + Phi_ee deps
+        // and the correction solves the same system for it (one more sweep with the same factor).
+        for (int pass = 0; pass < MPCQP_MS_REFINE; ++pass) {
+            for (int i = w.lane; i < nXt; i += WAVE) sm[c.gX + i] = 0.0;
+            for (int i = w.lane; i < nVt; i += WAVE) sm[c.gV + i] = 0.0;
+            double mxr = 0.0;
+            for (int i = w.lane; i < nDU; i += WAVE) {
+                const int j = i / nu, cc = i - j * nu, t = jlt[j];
+                double an = sm[c.nV + t * nu + cc];
+                for (int k = 0; k < nx; ++k) an += Bu[k + nx * cc] * sm[c.nX + t * nx + k];
+                const double r = sm[c.RD + i] * sm[c.dDU + i] + sm[c.hDU + i] + an + sm[c.fDU + i] * deps;
+                sm[c.eDU + i] = r;
+                mxr = fmax(mxr, fabs(r));
+            }
+            w.sync();
+            for (int i = w.lane; i < nDU; i += WAVE) sm[c.gDU + i] = sm[c.eDU + i];
+            double re = 0.0;
+            if (d.neps) re = ge_keep + dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.dX, sm + c.dV, sm + c.dDU) + phiee * deps;
+            w.sync();
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_DEBUG_MS)
+            { mxr = w.maxv(mxr); if (w.lane == 0 && b == MPCQP_DEBUG_MS) printf("      newton control-row residual %.3e slack row %.3e deps %.3e\n", mxr, re, deps); }
+#endif
+            sweep(sm + c.gX, sm + c.gV, sm + c.gDU, false, sm + c.eX, sm + c.eV, sm + c.eDU, sm + c.mX, sm + c.mV);
+            double de = 0.0;
+            if (d.neps) {
+                const double fy = dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.eX, sm + c.eV, sm + c.eDU);
+                de = -(re + fy) / (phiee + phipsi);
+            }
+            for (int i = w.lane; i < nXt; i += WAVE) { sm[c.dX + i] += sm[c.eX + i] + de * sm[c.pX + i]; sm[c.nX + i] += sm[c.mX + i] + de * sm[c.qX + i]; }
+            for (int i = w.lane; i < nVt; i += WAVE) { sm[c.dV + i] += sm[c.eV + i] + de * sm[c.pV + i]; sm[c.nV + i] += sm[c.mV + i] + de * sm[c.qV + i]; }
+            for (int i = w.lane; i < nDU; i += WAVE) sm[c.dDU + i] += sm[c.eDU + i] + de * sm[c.pDU + i];
+            deps += de;
             w.sync();
         }
         C_apply(sm + c.dX, sm + c.CD);
@@ -731,15 +849,24 @@ struct MsStep {
             rl[r] = 10.0 / rs[r];
         });
         w.sync();
-        double step_c = 1e300, zabs_c = 0.0;
+        double step_c = 1e300, zabs_c = 0.0, rd_prev = 1e300, alpha_prev = 0.0;
         const int max_iter = mact ? d.max_iter : 1;
         while (true) {
-            if (chol_broke_ && delta < 1e-8) { delta *= 100.0; chol_broke_ = false; }
             residuals(mu, rpn, rdn, ndd, cn, xs);
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_DEBUG_MS)
+            if (w.lane == 0 && b == MPCQP_DEBUG_MS) printf("  [ms] it %2d mu %.3e rd %.3e (ndd %.3e) rp %.3e (nh %.2e) defect %.3e step %.3e eps %.6e delta %.1e\n", it, mu, rdn, ndd, rpn, nh, cn, step_c, eps, delta);
+#endif
             if (!(mu == mu) || !(rdn == rdn) || !(rpn == rpn) || !(cn == cn)) { status = ST_ERROR; break; }
-            const bool conv = mu <= d.gap_tol && rdn <= d.res_tol * ndd && rpn <= 10.0 * d.res_tol * nh && cn <= d.res_tol * xs &&
-                              step_c <= 1e-6 * fmax(1.0, zabs_c);
-            if (conv && (mact || it > 0)) { status = ST_OPTIMAL; break; }
+            // (a dual residual that an exact evaluation finds where the previous one left it although the step in between
+            //  was nearly full sits on the float64 floor of the Newton systems -- rows held at D~ = 1/delta -- and counts as
+            //  converged; the step criterion vouches for the inputs then.  Same rule as Step::run.)
+            const bool rd_stalled = rdn >= 0.5 * rd_prev && alpha_prev >= 0.9;
+            rd_prev = rdn;
+            const bool conv = mu <= d.gap_tol && (rdn <= d.res_tol * ndd || rd_stalled) && rpn <= 10.0 * d.res_tol * nh &&
+                              cn <= d.res_tol * xs && step_c <= 1e-6 * fmax(1.0, zabs_c);
+            if (conv && mact) { status = ST_OPTIMAL; break; }
+            // no finite row at all: the first Newton step IS the optimum (what ExplicitMPC computes, explicitmpc.jl:216)
+            if (!mact && it > 0) { status = ST_OPTIMAL; it = 0; break; }
             if (it >= max_iter) break;
             // D~ of the rows -> stage diagonals, border column phi, Phi_ee
             double ee = 0.0;
@@ -779,7 +906,14 @@ struct MsStep {
                 sm[c.fX + i] = acc;
             }
             w.sync();
-            if (!factor()) chol_broke_ = true;
+            if (!factor()) {
+                // a pivot of some Lam_t <= 0: Phi left float64's range (rows held at D~ = 1/delta).  No step is taken with
+                // that factor; the iteration goes on with a 100 times larger dual regularisation (it biases nothing: delta
+                // multiplies the multiplier step, which vanishes at the optimum; same rule as Step::run)
+                if (delta < 1e-8) { delta *= 100.0; continue; }
+                status = ST_ERROR;
+                break;
+            }
             double phipsi = 0.0;
             const double phiee = d.neps ? 2.0 * m.Cwt[b] + ee : 1.0;
             if (d.neps) {
@@ -836,7 +970,7 @@ struct MsStep {
                     rl[r] += alpha * rgd[r];
                 });
             }
-            double stc = 0.0, zab = 0.0;
+            double stc = alpha >= 0.5 ? 0.0 : 1e300, zab = 0.0;      // (a blocked step says nothing about convergence)
             for (int k = w.lane; k < nDU; k += WAVE) {
                 const double st = alpha * sm[c.dDU + k];
                 stc = fmax(stc, fabs(st)); zab = fmax(zab, fabs(DU[k]));
@@ -845,6 +979,7 @@ struct MsStep {
             for (int i = w.lane; i < nXt; i += WAVE) { X[i] += alpha * sm[c.dX + i]; sm[c.NX + i] += alpha * (sm[c.nX + i] - sm[c.NX + i]); }
             for (int i = w.lane; i < nVt; i += WAVE) { V[i] += alpha * sm[c.dV + i]; sm[c.NV + i] += alpha * (sm[c.nV + i] - sm[c.NV + i]); }
             eps += alpha * deps;
+            alpha_prev = alpha;
             step_c = w.maxv(stc); zabs_c = w.maxv(zab);
             w.sync();
             ++it;
@@ -864,7 +999,6 @@ struct MsStep {
         }
         return status;
     }
-    bool chol_broke_ = false;
 };
 
 template <class W>

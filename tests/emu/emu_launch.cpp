@@ -18,84 +18,9 @@
     XNB(1, 1, 3, 6, 3, 1, 0x39Fu)    \
     XNB(1, 1, 3, 6, 3, 1, 0x08Du)
 
+#include "emu_wave.h"
+
 namespace mpcqp {
-
-struct EmuShared {
-    std::barrier<> bar{WAVE};
-    double xd[WAVE];
-    int xi[WAVE];
-};
-
-struct EmuWave {
-    int lane;
-    EmuShared* sh;
-    void sync() { sh->bar.arrive_and_wait(); }
-    double sum(double v) {
-        sh->xd[lane] = v; sync();
-        double s = 0.0;
-        for (int i = 0; i < WAVE; ++i) s += sh->xd[i];
-        sync();
-        return s;
-    }
-    double quad_sum(double v) {
-        sh->xd[lane] = v; sync();
-        const int q = lane & ~3;
-        double s = sh->xd[q] + sh->xd[q + 1] + sh->xd[q + 2] + sh->xd[q + 3];
-        sync();
-        return s;
-    }
-    double minv(double v) {
-        sh->xd[lane] = v; sync();
-        double s = sh->xd[0];
-        for (int i = 1; i < WAVE; ++i) s = fmin(s, sh->xd[i]);
-        sync();
-        return s;
-    }
-    double maxv(double v) {
-        sh->xd[lane] = v; sync();
-        double s = sh->xd[0];
-        for (int i = 1; i < WAVE; ++i) s = fmax(s, sh->xd[i]);
-        sync();
-        return s;
-    }
-    int isum(int v) {
-        sh->xi[lane] = v; sync();
-        int s = 0;
-        for (int i = 0; i < WAVE; ++i) s += sh->xi[i];
-        sync();
-        return s;
-    }
-    bool any(bool p) { return isum(p ? 1 : 0) != 0; }
-    void relane() {}
-    double fetch(double v, int src) {
-        sh->xd[lane] = v; sync();
-        double s = sh->xd[src & (WAVE - 1)];
-        sync();
-        return s;
-    }
-    double bcast(double v, int src) {
-        sh->xd[lane] = v; sync();
-        double s = sh->xd[src];
-        sync();
-        return s;
-    }
-};
-
-template <class F>
-static void run_waves(int B, size_t lds_doubles, F body) {
-    std::vector<double> smem(lds_doubles + 16, 0.0);
-    EmuShared sh;
-    std::vector<std::thread> th;
-    for (int lane = 0; lane < WAVE; ++lane)
-        th.emplace_back([&, lane] {
-            EmuWave w{lane, &sh};
-            for (int b = 0; b < B; ++b) {
-                body(w, b, smem.data());
-                w.sync();
-            }
-        });
-    for (auto& t : th) t.join();
-}
 
 hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStream_t) {
     run_waves(d.B, predmat_lds_doubles(d), [&](EmuWave& w, int b, double* sm) { predmat_body(w, d, m, b, sm, terminal); });

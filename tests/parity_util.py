@@ -293,7 +293,10 @@ def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
     return out
 
 
-def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, kinds=None):
+EXTRA_KW = None      # (experiments: extra BatchLinMPC keywords for run_random_case)
+
+
+def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, kinds=None, transcription="SingleShooting"):
     """One randomly drawn controller family (dimensions, move blocking, which bounds exist, hard /
     soft mix, terminal bounds, measured disturbance, Cwt finite or Inf) as a batch of B DIFFERENT
     controllers of that family -- every member has its own model, weights, operating points, bound
@@ -377,7 +380,7 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, k
                             Lwt=st(lambda m: m["kw"]["Lwt"]), Cwt=st(lambda m: m["kw"]["Cwt"]),
                             uop=st(lambda m: m["model"].uop), yop=st(lambda m: m["model"].yop),
                             dop=st(lambda m: m["model"].dop), xhop=st(lambda m: m["kf"].xhop),
-                            fhop=st(lambda m: m["kf"].fhop))
+                            fhop=st(lambda m: m["kf"].fhop), transcription=transcription, **(EXTRA_KW or {}))
     gname = dict(dumin="Δumin", dumax="Δumax", c_dumin="c_Δumin", c_dumax="c_Δumax", xhatmax="x̂max")
     gpu.setconstraint(**{gname.get(k, k): st(lambda m: m["con"][k]) for k in mem[0]["con"]})
     gpu.initstate(st(lambda m: m["u_prev"]))
@@ -721,4 +724,54 @@ def shape_vs_cport(cfg, B=256, seed=11, lib=None):
     out = dict(kind=kind, nZ=hd.nZ, ms=hd.last_step_ms(), optimal=float(np.mean(st == 0)), optimal_cport=float(np.mean(stc == 0)),
                iters=float(it.mean()), iters_cport=float(itc.mean()), err99=float(np.quantile(err, 0.99)), errmax=float(err.max()))
     hd.close()
+    return out
+
+
+def unstable_plant_members(B, rho=(1.12, 1.05), Hp=50, Hc=50, seed=77, nx=4, nu=2, ny=2):
+    """B different UNSTABLE plants (two eigenvalues outside the unit circle, `rho`) with output integrators, long
+    horizons Hp = Hc = 50: cond(H̃) of the condensed QP is 1e8 and beyond -- the case the reference's documentation sends to
+    MultipleShooting (src/controller/construct.jl:855-866).  Returns per-member dicts with the augmented model, the
+    constructor keywords, the constraints and one (x̂0, ry)."""
+    mem = []
+    for i in range(B):
+        rg = np.random.default_rng([seed, i])
+        lam = np.concatenate([np.array(rho), rg.uniform(0.5, 0.9, nx - len(rho))])
+        Q, _ = np.linalg.qr(rg.standard_normal((nx, nx)))
+        A = Q @ np.diag(lam) @ Q.T
+        Bu = rg.standard_normal((nx, nu)) / np.sqrt(nx); C = rg.standard_normal((ny, nx)) / np.sqrt(nx)
+        Ah = np.block([[A, np.zeros((nx, ny))], [np.zeros((ny, nx)), np.eye(ny)]])
+        Bhu = np.vstack([Bu, np.zeros((ny, nu))]); Ch = np.hstack([C, np.eye(ny)])
+        kw = dict(Hp=Hp, Hc=Hc, Mwt=np.ones(ny), Nwt=np.full(nu, 0.1), Lwt=np.zeros(nu), Cwt=1e5)
+        con = dict(umin=[-2.0] * nu, umax=[2.0] * nu, dumin=[-0.5] * nu, dumax=[0.5] * nu, ymax=[1.5] * ny)
+        mem.append(dict(Ah=Ah, Bhu=Bhu, Ch=Ch, kw=kw, con=con, x0=0.05 * rg.standard_normal(nx + ny),
+                        ry=0.5 * rg.standard_normal(ny)))
+    return mem
+
+
+def run_unstable_plant(lib=None, B=4, transcription="MultipleShooting", rho=(1.12, 1.05), check=None, hp=False):
+    """The unstable plants of `unstable_plant_members` through the C-ABI with the given transcription against the dense
+    MultipleShooting oracle (oracle/ms.py; `hp`: its 60-digit solve).  Returns dict(err per member, cond of H̃, kernel kind,
+    statuses, defect of the model equations of the returned X̂0)."""
+    from oracle import ms as oms
+    mem = unstable_plant_members(B, rho=rho)
+    st = lambda f: np.stack([f(m) for m in mem])
+    g = mpcqp.BatchLinMPC(st(lambda m: m["Ah"]), st(lambda m: m["Bhu"]), st(lambda m: m["Ch"]), lib=lib,
+                          transcription=transcription, **mem[0]["kw"])
+    c = mem[0]["con"]
+    g.setconstraint(umin=c["umin"], umax=c["umax"], Δumin=c["dumin"], Δumax=c["dumax"], ymax=c["ymax"])
+    g.moveinput(st(lambda m: m["x0"]), st(lambda m: m["ry"]))
+    nDU = g.nDU
+    errs, conds, certs = [], [], []
+    for i in (range(B) if check is None else check):
+        m = mem[i]
+        o = oms.LinMPCOracleMS(m["Ah"], m["Bhu"], m["Ch"], **m["kw"]).setconstraint(**m["con"])
+        o.moveinput(m["x0"], m["ry"], hp=hp)
+        assert o.status == 0 and max(o.info["kkt_full"].values()) <= 1e-9, o.info["kkt_full"]
+        certs.append(o.info["certificate"])
+        z = o.Zt[:nDU]
+        errs.append(float(np.abs(g.Z[i, :nDU] - z).max() / max(1.0, np.abs(z).max())))
+        conds.append(float(np.linalg.cond(o.ss.Ht)))
+    out = dict(err=np.array(errs), cond=np.array(conds), kind=g.kernel, status=g.status.copy(), iters=g.iters.copy(), cert=certs)
+    if g.kernel == mpcqp.api.KERNEL_MS:
+        out["defect"] = g.hd.get(mpcqp.api.GET_MS_DEFECT)
     return out

@@ -110,7 +110,7 @@ def test_shapes_and_constraint_patterns_against_the_c_port(name, pattern, hiplib
     r = shape_vs_cport(dataclasses.replace(synth.get_config(name), **pats[pattern]), B=256)
     assert r["kind"] == mpcqp.api.KERNEL_ONDEMAND, r
     assert r["optimal"] == 1.0 and r["optimal_cport"] == 1.0, r
-    assert r["err99"] <= TOL and r["errmax"] <= 1e-3, r
+    assert r["errmax"] <= TOL, r
     assert abs(r["iters"] - r["iters_cport"]) <= 1.0, r
 
 
