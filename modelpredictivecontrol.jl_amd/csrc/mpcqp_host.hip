@@ -50,7 +50,7 @@ struct mpcqp_handle_s {
     // MultipleShooting transcription (mpcqp_set_transcription): the stage-structured kernel of ms_bodies.h
     int transcription = MPCQP_SINGLE_SHOOTING;
     bool dual_reg_given = false;     // mpcqp_dims.dual_reg > 0 (else each kernel's own default)
-    DBuf ms_X, ms_defect;
+    DBuf ms_X, ms_defect, ms_scratch;
 };
 
 static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
@@ -596,14 +596,20 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
         if (!rc) rc = dev_alloc(h, h->ms_defect, (size_t)d.B * sizeof(double));
         if (rc) return rc;
         ms.Xhat = (double*)h->ms_X.p; ms.defect = (double*)h->ms_defect.p;
-        // default dual regularisation of this kernel: 1e-9.  The cost-to-go matrices of the Riccati recursion keep the
-        // barrier weights D~ <= 1/delta of rows on the STATES (output bounds, input bounds) in the same entries as the O(1)
-        // curvature of the objective: at delta = 1e-12 the latter keeps 4 digits and heavily constrained controllers end
-        // 1e-4 from the optimum; at 1e-8 the primal residual delta*dlam of soft rows with 1e5-size multipliers stalls.
-        // Measured on 2048 C3 controllers against the condensed kernel (scripts/ms_c3_check.py, profiles/r4):
-        // delta 1e-10 / 1e-9 / 1e-8: 99.9 % quantile of the dU difference 4e-2 / 4e-7 / 1e-5, not OPTIMAL 23 / 2 / 3.
+        {   // horizon-long data of the resident wavefronts when they do not fit the LDS share (ms_kernels.hip)
+            int nslots = 0;
+            const size_t sb = ms_scratch_bytes(d, h->m, &nslots);
+            if (sb) {
+                rc = dev_alloc(h, h->ms_scratch, sb);
+                if (rc) return rc;
+                ms.scratch = (double*)h->ms_scratch.p; ms.nslots = nslots;
+            }
+        }
+        // (dual regularisation: the handle's, default 1e-12 like the condensed kernels.  Measured on 8192 C3 controllers
+        //  against the condensed kernel once the gains of the Riccati recursion are refined (ms_bodies.h: factor):
+        //  delta 1e-12 / 1e-10 / 1e-9: not OPTIMAL 0 / 3 / 5, worst dU difference 2.7e-6 / 1.4e-2 / 1 (error branch), 99.9 %
+        //  quantile 2e-7 / 3e-8 / 2e-7; profiles/r4/ms_delta_sweep.txt)
         Dims dm = d;
-        if (!h->dual_reg_given) dm.dual_reg = 1e-9;
         HIPCHK(launch_ms_step(dm, h->m, io, ms, st));
     } else {
         HIPCHK(launch_step(d, h->m, io, st));

@@ -34,6 +34,13 @@
 #include "mpcqp_bodies.h"
 #include "mpcqp_types.h"
 
+#ifndef MPCQP_MS_LDS_SHARE
+#define MPCQP_MS_LDS_SHARE (40 * 1024)   // horizon-long data stay in LDS up to this many bytes per wavefront (160 KB / 4: measured
+                                         // on C2 shapes, 24 KB: 29 ms in LDS against 70 ms through the HBM scratch for 8192 controllers)
+#endif
+#ifndef MPCQP_MS_ADAPT_DELTA
+#define MPCQP_MS_ADAPT_DELTA 0      // (experiment: delta / 10 when r_p stalls at small mu -- fewer flagged solves on C3, but randomised family 1 then wanders at mu < 1e-13: off)
+#endif
 #ifndef MPCQP_MS_REFINE
 #define MPCQP_MS_REFINE 0         // steps of iterative refinement per Newton solve (MsStep::newton; measured: no gain, see there)
 #endif
@@ -44,6 +51,8 @@ namespace mpcqp {
 struct MsIO {
     double* Xhat;     // [B][Hp][nxh]  X^0(k+1..k+Hp) at the optimum (the second block of Z), may be null
     double* defect;   // [B]           max |E_S Z + F_S| at the returned point, may be null
+    double* scratch;  // [nslots][big] horizon-long data of the resident wavefronts (null: they live in LDS)
+    int nslots;
 };
 
 enum { MS_UMIN = 0, MS_UMAX, MS_DUMIN, MS_DUMAX, MS_YMIN, MS_YMAX, MS_XMIN, MS_XMAX, MS_EPS, MS_NGROUP };
@@ -63,13 +72,15 @@ struct MsCarve {
     int ry, ru;                         // targets: C^ x - ry[t] with ry = R^y - D^d d^ (nY); u - ru (nU)
     int QY, QV, RD;                     // stage Hessian diagonals: output weight 2M + D_Y (nY), 2L + D_U (nU), 2N + D_dU (nDU)
     int CX, CD;                         // C^ x of the iterate / of a direction (nY)
-    int P, K, Li, pv, kk;               // factor: P_t packed lower [Hp][npk], K_t [Hc][nu][ns], Lam^-1 [Hc][nu][nu], p_t [Hp][ns], k_t [nDU]
-    int S, T, wv, av;                   // stage work: S, T (ns x ns), w, a (ns)
+    int P, K, Li, Lm, pv, kk;               // factor: P_t packed lower [Hp][npk], K_t [Hc][nu][ns], Lam^-1 [Hc][nu][nu], p_t [Hp][ns], k_t [nDU]
+    int S, T, wv, av, Pl;               // stage work: S, T (ns x ns), w, a (ns); P_{t+1} of the stage in flight (packed)
     int x0, lu;                         // x^0(k), u0(k-1)
     int rows[MS_NROWARR];
     int rowoff[MS_NGROUP + 1];
     int jl, ctrl;                       // int tables: first step of block j [Hc+1]; block that starts at step t or -1 [Hp]
     int nrows, total;
+    int small, big;                     // doubles of the always-in-LDS block / of the horizon-long data
+    bool big_in_lds;
 };
 
 MPCQP_HD inline int ms_group_count(const Dims& d, int g) {
@@ -101,7 +112,18 @@ MPCQP_HD inline MsCarve make_ms_carve(const Dims& d, const Model& m) {
     const int nX = nx * Hp, nV = nu * Hp, nDU = d.nDU, nY = d.nY, npk = ns * (ns + 1) / 2;
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 1) & ~1; return r; };
+    // -- always in LDS (offsets from the LDS base): the model, the work matrices of a stage, the horizon tables
     c.A = take(nx * nx); c.Bu = take(nx * nu); c.C = take(ny * nx);
+    c.S = take(ns * ns); c.T = take(ns * ns); c.wv = take(ns > ny ? ns : ny); c.av = take(ns);
+    c.Pl = take(npk);                   // cost-to-go of the stage in flight (copy of P_{t+1}: ns^3 reads per stage)
+    c.x0 = take(nx); c.lu = take(nu);
+    c.jl = take((Hc + 2) / 2 + 1);
+    c.ctrl = take((Hp + 1) / 2 + 1);
+    c.small = o;
+    // -- the horizon-long data (offsets from the "big" base): behind the small block in LDS when everything fits a share
+    //    of the LDS that keeps eight wavefronts per CU resident, else in a per-wavefront scratch in HBM (make_ms_carve's
+    //    `big_in_lds`; the kernels are instantiated for both placements)
+    o = 0;
     c.X = take(nX); c.V = take(nV); c.DU = take(nDU);
     c.NX = take(nX); c.NV = take(nV);
     c.dX = take(nX); c.dV = take(nV); c.dDU = take(nDU); c.nX = take(nX); c.nV = take(nV);
@@ -114,9 +136,7 @@ MPCQP_HD inline MsCarve make_ms_carve(const Dims& d, const Model& m) {
     c.ry = take(nY); c.ru = take(nV);
     c.QY = take(nY); c.QV = take(nV); c.RD = take(nDU);
     c.CX = take(nY); c.CD = take(nY);
-    c.P = take(Hp * npk); c.K = take(Hc * nu * ns); c.Li = take(Hc * nu * nu); c.pv = take(Hp * ns); c.kk = take(nDU);
-    c.S = take(ns * ns); c.T = take(ns * ns); c.wv = take(ns); c.av = take(ns);
-    c.x0 = take(nx); c.lu = take(nu);
+    c.P = take(Hp * npk); c.K = take(Hc * nu * ns); c.Li = take(Hc * nu * nu); c.Lm = take(Hc * nu * nu); c.pv = take(Hp * ns); c.kk = take(nDU);
     int r = 0;
     for (int g = 0; g < MS_NGROUP; ++g) {
         c.rowoff[g] = r;
@@ -125,15 +145,16 @@ MPCQP_HD inline MsCarve make_ms_carve(const Dims& d, const Model& m) {
     c.rowoff[MS_NGROUP] = r;
     c.nrows = r;
     for (int a = 0; a < MS_NROWARR; ++a) c.rows[a] = take(r);
-    c.jl = take((Hc + 2) / 2 + 1);
-    c.ctrl = take((Hp + 1) / 2 + 1);
-    c.total = o;
+    c.big = o;
+    c.big_in_lds = (size_t)(c.small + c.big) * sizeof(double) <= MPCQP_MS_LDS_SHARE;
+    c.total = c.small + (c.big_in_lds ? c.big : 0);      // doubles of LDS per wavefront
     return c;
 }
 
 template <class W>
 struct MsStep {
     W& w;
+    double* bg;         // base of the horizon-long data: LDS behind the small block, or this wavefront's HBM scratch
     const Dims& d;
     const Model& m;
     const StepIO& io;
@@ -147,15 +168,15 @@ struct MsStep {
     double eps = 0.0, deps = 0.0, delta, nh = 1.0, wsum = 0.0;
     int mact = 0;
 
-    MPCQP_HD MsStep(W& w_, const Dims& d_, const Model& m_, const StepIO& io_, int b_, double* sm_)
-        : w(w_), d(d_), m(m_), io(io_), b(b_), sm(sm_), c(make_ms_carve(d_, m_)), nx(d_.nxh), nu(d_.nu), ny(d_.ny), nd(d_.nd),
+    MPCQP_HD MsStep(W& w_, const Dims& d_, const Model& m_, const StepIO& io_, int b_, double* sm_, double* big_)
+        : w(w_), bg(big_), d(d_), m(m_), io(io_), b(b_), sm(sm_), c(make_ms_carve(d_, m_)), nx(d_.nxh), nu(d_.nu), ny(d_.ny), nd(d_.nd),
           ns(d_.nxh + d_.nu), Hp(d_.Hp), Hc(d_.Hc), nDU(d_.nDU), nY(d_.nY), nXt(d_.nxh * d_.Hp), nVt(d_.nu * d_.Hp),
           npk((d_.nxh + d_.nu) * (d_.nxh + d_.nu + 1) / 2) {
         jlt = reinterpret_cast<int*>(sm + c.jl);
         ctrl = reinterpret_cast<int*>(sm + c.ctrl);
         A = sm + c.A; Bu = sm + c.Bu; Cm = sm + c.C;
-        rh = sm + c.rows[0]; rs = sm + c.rows[1]; rl = sm + c.rows[2]; rrp = sm + c.rows[3];
-        rgd = sm + c.rows[4]; rpp = sm + c.rows[5]; rcs = sm + c.rows[6]; rwi = sm + c.rows[7];
+        rh = bg + c.rows[0]; rs = bg + c.rows[1]; rl = bg + c.rows[2]; rrp = bg + c.rows[3];
+        rgd = bg + c.rows[4]; rpp = bg + c.rows[5]; rcs = bg + c.rows[6]; rwi = bg + c.rows[7];
         delta = d.dual_reg;
     }
 
@@ -214,7 +235,7 @@ struct MsStep {
                 const double de = t == 0 ? io.d0[(size_t)b * nd + e] : io.Dhat0[(size_t)b * d.nD + (t - 1) * nd + e];
                 acc += m.Bd[(size_t)b * nx * nd + r + nx * e] * de;
             }
-            sm[c.gv + i] = acc;
+            bg[c.gv + i] = acc;
         }
         // output target of stage t: R^y - Yop - D^d d^0(k+t+1)  (F = J D^0, transcription.jl:232; execute.jl:262-266)
         const bool rconst = d.flags & 1u;
@@ -222,9 +243,9 @@ struct MsStep {
             const int t = r / ny, a = r - t * ny;
             double acc = rconst ? io.Ry[(size_t)b * ny + a] : io.Ry[(size_t)b * nY + r];
             for (int e = 0; e < nd; ++e) acc -= m.Dd[(size_t)b * ny * nd + a + ny * e] * io.Dhat0[(size_t)b * d.nD + t * nd + e];
-            sm[c.ry + r] = acc;
+            bg[c.ry + r] = acc;
         }
-        for (int r = w.lane; r < nVt; r += WAVE) sm[c.ru + r] = io.Ru ? io.Ru[(size_t)b * d.nU + r] : 0.0;
+        for (int r = w.lane; r < nVt; r += WAVE) bg[c.ru + r] = io.Ru ? io.Ru[(size_t)b * d.nU + r] : 0.0;
         w.sync();
     }
 
@@ -276,7 +297,7 @@ struct MsStep {
             for (int cc = w.lane; cc < nu; cc += WAVE) Vv[t * nu + cc] = vat(Vv, t - 1, cc, false) + (j >= 0 ? DU[j * nu + cc] : 0.0);
             w.sync();
             for (int i = w.lane; i < nx; i += WAVE) {
-                double acc = sm[c.gv + t * nx + i];
+                double acc = bg[c.gv + t * nx + i];
                 for (int k = 0; k < nx; ++k) acc += A[i + nx * k] * xat(Xv, t - 1, k, false);
                 for (int cc = 0; cc < nu; ++cc) acc += Bu[i + nx * cc] * Vv[t * nu + cc];
                 Xv[t * nx + i] = acc;
@@ -332,7 +353,7 @@ struct MsStep {
             for (int a = 0; a < ny; ++a) {
                 const int r = t * ny + a;
                 double ty = rowv(MS_YMAX, r) - rowv(MS_YMIN, r);
-                if (with_cost) ty += 2.0 * m.Mdiag[(size_t)b * nY + r] * (sm[c.CX + r] - sm[c.ry + r]);
+                if (with_cost) ty += 2.0 * m.Mdiag[(size_t)b * nY + r] * (bg[c.CX + r] - bg[c.ry + r]);
                 acc += Cm[a + ny * k] * ty;
             }
             if (t == Hp - 1) acc += rowv(MS_XMAX, k) - rowv(MS_XMIN, k);
@@ -340,12 +361,12 @@ struct MsStep {
         }
         for (int i = w.lane; i < nVt; i += WAVE) {
             double acc = rowv(MS_UMAX, i) - rowv(MS_UMIN, i);
-            if (with_cost) acc += 2.0 * m.Ldiag[(size_t)b * d.nU + i] * (sm[c.V + i] - sm[c.ru + i]);
+            if (with_cost) acc += 2.0 * m.Ldiag[(size_t)b * d.nU + i] * (bg[c.V + i] - bg[c.ru + i]);
             oV[i] = acc;
         }
         for (int i = w.lane; i < nDU; i += WAVE) {
             double acc = rowv(MS_DUMAX, i) - rowv(MS_DUMIN, i);
-            if (with_cost) acc += 2.0 * m.Ndiag[(size_t)b * nDU + i] * sm[c.DU + i];
+            if (with_cost) acc += 2.0 * m.Ndiag[(size_t)b * nDU + i] * bg[c.DU + i];
             oDU[i] = acc;
         }
         w.sync();
@@ -405,10 +426,10 @@ struct MsStep {
             const int j = idx - i * (i + 1) / 2;
             double acc = 0.0;
             if (i < nx) {           // C^' diag(QY_t) C^  (+ terminal rows on the last stage)
-                for (int a = 0; a < ny; ++a) acc += Cm[a + ny * i] * sm[c.QY + t * ny + a] * Cm[a + ny * j];
+                for (int a = 0; a < ny; ++a) acc += Cm[a + ny * i] * bg[c.QY + t * ny + a] * Cm[a + ny * j];
                 if (t == Hp - 1 && i == j) acc += xterm(i);
             } else if (i == j) {
-                acc = sm[c.QV + t * nu + (i - nx)];
+                acc = bg[c.QV + t * nu + (i - nx)];
             }
             Pt[idx] += acc;
         }
@@ -456,7 +477,7 @@ struct MsStep {
     // held at D~ = 1/delta on the input part of the state) from each other and loses the definiteness of P within a few
     // stages (met on the GPU: randomised family 1, a pivot of Lam <= 0 at mu = 3e-7).  One product more per free move.
     MPCQP_HD bool factor() {
-        double* P = sm + c.P;
+        double* P = bg + c.P;
         double* S = sm + c.S;
         bool ok = true;
         double* PT = P + (size_t)(Hp - 1) * npk;
@@ -466,10 +487,12 @@ struct MsStep {
         w.sync();
         for (int t = Hp - 1; t >= 0; --t) {
             // stage t maps xi_t (stored at t-1; given for t = 0) to xi_{t+1} (stored at t)
-            const double* Pn = P + (size_t)t * npk;
+            double* const Pn = sm + c.Pl;                       // P_{t+1} staged in LDS: the products read it ns times over
+            for (int i = w.lane; i < npk; i += WAVE) Pn[i] = P[(size_t)t * npk + i];
+            w.sync();
             const int j = ctrl[t];
-            double* K = sm + c.K + (size_t)(j >= 0 ? j : 0) * nu * ns;
-            double* Li = sm + c.Li + (size_t)(j >= 0 ? j : 0) * nu * nu;
+            double* K = bg + c.K + (size_t)(j >= 0 ? j : 0) * nu * ns;
+            double* Li = bg + c.Li + (size_t)(j >= 0 ? j : 0) * nu * nu;
             PtimesM(Pn, nullptr);                               // T = P_{t+1} Abar
             if (j >= 0) {
                 // S_u. = Bbar' T (rows nx.. of Abar' T) into S[0 .. nu*ns); Lam = R + S_uu
@@ -481,8 +504,10 @@ struct MsStep {
                 for (int idx = w.lane; idx < nu * nu; idx += WAVE) {
                     const int a = idx / nu, e = idx - a * nu;
                     // (symmetrised: the two triangles of Bbar'P Bbar differ by rounding)
-                    Li[idx] = 0.5 * (S[a * ns + nx + e] + S[e * ns + nx + a]) + (a == e ? sm[c.RD + j * nu + a] : 0.0);
+                    Li[idx] = 0.5 * (S[a * ns + nx + e] + S[e * ns + nx + a]) + (a == e ? bg[c.RD + j * nu + a] : 0.0);
                 }
+                double* Lm = bg + c.Lm + (size_t)j * nu * nu;
+                for (int idx = w.lane; idx < nu * nu; idx += WAVE) Lm[idx] = Li[idx];
                 w.sync();
                 ok = invert_spd(Li) && ok;
                 for (int idx = w.lane; idx < nu * ns; idx += WAVE) {          // K = -Lam^-1 S_u.
@@ -490,6 +515,22 @@ struct MsStep {
                     double acc = 0.0;
                     for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * S[e * ns + col];
                     K[idx] = -acc;
+                }
+                w.sync();
+                // one refinement step of the gain: K -= Lam^-1 (S_u. + Lam K)  (the explicit inverse of a Lam with 1/delta-size
+                // entries next to O(0.1) ones leaves eps cond(Lam) in K; a row held at D~ = 1/delta multiplies that by 1e12)
+                for (int idx = w.lane; idx < nu * ns; idx += WAVE) {
+                    const int a = idx / ns, col = idx - a * ns;
+                    double acc = S[a * ns + col];
+                    for (int e = 0; e < nu; ++e) acc += Lm[a * nu + e] * K[e * ns + col];
+                    sm[c.T + idx] = acc;
+                }
+                w.sync();
+                for (int idx = w.lane; idx < nu * ns; idx += WAVE) {
+                    const int a = idx / ns, col = idx - a * ns;
+                    double acc = 0.0;
+                    for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * sm[c.T + e * ns + col];
+                    K[idx] -= acc;
                 }
                 w.sync();
             }
@@ -514,7 +555,7 @@ struct MsStep {
                     int i, jj;
                     unpack_low(idx, i, jj);
                     double acc = MtT(S, i, jj);
-                    for (int e = 0; e < nu; ++e) acc += K[e * ns + i] * sm[c.RD + j * nu + e] * K[e * ns + jj];
+                    for (int e = 0; e < nu; ++e) acc += K[e * ns + i] * bg[c.RD + j * nu + e] * K[e * ns + jj];
                     Pt[idx] = acc;
                 }
             } else {
@@ -536,11 +577,11 @@ struct MsStep {
     // in: gX, gV (stage gradients), gDU; out: oX, oV, oDU (the step), nuX, nuV (multipliers nu+)
     MPCQP_HD void sweep(const double* gX, const double* gV, const double* gDU, bool defect,
                         double* oX, double* oV, double* oDU, double* nuX, double* nuV) {
-        double* P = sm + c.P;
-        double* pv = sm + c.pv;
+        double* P = bg + c.P;
+        double* pv = bg + c.pv;
         double* wv = sm + c.wv;
         double* av = sm + c.av;
-        double* kk = sm + c.kk;
+        double* kk = bg + c.kk;
         // backward: p_t for t = Hp..1 (stored at t-1), k_j
         for (int i = w.lane; i < ns; i += WAVE) pv[(Hp - 1) * ns + i] = i < nx ? gX[(Hp - 1) * nx + i] : gV[(Hp - 1) * nu + i - nx];
         w.sync();
@@ -551,8 +592,8 @@ struct MsStep {
             for (int i = w.lane; i < ns; i += WAVE) {
                 double acc = pn[i];
                 if (defect) {
-                    for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * sm[c.cX + t * nx + k];
-                    for (int cc = 0; cc < nu; ++cc) acc += Pn[pidx(i, nx + cc)] * sm[c.cV + t * nu + cc];
+                    for (int k = 0; k < nx; ++k) acc += Pn[pidx(i, k)] * bg[c.cX + t * nx + k];
+                    for (int cc = 0; cc < nu; ++cc) acc += Pn[pidx(i, nx + cc)] * bg[c.cV + t * nu + cc];
                 }
                 wv[i] = acc;
             }
@@ -571,17 +612,30 @@ struct MsStep {
             w.sync();
             const int j = ctrl[t];
             if (j >= 0) {
-                const double* Li = sm + c.Li + (size_t)j * nu * nu;
+                const double* Li = bg + c.Li + (size_t)j * nu * nu;
                 // k_j = -Lam^-1 (g_u + (Abar'w)_u)
+                const double* Lm = bg + c.Lm + (size_t)j * nu * nu;
                 for (int a = w.lane; a < nu; a += WAVE) {
                     double acc = 0.0;
                     for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * (gDU[j * nu + e] + av[nx + e]);
                     kk[j * nu + a] = -acc;
                 }
                 w.sync();
+                for (int a = w.lane; a < nu; a += WAVE) {               // refinement: k -= Lam^-1 (h + Lam k)
+                    double acc = gDU[j * nu + a] + av[nx + a];
+                    for (int e = 0; e < nu; ++e) acc += Lm[a * nu + e] * kk[j * nu + e];
+                    wv[a] = acc;
+                }
+                w.sync();
+                for (int a = w.lane; a < nu; a += WAVE) {
+                    double acc = 0.0;
+                    for (int e = 0; e < nu; ++e) acc += Li[a * nu + e] * wv[e];
+                    kk[j * nu + a] -= acc;
+                }
+                w.sync();
             }
             if (t == 0) break;
-            const double* K = sm + c.K + (size_t)(j >= 0 ? j : 0) * nu * ns;
+            const double* K = bg + c.K + (size_t)(j >= 0 ? j : 0) * nu * ns;
             // p_t = g_xi[t] + a + K'(g_u + a_u)   and -K' Lam k = K'(g_u + a_u)  =>  use  K'(g_u + a_u)
             for (int i = w.lane; i < ns; i += WAVE) {
                 double acc = (i < nx ? gX[(t - 1) * nx + i] : gV[(t - 1) * nu + i - nx]) + av[i];
@@ -595,7 +649,7 @@ struct MsStep {
         for (int t = 0; t < Hp; ++t) {
             const int j = ctrl[t];
             if (j >= 0) {
-                const double* K = sm + c.K + (size_t)j * nu * ns;
+                const double* K = bg + c.K + (size_t)j * nu * ns;
                 for (int a = w.lane; a < nu; a += WAVE) {
                     double acc = kk[j * nu + a];
                     if (t > 0) {
@@ -607,14 +661,14 @@ struct MsStep {
                 w.sync();
             }
             for (int cc = w.lane; cc < nu; cc += WAVE)
-                oV[t * nu + cc] = vat(oV, t - 1, cc, true) + (j >= 0 ? oDU[j * nu + cc] : 0.0) + (defect ? sm[c.cV + t * nu + cc] : 0.0);
+                oV[t * nu + cc] = vat(oV, t - 1, cc, true) + (j >= 0 ? oDU[j * nu + cc] : 0.0) + (defect ? bg[c.cV + t * nu + cc] : 0.0);
             w.sync();
             // dx_{t+1} = A^ dx_t + B^u (dv_t + du_t) + c_x  (dv_t + du_t = dv_{t+1} - c_v)
             for (int i = w.lane; i < nx; i += WAVE) {
-                double acc = defect ? sm[c.cX + t * nx + i] : 0.0;
+                double acc = defect ? bg[c.cX + t * nx + i] : 0.0;
                 for (int k = 0; k < nx; ++k) acc += A[i + nx * k] * xat(oX, t - 1, k, true);
                 for (int cc = 0; cc < nu; ++cc)
-                    acc += Bu[i + nx * cc] * (oV[t * nu + cc] - (defect ? sm[c.cV + t * nu + cc] : 0.0));
+                    acc += Bu[i + nx * cc] * (oV[t * nu + cc] - (defect ? bg[c.cV + t * nu + cc] : 0.0));
                 oX[t * nx + i] = acc;
             }
             w.sync();
@@ -630,7 +684,7 @@ struct MsStep {
             for (int a = w.lane; a < ny; a += WAVE) {
                 double acc = 0.0;
                 for (int k = 0; k < nx; ++k) acc += Cm[a + ny * k] * oX[t * nx + k];
-                tmp[a] = acc * sm[c.QY + t * ny + a];
+                tmp[a] = acc * bg[c.QY + t * ny + a];
             }
             w.sync();
             for (int i = w.lane; i < ns; i += WAVE) {
@@ -644,7 +698,7 @@ struct MsStep {
                     nuX[t * nx + i] = acc;
                 } else {
                     const int cc = i - nx;
-                    acc = gV[t * nu + cc] + sm[c.QV + t * nu + cc] * oV[t * nu + cc];
+                    acc = gV[t * nu + cc] + bg[c.QV + t * nu + cc] * oV[t * nu + cc];
                     if (t + 1 < Hp) {
                         for (int k = 0; k < nx; ++k) acc += Bu[k + nx * cc] * nuX[(t + 1) * nx + k];
                         acc += nuV[(t + 1) * nu + cc];
@@ -666,12 +720,12 @@ struct MsStep {
 
     // ---- residuals of the iterate: r_p (rows), mu, defects c, dual residual with the current nu ----------
     MPCQP_HD void residuals(double& mu, double& rpn, double& rdn, double& ndd, double& cn, double& xs) {
-        double* X = sm + c.X; double* V = sm + c.V; double* DU = sm + c.DU;
-        C_apply(X, sm + c.CX);
+        double* X = bg + c.X; double* V = bg + c.V; double* DU = bg + c.DU;
+        C_apply(X, bg + c.CX);
         double musum = 0.0, rpmax = 0.0;
         for_rows([&](int g, int k, int r) {
             if (!fin(r)) return;
-            const double gz = prim(g, k, X, V, DU, sm + c.CX, eps) - (g == MS_EPS ? 0.0 : rcs[r] * eps);
+            const double gz = prim(g, k, X, V, DU, bg + c.CX, eps) - (g == MS_EPS ? 0.0 : rcs[r] * eps);
             const double v = gz + rs[r] - rh[r];
             rrp[r] = v;
             rpmax = fmax(rpmax, fabs(v));
@@ -684,31 +738,31 @@ struct MsStep {
         for (int i = w.lane; i < nVt; i += WAVE) {
             const int t = i / nu, cc = i - t * nu, j = ctrl[t];
             const double v = vat(V, t - 1, cc, false) + (j >= 0 ? DU[j * nu + cc] : 0.0) - V[i];
-            sm[c.cV + i] = v;
+            bg[c.cV + i] = v;
             cmax = fmax(cmax, fabs(v));
         }
         w.sync();
         for (int i = w.lane; i < nXt; i += WAVE) {
             const int t = i / nx, r = i - t * nx;
-            double acc = sm[c.gv + i] - X[i];
+            double acc = bg[c.gv + i] - X[i];
             for (int k = 0; k < nx; ++k) acc += A[r + nx * k] * xat(X, t - 1, k, false);
-            for (int cc = 0; cc < nu; ++cc) acc += Bu[r + nx * cc] * (V[t * nu + cc] + sm[c.cV + t * nu + cc]);
-            sm[c.cX + i] = acc;
+            for (int cc = 0; cc < nu; ++cc) acc += Bu[r + nx * cc] * (V[t * nu + cc] + bg[c.cV + t * nu + cc]);
+            bg[c.cX + i] = acc;
             cmax = fmax(cmax, fabs(acc));
             xmax = fmax(xmax, fabs(X[i]));
         }
         cn = w.maxv(cmax);
         xs = 1.0 + w.maxv(xmax);
         // gradient of the Lagrangian without the model multipliers: cost + G'lam  (into gX, gV, gDU)
-        const double ge = Gt_apply([&](int r) { return rl[r]; }, sm + c.gX, sm + c.gV, sm + c.gDU, true);
+        const double ge = Gt_apply([&](int r) { return rl[r]; }, bg + c.gX, bg + c.gV, bg + c.gDU, true);
         // + model multipliers: r_xi_t = g_t - nu_t + Abar' nu_{t+1};  r_u_j = g_u + (Abar' nu_{t+1})_u at t = j_l
         double mx = 0.0, sc = 0.0;
-        const double* NX = sm + c.NX; const double* NV = sm + c.NV;
+        const double* NX = bg + c.NX; const double* NV = bg + c.NV;
         for (int i = w.lane; i < nXt + nVt; i += WAVE) {
             const bool isx = i < nXt;
             const int ii = isx ? i : i - nXt;
             const int t = isx ? ii / nx : ii / nu, k = isx ? ii - t * nx : ii - t * nu;
-            double g0 = isx ? sm[c.gX + ii] : sm[c.gV + ii];
+            double g0 = isx ? bg[c.gX + ii] : bg[c.gV + ii];
             double nu_t = isx ? NX[ii] : NV[ii];
             double an = 0.0;                     // (Abar' nu_{t+2})[component]
             if (t + 1 < Hp) {
@@ -730,7 +784,7 @@ struct MsStep {
             const int j = i / nu, cc = i - j * nu, t = jlt[j];
             double an = NV[t * nu + cc];
             for (int kk2 = 0; kk2 < nx; ++kk2) an += Bu[kk2 + nx * cc] * NX[t * nx + kk2];
-            const double g0 = sm[c.gDU + i];
+            const double g0 = bg[c.gDU + i];
             const double r = g0 + an;
             mx = fmax(mx, fabs(r));
             sc = fmax(sc, fmax(fabs(g0), fabs(an)));
@@ -760,66 +814,66 @@ struct MsStep {
     template <class Fn>
     MPCQP_HD void newton(Fn rc, double phipsi, double phiee) {
         // g^ = cost gradient + G'(lam + D~ rp - wi rc)
-        const double ge0 = Gt_apply([&](int r) { return rl[r] + rwi[r] * (rl[r] * rrp[r] - rc(r)); }, sm + c.gX, sm + c.gV, sm + c.gDU, true);
-        sweep(sm + c.gX, sm + c.gV, sm + c.gDU, true, sm + c.dX, sm + c.dV, sm + c.dDU, sm + c.nX, sm + c.nV);
-        if (MPCQP_MS_REFINE) for (int i = w.lane; i < nDU; i += WAVE) sm[c.hDU + i] = sm[c.gDU + i];
+        const double ge0 = Gt_apply([&](int r) { return rl[r] + rwi[r] * (rl[r] * rrp[r] - rc(r)); }, bg + c.gX, bg + c.gV, bg + c.gDU, true);
+        sweep(bg + c.gX, bg + c.gV, bg + c.gDU, true, bg + c.dX, bg + c.dV, bg + c.dDU, bg + c.nX, bg + c.nV);
+        if (MPCQP_MS_REFINE) for (int i = w.lane; i < nDU; i += WAVE) bg[c.hDU + i] = bg[c.gDU + i];
         deps = 0.0;
         const double ge_keep = d.neps ? 2.0 * m.Cwt[b] * eps + ge0 : 0.0;
         if (d.neps) {
             const double ge = ge_keep;
-            const double fy = dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.dX, sm + c.dV, sm + c.dDU);
+            const double fy = dot_z(bg + c.fX, bg + c.fV, bg + c.fDU, bg + c.dX, bg + c.dV, bg + c.dDU);
             deps = -(ge + fy) / (phiee + phipsi);
-            for (int i = w.lane; i < nXt; i += WAVE) { sm[c.dX + i] += deps * sm[c.pX + i]; sm[c.nX + i] += deps * sm[c.qX + i]; }
-            for (int i = w.lane; i < nVt; i += WAVE) { sm[c.dV + i] += deps * sm[c.pV + i]; sm[c.nV + i] += deps * sm[c.qV + i]; }
-            for (int i = w.lane; i < nDU; i += WAVE) sm[c.dDU + i] += deps * sm[c.pDU + i];
+            for (int i = w.lane; i < nXt; i += WAVE) { bg[c.dX + i] += deps * bg[c.pX + i]; bg[c.nX + i] += deps * bg[c.qX + i]; }
+            for (int i = w.lane; i < nVt; i += WAVE) { bg[c.dV + i] += deps * bg[c.pV + i]; bg[c.nV + i] += deps * bg[c.qV + i]; }
+            for (int i = w.lane; i < nDU; i += WAVE) bg[c.dDU + i] += deps * bg[c.pDU + i];
             w.sync();
         }
-        // Optional iterative refinement (MPCQP_MS_REFINE, off).  As mu -> 0 the control rows of the Newton system are left
-        // with an O(1) residual (measured: 0.99 against terms of 6.6 at mu = 1e-9): the feedback form du = K dxi + k forms the
-        // 1e-12-size step of an input held at its bound as a difference of 1e-5-size numbers, and a row held at D~ = 1/delta
-        // turns that rounding into the residual.  The error lies in the stiff directions only -- the inputs agree with the
-        // oracle to 1e-11 -- and a refinement step with the same factor does not remove it (measured), so the dual residual
-        // cannot certify convergence at small mu: the termination test relies on the gap, the primal residual, the defect
-        // and the last-step criterion, with the stall rule of Step::run for r_d.  The state rows hold by construction
-        // (adjoint nu+), so the residual lives in the control rows and the slack row:
+        // Optional iterative refinement of the whole Newton solve (MPCQP_MS_REFINE, off: not needed once the gains are
+        // refined, see factor()).  History: with K = -Lam^-1 S_u. from the explicit inverse alone, the control rows of the
+        // Newton system were left with an O(1) residual as mu -> 0 (0.99 against terms of 6.6 at mu = 1e-9) -- eps cond(Lam)
+        // of relative error in K, times the 1e-5-size state step, times the 1e12 of a row held at D~ = 1/delta -- the dual
+        // residual grew instead of shrinking and the iterates wandered at mu < 1e-13.  One refinement step of K and k
+        // against the stored Lam brings that residual to 1e-10 .. 1e-14 and the dual residual to 1e-14 (quadratic
+        // convergence to the end).  The state rows hold by construction (adjoint nu+), so what is left lives in the control
+        // rows and the slack row:
         //     r_u = R du + g_u + Bbar' nu+ + phi_u deps,     r_e = g_e + phi'dz + Phi_ee deps
         // and the correction solves the same system for it (one more sweep with the same factor).
         for (int pass = 0; pass < MPCQP_MS_REFINE; ++pass) {
-            for (int i = w.lane; i < nXt; i += WAVE) sm[c.gX + i] = 0.0;
-            for (int i = w.lane; i < nVt; i += WAVE) sm[c.gV + i] = 0.0;
+            for (int i = w.lane; i < nXt; i += WAVE) bg[c.gX + i] = 0.0;
+            for (int i = w.lane; i < nVt; i += WAVE) bg[c.gV + i] = 0.0;
             double mxr = 0.0;
             for (int i = w.lane; i < nDU; i += WAVE) {
                 const int j = i / nu, cc = i - j * nu, t = jlt[j];
-                double an = sm[c.nV + t * nu + cc];
-                for (int k = 0; k < nx; ++k) an += Bu[k + nx * cc] * sm[c.nX + t * nx + k];
-                const double r = sm[c.RD + i] * sm[c.dDU + i] + sm[c.hDU + i] + an + sm[c.fDU + i] * deps;
-                sm[c.eDU + i] = r;
+                double an = bg[c.nV + t * nu + cc];
+                for (int k = 0; k < nx; ++k) an += Bu[k + nx * cc] * bg[c.nX + t * nx + k];
+                const double r = bg[c.RD + i] * bg[c.dDU + i] + bg[c.hDU + i] + an + bg[c.fDU + i] * deps;
+                bg[c.eDU + i] = r;
                 mxr = fmax(mxr, fabs(r));
             }
             w.sync();
-            for (int i = w.lane; i < nDU; i += WAVE) sm[c.gDU + i] = sm[c.eDU + i];
+            for (int i = w.lane; i < nDU; i += WAVE) bg[c.gDU + i] = bg[c.eDU + i];
             double re = 0.0;
-            if (d.neps) re = ge_keep + dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.dX, sm + c.dV, sm + c.dDU) + phiee * deps;
+            if (d.neps) re = ge_keep + dot_z(bg + c.fX, bg + c.fV, bg + c.fDU, bg + c.dX, bg + c.dV, bg + c.dDU) + phiee * deps;
             w.sync();
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_DEBUG_MS)
             { mxr = w.maxv(mxr); if (w.lane == 0 && b == MPCQP_DEBUG_MS) printf("      newton control-row residual %.3e slack row %.3e deps %.3e\n", mxr, re, deps); }
 #endif
-            sweep(sm + c.gX, sm + c.gV, sm + c.gDU, false, sm + c.eX, sm + c.eV, sm + c.eDU, sm + c.mX, sm + c.mV);
+            sweep(bg + c.gX, bg + c.gV, bg + c.gDU, false, bg + c.eX, bg + c.eV, bg + c.eDU, bg + c.mX, bg + c.mV);
             double de = 0.0;
             if (d.neps) {
-                const double fy = dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.eX, sm + c.eV, sm + c.eDU);
+                const double fy = dot_z(bg + c.fX, bg + c.fV, bg + c.fDU, bg + c.eX, bg + c.eV, bg + c.eDU);
                 de = -(re + fy) / (phiee + phipsi);
             }
-            for (int i = w.lane; i < nXt; i += WAVE) { sm[c.dX + i] += sm[c.eX + i] + de * sm[c.pX + i]; sm[c.nX + i] += sm[c.mX + i] + de * sm[c.qX + i]; }
-            for (int i = w.lane; i < nVt; i += WAVE) { sm[c.dV + i] += sm[c.eV + i] + de * sm[c.pV + i]; sm[c.nV + i] += sm[c.mV + i] + de * sm[c.qV + i]; }
-            for (int i = w.lane; i < nDU; i += WAVE) sm[c.dDU + i] += sm[c.eDU + i] + de * sm[c.pDU + i];
+            for (int i = w.lane; i < nXt; i += WAVE) { bg[c.dX + i] += bg[c.eX + i] + de * bg[c.pX + i]; bg[c.nX + i] += bg[c.mX + i] + de * bg[c.qX + i]; }
+            for (int i = w.lane; i < nVt; i += WAVE) { bg[c.dV + i] += bg[c.eV + i] + de * bg[c.pV + i]; bg[c.nV + i] += bg[c.mV + i] + de * bg[c.qV + i]; }
+            for (int i = w.lane; i < nDU; i += WAVE) bg[c.dDU + i] += bg[c.eDU + i] + de * bg[c.pDU + i];
             deps += de;
             w.sync();
         }
-        C_apply(sm + c.dX, sm + c.CD);
+        C_apply(bg + c.dX, bg + c.CD);
         for_rows([&](int g, int k, int r) {
             if (!fin(r)) return;
-            rgd[r] = prim(g, k, sm + c.dX, sm + c.dV, sm + c.dDU, sm + c.CD, deps) - (g == MS_EPS ? 0.0 : rcs[r] * deps);
+            rgd[r] = prim(g, k, bg + c.dX, bg + c.dV, bg + c.dDU, bg + c.CD, deps) - (g == MS_EPS ? 0.0 : rcs[r] * deps);
         });
         w.sync();
     }
@@ -827,29 +881,29 @@ struct MsStep {
     static constexpr int ST_OPTIMAL = 0, ST_ITERATION_LIMIT = 1, ST_ERROR = 2;
 
     MPCQP_HD int run(int& iters_out, double& defect_out) {
-        double* X = sm + c.X; double* V = sm + c.V; double* DU = sm + c.DU;
+        double* X = bg + c.X; double* V = bg + c.V; double* DU = bg + c.DU;
         // warm start: dU shifted (transcription.jl:1001-1004), X^0 rolled out from it, multipliers of the model 0
         const double* Zg = io.Z + (size_t)b * d.nZ;
         const bool cold = d.flags & 2u;
         for (int k = w.lane; k < nDU; k += WAVE) DU[k] = (!cold && k < nDU - nu) ? Zg[k + nu] : 0.0;
         eps = (!cold && d.neps) ? Zg[d.nZ - 1] : 0.0;
-        for (int i = w.lane; i < nXt; i += WAVE) sm[c.NX + i] = 0.0;
-        for (int i = w.lane; i < nVt; i += WAVE) sm[c.NV + i] = 0.0;
+        for (int i = w.lane; i < nXt; i += WAVE) bg[c.NX + i] = 0.0;
+        for (int i = w.lane; i < nVt; i += WAVE) bg[c.NV + i] = 0.0;
         w.sync();
         rollout(DU, X, V);
         const double eps_ws = eps;
         double mu = 0.0, rpn = 0.0, rdn = 0.0, ndd = 1.0, cn = 0.0, xs = 1.0;
         int status = ST_ITERATION_LIMIT, it = 0;
         // starting point of the rows: s = max(h - G z, 1), lam = 10 / s   (Step::run)
-        C_apply(X, sm + c.CX);
+        C_apply(X, bg + c.CX);
         for_rows([&](int g, int k, int r) {
             if (!fin(r)) return;
-            const double gz = prim(g, k, X, V, DU, sm + c.CX, eps) - (g == MS_EPS ? 0.0 : rcs[r] * eps);
+            const double gz = prim(g, k, X, V, DU, bg + c.CX, eps) - (g == MS_EPS ? 0.0 : rcs[r] * eps);
             rs[r] = fmax(rh[r] - gz, 1.0);
             rl[r] = 10.0 / rs[r];
         });
         w.sync();
-        double step_c = 1e300, zabs_c = 0.0, rd_prev = 1e300, alpha_prev = 0.0;
+        double step_c = 1e300, zabs_c = 0.0, rd_prev = 1e300, rp_prev = 1e300, alpha_prev = 0.0;
         const int max_iter = mact ? d.max_iter : 1;
         while (true) {
             residuals(mu, rpn, rdn, ndd, cn, xs);
@@ -862,6 +916,14 @@ struct MsStep {
             //  converged; the step criterion vouches for the inputs then.  Same rule as Step::run.)
             const bool rd_stalled = rdn >= 0.5 * rd_prev && alpha_prev >= 0.9;
             rd_prev = rdn;
+            // The primal residual of a dual-regularised iteration follows r_p <- (1 - alpha) r_p + alpha delta dlam: once the
+            // gap is small and r_p no longer shrinks although the steps are long, it sits on delta dlam -- rows whose
+            // multipliers still have a long way to go (soft rows, 2 Cwt eps ~ 1e5) -- and the iteration has become a method
+            // of multipliers with penalty 1/delta: a ten times smaller delta makes it ten times faster (down to 1e-12; a
+            // factorisation that breaks raises it again, below).
+            if (MPCQP_MS_ADAPT_DELTA && mu <= 1e-6 && rpn > 10.0 * d.res_tol * nh && rpn >= 0.5 * rp_prev && alpha_prev >= 0.5 && delta > 1e-12)
+                delta *= 0.1;
+            rp_prev = rpn;
             const bool conv = mu <= d.gap_tol && (rdn <= d.res_tol * ndd || rd_stalled) && rpn <= 10.0 * d.res_tol * nh &&
                               cn <= d.res_tol * xs && step_c <= 1e-6 * fmax(1.0, zabs_c);
             if (conv && mact) { status = ST_OPTIMAL; break; }
@@ -886,24 +948,24 @@ struct MsStep {
             auto dt_ = [&](int g, int k) { return on(g) ? rpp[c.rowoff[g] + k] : 0.0; };
             auto cs_ = [&](int g, int k) { return on(g) ? rcs[c.rowoff[g] + k] : 0.0; };
             for (int r = w.lane; r < nY; r += WAVE) {
-                sm[c.QY + r] = 2.0 * m.Mdiag[(size_t)b * nY + r] + dt_(MS_YMIN, r) + dt_(MS_YMAX, r);
-                sm[c.CD + r] = cs_(MS_YMIN, r) * dt_(MS_YMIN, r) - cs_(MS_YMAX, r) * dt_(MS_YMAX, r);      // tB of the output rows
+                bg[c.QY + r] = 2.0 * m.Mdiag[(size_t)b * nY + r] + dt_(MS_YMIN, r) + dt_(MS_YMAX, r);
+                bg[c.CD + r] = cs_(MS_YMIN, r) * dt_(MS_YMIN, r) - cs_(MS_YMAX, r) * dt_(MS_YMAX, r);      // tB of the output rows
             }
             for (int r = w.lane; r < nVt; r += WAVE) {
-                sm[c.QV + r] = 2.0 * m.Ldiag[(size_t)b * d.nU + r] + dt_(MS_UMIN, r) + dt_(MS_UMAX, r);
-                sm[c.fV + r] = cs_(MS_UMIN, r) * dt_(MS_UMIN, r) - cs_(MS_UMAX, r) * dt_(MS_UMAX, r);
+                bg[c.QV + r] = 2.0 * m.Ldiag[(size_t)b * d.nU + r] + dt_(MS_UMIN, r) + dt_(MS_UMAX, r);
+                bg[c.fV + r] = cs_(MS_UMIN, r) * dt_(MS_UMIN, r) - cs_(MS_UMAX, r) * dt_(MS_UMAX, r);
             }
             for (int r = w.lane; r < nDU; r += WAVE) {
-                sm[c.RD + r] = 2.0 * m.Ndiag[(size_t)b * nDU + r] + dt_(MS_DUMIN, r) + dt_(MS_DUMAX, r);
-                sm[c.fDU + r] = cs_(MS_DUMIN, r) * dt_(MS_DUMIN, r) - cs_(MS_DUMAX, r) * dt_(MS_DUMAX, r);
+                bg[c.RD + r] = 2.0 * m.Ndiag[(size_t)b * nDU + r] + dt_(MS_DUMIN, r) + dt_(MS_DUMAX, r);
+                bg[c.fDU + r] = cs_(MS_DUMIN, r) * dt_(MS_DUMIN, r) - cs_(MS_DUMAX, r) * dt_(MS_DUMAX, r);
             }
             w.sync();
             for (int i = w.lane; i < nXt; i += WAVE) {
                 const int t = i / nx, k = i - t * nx;
                 double acc = 0.0;
-                for (int a = 0; a < ny; ++a) acc += Cm[a + ny * k] * sm[c.CD + t * ny + a];
+                for (int a = 0; a < ny; ++a) acc += Cm[a + ny * k] * bg[c.CD + t * ny + a];
                 if (t == Hp - 1) acc += cs_(MS_XMIN, k) * dt_(MS_XMIN, k) - cs_(MS_XMAX, k) * dt_(MS_XMAX, k);
-                sm[c.fX + i] = acc;
+                bg[c.fX + i] = acc;
             }
             w.sync();
             if (!factor()) {
@@ -918,8 +980,8 @@ struct MsStep {
             const double phiee = d.neps ? 2.0 * m.Cwt[b] + ee : 1.0;
             if (d.neps) {
                 // psi = -Phi^-1 phi (no defects), its multipliers q
-                sweep(sm + c.fX, sm + c.fV, sm + c.fDU, false, sm + c.pX, sm + c.pV, sm + c.pDU, sm + c.qX, sm + c.qV);
-                phipsi = dot_z(sm + c.fX, sm + c.fV, sm + c.fDU, sm + c.pX, sm + c.pV, sm + c.pDU);
+                sweep(bg + c.fX, bg + c.fV, bg + c.fDU, false, bg + c.pX, bg + c.pV, bg + c.pDU, bg + c.qX, bg + c.qV);
+                phipsi = dot_z(bg + c.fX, bg + c.fV, bg + c.fDU, bg + c.pX, bg + c.pV, bg + c.pDU);
             }
             // restore rpp (it carried D~): not needed -- newton() overwrites it per pass below
             double smu = 0.0, tmax = 1.0;
@@ -972,12 +1034,12 @@ struct MsStep {
             }
             double stc = alpha >= 0.5 ? 0.0 : 1e300, zab = 0.0;      // (a blocked step says nothing about convergence)
             for (int k = w.lane; k < nDU; k += WAVE) {
-                const double st = alpha * sm[c.dDU + k];
+                const double st = alpha * bg[c.dDU + k];
                 stc = fmax(stc, fabs(st)); zab = fmax(zab, fabs(DU[k]));
                 DU[k] += st;
             }
-            for (int i = w.lane; i < nXt; i += WAVE) { X[i] += alpha * sm[c.dX + i]; sm[c.NX + i] += alpha * (sm[c.nX + i] - sm[c.NX + i]); }
-            for (int i = w.lane; i < nVt; i += WAVE) { V[i] += alpha * sm[c.dV + i]; sm[c.NV + i] += alpha * (sm[c.nV + i] - sm[c.NV + i]); }
+            for (int i = w.lane; i < nXt; i += WAVE) { X[i] += alpha * bg[c.dX + i]; bg[c.NX + i] += alpha * (bg[c.nX + i] - bg[c.NX + i]); }
+            for (int i = w.lane; i < nVt; i += WAVE) { V[i] += alpha * bg[c.dV + i]; bg[c.NV + i] += alpha * (bg[c.nV + i] - bg[c.NV + i]); }
             eps += alpha * deps;
             alpha_prev = alpha;
             step_c = w.maxv(stc); zabs_c = w.maxv(zab);
@@ -1001,29 +1063,30 @@ struct MsStep {
     }
 };
 
+// `scratch`: the wavefront's horizon-long data in HBM (make_ms_carve(d, m).big doubles), or null when they live in LDS
 template <class W>
-MPCQP_HD void ms_step_body(W& w, const Dims& d, const Model& m, const StepIO& io, const MsIO& ms, int b, double* sm) {
-    MsStep<W> st(w, d, m, io, b, sm);
+MPCQP_HD void ms_step_body(W& w, const Dims& d, const Model& m, const StepIO& io, const MsIO& ms, int b, double* sm, double* scratch) {
+    MsStep<W> st(w, d, m, io, b, sm, scratch ? scratch : sm + make_ms_carve(d, m).small);
     st.load();
     st.build_rows();
     int iters = 0;
     double defect = 0.0;
     const int status = st.run(iters, defect);
-    const double* DU = sm + st.c.DU;
+    const double* DU = st.bg + st.c.DU;
     for (int k = w.lane; k < d.nDU; k += WAVE) io.Z[(size_t)b * d.nZ + k] = DU[k];
     if (d.neps && w.lane == 0) io.Z[(size_t)b * d.nZ + d.nZ - 1] = st.eps;
     for (int k = w.lane; k < d.nu; k += WAVE) io.u0[(size_t)b * d.nu + k] = DU[k] + io.lastu0[(size_t)b * d.nu + k];
     if (io.Yhat0) {                // predict!: Y^0 = C^ X^0 + D^d D^0  (transcription.jl:1136-1145 with E = [0 diag(C^)])
-        st.C_apply(sm + st.c.X, sm + st.c.CX);
+        st.C_apply(st.bg + st.c.X, st.bg + st.c.CX);
         for (int r = w.lane; r < d.nY; r += WAVE) {
             const int t = r / d.ny, a = r - t * d.ny;
-            double acc = sm[st.c.CX + r];
+            double acc = st.bg[st.c.CX + r];
             for (int e = 0; e < d.nd; ++e) acc += m.Dd[(size_t)b * d.ny * d.nd + a + d.ny * e] * io.Dhat0[(size_t)b * d.nD + t * d.nd + e];
             io.Yhat0[(size_t)b * d.nY + r] = acc;
         }
     }
     if (ms.Xhat)
-        for (int i = w.lane; i < d.nxh * d.Hp; i += WAVE) ms.Xhat[(size_t)b * d.nxh * d.Hp + i] = sm[st.c.X + i];
+        for (int i = w.lane; i < d.nxh * d.Hp; i += WAVE) ms.Xhat[(size_t)b * d.nxh * d.Hp + i] = st.bg[st.c.X + i];
     if (w.lane == 0) {
         io.status[b] = status;
         if (io.iters) io.iters[b] = iters;

@@ -1,5 +1,9 @@
-// ms_kernels.hip -- gfx950 kernel of the MultipleShooting LinMPC step (ms_bodies.h): one controller per 64-lane
-// wavefront, one wavefront per workgroup, the stage data (iterate, Riccati factor, rows) in LDS.
+// ms_kernels.hip -- gfx950 kernels of the MultipleShooting LinMPC step (ms_bodies.h): one controller per 64-lane
+// wavefront, one wavefront per workgroup.  Two placements of the horizon-long data (iterate, Riccati factor, rows):
+//   k_ms_step    everything in LDS (small problems: up to MPCQP_MS_LDS_SHARE bytes per wavefront), grid = B;
+//   k_ms_step_g  the model and the work matrices of a stage in LDS, the horizon-long data in a per-wavefront scratch in
+//                HBM (L2-resident for the stage in flight); persistent grid of `nslots` wavefronts looping over the batch,
+//                so the scratch is nslots x big doubles whatever B -- any horizon, eight wavefronts per CU.
 #include <hip/hip_runtime.h>
 
 #include "mpcqp_bodies.h"
@@ -11,16 +15,50 @@ namespace mpcqp {
 
 __global__ __launch_bounds__(64) void k_ms_step(Dims d, Model m, StepIO io, MsIO ms) {
     DevWave w{(int)threadIdx.x};
-    ms_step_body(w, d, m, io, ms, (int)blockIdx.x, mpcqp_smem);
+    ms_step_body(w, d, m, io, ms, (int)blockIdx.x, mpcqp_smem, (double*)nullptr);
+}
+
+// (two wavefronts per SIMD: without the attribute the compiler takes 372 registers and leaves one)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ms_step_g(Dims d, Model m, StepIO io, MsIO ms, size_t big) {
+    DevWave w{(int)threadIdx.x};
+    double* scratch = ms.scratch + (size_t)blockIdx.x * big;
+    for (int b = (int)blockIdx.x; b < d.B; b += (int)gridDim.x) {
+        ms_step_body(w, d, m, io, ms, b, mpcqp_smem, scratch);
+        w.sync();
+    }
 }
 
 size_t ms_lds_bytes(const Dims& d, const Model& m) { return (size_t)make_ms_carve(d, m).total * sizeof(double); }
 
+// bytes of HBM scratch the step needs (0: everything lives in LDS) and the number of resident wavefronts
+size_t ms_scratch_bytes(const Dims& d, const Model& m, int* nslots) {
+    const MsCarve c = make_ms_carve(d, m);
+    if (c.big_in_lds) { if (nslots) *nslots = 0; return 0; }
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const size_t lds = (size_t)c.small * sizeof(double);
+    int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+    per_cu = per_cu > 8 ? 8 : per_cu < 1 ? 1 : per_cu;          // (the kernel's register budget: two wavefronts per SIMD)
+    int n = cus * per_cu;
+    if (n > d.B) n = d.B;
+    if (nslots) *nslots = n;
+    return (size_t)n * c.big * sizeof(double);
+}
+
 hipError_t launch_ms_step(const Dims& d, const Model& m, const StepIO& io, const MsIO& ms, hipStream_t st) {
-    const size_t lds = ms_lds_bytes(d, m);
-    hipError_t e = ensure_lds((const void*)k_ms_step, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ms_step, dim3(d.B), dim3(WAVE), lds, st, d, m, io, ms);
+    const MsCarve c = make_ms_carve(d, m);
+    const size_t lds = (size_t)c.total * sizeof(double);
+    if (c.big_in_lds) {
+        hipError_t e = ensure_lds((const void*)k_ms_step, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ms_step, dim3(d.B), dim3(WAVE), lds, st, d, m, io, ms);
+    } else {
+        if (!ms.scratch || ms.nslots < 1) return hipErrorInvalidValue;
+        hipError_t e = ensure_lds((const void*)k_ms_step_g, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ms_step_g, dim3(ms.nslots), dim3(WAVE), lds, st, d, m, io, ms, (size_t)c.big);
+    }
     return hipGetLastError();
 }
 

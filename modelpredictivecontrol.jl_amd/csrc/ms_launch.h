@@ -8,4 +8,5 @@ namespace mpcqp {
 struct MsIO;
 hipError_t launch_ms_step(const Dims& d, const Model& m, const StepIO& io, const MsIO& ms, hipStream_t st);
 size_t ms_lds_bytes(const Dims& d, const Model& m);
+size_t ms_scratch_bytes(const Dims& d, const Model& m, int* nslots);    // HBM scratch of the step (0: all in LDS)
 }  // namespace mpcqp

@@ -101,12 +101,20 @@ def test_multiple_shooting_kernel_on_an_unstable_plant_on_the_emulator(emulib):
 
 
 def test_multiple_shooting_fallback_is_announced(emulib):
-    """A MultipleShooting controller the stage-structured kernel does not take (here: Hp = 1000, whose stage data exceed
-    the 160 KB of LDS) keeps the SingleShooting kernels -- same optimal ΔU -- and says so."""
-    model = es.LinModelOracle(*es.tf1_zoh(5.0, 2.0, 3.0), Ts=3.0)
-    kf = es.SteadyKalmanFilterOracle(model)
+    """A MultipleShooting controller the stage-structured kernel does not take (here: a block-diagonal M_Hp) keeps the
+    SingleShooting kernels -- same optimal ΔU -- and says so."""
+    rng = np.random.default_rng(5)
+    Ah, Bhu, Ch = _plant(rng, 3, 2, 2)
     rep = lambda M: np.repeat(np.asarray(M, float)[None], 2, 0)
-    mpc = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), Hp=1000, Hc=1, Nwt=[0], transcription="MultipleShooting", lib=emulib)
+    Hp = 6
+    M = np.kron(np.eye(Hp), np.array([[2.0, 0.3], [0.3, 1.0]]))
+    kw = dict(Hp=Hp, Hc=2, M_Hp=M, Nwt=[0.1, 0.1])
+    mpc = mpcqp.BatchLinMPC(rep(Ah), rep(Bhu), rep(Ch), transcription="MultipleShooting", lib=emulib, **kw)
+    x0, ry = rng.standard_normal(5), rng.standard_normal(2)
     with pytest.warns(RuntimeWarning, match="MultipleShooting kernel not available"):
-        u = mpc.moveinput(np.zeros((2, kf.nxh)), [15.0])
-    assert mpc.kernel != api.KERNEL_MS and np.allclose(u, 3.0, atol=1e-2)
+        mpc.moveinput(rep(x0), ry)
+    assert mpc.kernel != api.KERNEL_MS
+    o = cd.LinMPCOracle(Ah, Bhu, Ch, **kw)
+    o.moveinput(x0, ry)
+    assert np.abs(mpc.Z[0, :o.nDU] - o.Zt[:o.nDU]).max() <= 1e-8
+    assert mpc.getinfo()["Z̃"].shape[1] == o.nDU + 5 * Hp + 1          # [ΔU; X̂0; ϵ]: the MultipleShooting layout all the same
