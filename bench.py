@@ -64,7 +64,7 @@ def algorithmic_bytes(cfg):
 class Shard:
     """This rank's contiguous shard [lo, lo + B) of a seeded global batch, resident on its GPU."""
 
-    def __init__(self, cfg, lo, B, seed, local):
+    def __init__(self, cfg, lo, B, seed, local, multiple_shooting=False):
         import torch
         import mpcqp
         from mpcqp import synth
@@ -81,7 +81,10 @@ class Shard:
         hd.set_bounds(U0min=full(cfg.umin, hd.nU), U0max=full(cfg.umax, hd.nU),
                       DUmin=full(cfg.dumin, hd.nDU), DUmax=full(cfg.dumax, hd.nDU),
                       Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY))
-        self.kernel = hd.prepare()              # specialised kernel (compiled once per shape, never in a step)
+        if multiple_shooting:                   # the stage-structured kernel (csrc/ms_bodies.h): nothing to prepare
+            hd.set_transcription(mpcqp.api.MULTIPLE_SHOOTING)
+            assert hd.transcription_supported() == 0
+        self.kernel = mpcqp.api.KERNEL_MS if multiple_shooting else hd.prepare()   # specialised kernel (compiled once per shape, never in a step)
         self.hd = hd
         dev = torch.device("cuda", local)
         self.dev = dev
@@ -387,6 +390,28 @@ def secondary(args, local):
                                   "frac": ach / FP64_PEAK_TFLOPS, "flops_per_solve": flops}})
         del sh
         torch.cuda.empty_cache()
+    # the MultipleShooting transcription on its stage-structured kernel (Riccati recursion inside the
+    # interior-point iteration; horizon-long data in a per-wavefront HBM scratch): a long-horizon shape, Hp = Hc = 50.
+    # Flops: per iteration and stage three ns x ns x ns products of the Joseph-form recursion (6 ns^3) and five vector
+    # sweeps of ~8 ns^2; the condensed record of the same shape would be cheaper -- this kernel is the ROBUST path
+    # (unstable plants, cond(H~) up to 3e13: profiles/r4/ms_vs_condensed_unstable_plants.txt), not the fast one.
+    for name, B in (("6,2,2,50,50", 8192),):
+        cfg = synth.get_config(name)
+        sh = Shard(cfg, 0, B, args.seed, local, multiple_shooting=True)
+        elapsed, kern_ms = timed_run(sh, max(1, args.steps // 4), 1, None)
+        status, iters = sh.t_st.cpu().numpy(), sh.t_it.cpu().numpy()
+        ns = cfg.nxh + cfg.nu
+        flops = float(iters.mean()) * cfg.Hp * (6.0 * ns ** 3 + 40.0 * ns ** 2)
+        kms = float(np.mean(kern_ms))
+        ach = flops * B / (kms * 1e-3) / 1e12
+        recs.append({"workload": cfg.name + ", transcription = MultipleShooting", "batch": B, "metric": "QP solves/sec (moveinput!)",
+                     "value": B * max(1, args.steps // 4) / elapsed, "unit": "solves/s", "ms_per_step": elapsed / max(1, args.steps // 4) * 1e3,
+                     "kernel_ms": kms, "ipm_mean_iters": float(iters.mean()), "optimal_fraction": float((status == 0).mean()),
+                     "kernel": "k_ms_step_g (stage-structured MultipleShooting kernel, HBM scratch)",
+                     "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / FP64_PEAK_TFLOPS, "flops_per_solve": flops}})
+        del sh
+        torch.cuda.empty_cache()
     a5 = copy.copy(args)
     a5.config, a5.batch = "C5", 0
     r5 = bench_mhe.measure(a5, 0, 1, local, None, cpu=not args.no_cpu_baseline)
@@ -396,6 +421,15 @@ def secondary(args, local):
                  "optimal_fraction": r5["config"]["optimal_fraction"], "kernel": "k_mhe_step (+ 2 k_mhe_cov per period)",
                  "roofline": {k: r5["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flops_per_solve")},
                  "cpu_baseline": r5.get("cpu_baseline")})
+    # the soft variant of the estimator kernel (bounds relaxed by the slack: k_mhe_step<12, 15>), VERDICT r3 item 4
+    a5s = copy.copy(args)
+    a5s.config, a5s.batch = "C5S", 0
+    r5s = bench_mhe.measure(a5s, 0, 1, local, None, cpu=False)
+    recs.append({"workload": r5s["config"]["workload"], "batch": r5s["config"]["batch_per_gpu"], "metric": r5s["metric"],
+                 "value": r5s["value"], "unit": r5s["unit"], "ms_per_step": r5s["ms_per_step"],
+                 "kernel_ms": r5s["roofline"]["kernel_ms"], "ipm_mean_iters": r5s["config"]["ipm_mean_iters"],
+                 "optimal_fraction": r5s["config"]["optimal_fraction"], "kernel": "k_mhe_step, soft variant (+ 2 k_mhe_cov per period)",
+                 "roofline": {k: r5s["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "flops_per_solve")}})
     return recs
 
 

@@ -46,6 +46,9 @@ class MheShard:
         neg = lambda a: None if a is None else -a
         h.set_bounds(neg(full(cfg.xabs, cfg.nxh)), full(cfg.xabs, cfg.nxh), neg(full(cfg.wabs, cfg.nxh)),
                      full(cfg.wabs, cfg.nxh), neg(full(cfg.vabs, cfg.nym)), full(cfg.vabs, cfg.nym))
+        if np.isfinite(cfg.Cwt):                 # bounds relaxed by the slack (soft kernel variant)
+            one = np.ones((B, cfg.nxh))
+            h.set_softness(np.full(B, cfg.Cwt), c_xmin=one if np.isfinite(cfg.xabs) else None, c_xmax=one if np.isfinite(cfg.xabs) else None)
         h.init(None, bt["P0"])
         self.h = h
         dev = torch.device("cuda", local)
@@ -194,6 +197,46 @@ def _cpu_worker(job):
 
 
 def cpu_baseline(cfg, args):
+    """The oracle's C port of the estimator period (oracle/mhe_ref.c: the same QP in the state-sequence, block-tridiagonal
+    form the GPU kernel solves, Mehrotra interior point, OpenMP over estimators) on this box's host cores: a bounded
+    sample of the same workload.  Steady-state periods only: the time of a run over the window fill alone is subtracted
+    from a run over fill + K periods.  (Round 3 timed the dense NumPy oracle here, 166 solves/s on 256 cores: the
+    reference's condensed 252-variable QP -- kept as `numpy_dense_oracle` for the record when MPCQP_BENCH_NUMPY_MHE=1.)"""
+    from mpcqp import synth
+    from oracle import mhe_cport
+    if cfg.nd or not cfg.direct or np.isfinite(cfg.wabs) or np.isfinite(cfg.vabs) or np.isfinite(cfg.Cwt):
+        return {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "the C port covers x̂ bounds, current form, nd = 0"}
+    threads = mhe_cport.threads()
+    n = 64 * max(1, threads // 4)
+    K = 8
+    bt = synth.make_mhe_batch(cfg, n, seed=args.seed)
+    Y, U, _ = synth.make_mhe_data(cfg, bt, cfg.He + K, seed=args.seed)
+    t0 = time.perf_counter()
+    mhe_cport.run(bt, Y[:cfg.He], U[:cfg.He], cfg.He, cfg.xabs)
+    t_fill = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, it, st = mhe_cport.run(bt, Y, U, cfg.He, cfg.xabs)
+    t_all = time.perf_counter() - t0
+    rate = n * K / max(t_all - t_fill, 1e-9)
+    # scale the sample to ~cpu_seconds of work
+    K2 = int(max(K, min(400, rate * args.cpu_seconds / n)))
+    if K2 > K:
+        Y, U, _ = synth.make_mhe_data(cfg, bt, cfg.He + K2, seed=args.seed)
+        t0 = time.perf_counter()
+        _, it, st = mhe_cport.run(bt, Y, U, cfg.He, cfg.xabs)
+        t_all = time.perf_counter() - t0
+        K = K2
+        rate = n * K / max(t_all - t_fill, 1e-9)
+    out = {"value": rate, "unit": "solves/s", "cores": int(threads), "kind": "port",
+           "sample": f"{n} estimators of the same workload x {K} steady-state periods (full window; the window fill timed separately and "
+                     f"subtracted), {t_all - t_fill:.1f} s; oracle/mhe_ref.c: block-tridiagonal state-sequence QP, Mehrotra interior point, "
+                     f"OpenMP over estimators, mean {float(it[cfg.He:].mean()):.1f} iterations, all solved: {bool((st == 0).all())}"}
+    if os.environ.get("MPCQP_BENCH_NUMPY_MHE") == "1":
+        out["numpy_dense_oracle"] = cpu_baseline_numpy(cfg, args)
+    return out
+
+
+def cpu_baseline_numpy(cfg, args):
     """oracle/mhe.py (dense NumPy restatement of the reference's condensed QP + exact active-set solve) on every host
     core: one estimator of the same workload per core (single-threaded BLAS), a bounded number of steady-state periods
     each; value = sum over the cores of periods / seconds.  Runs in a fresh interpreter (no GPU runtime in the process

@@ -130,6 +130,16 @@ function BatchLinMPC(mpcs::Vector{<:LinMPC}; device::Integer=0, flags::Unsigned=
     push_bounds!(h[], mpcs)
     # the specialised kernel of this shape and constraint pattern: built here (once per shape and
     # machine, cached), never inside a step -- the analogue of init_optimization! (linmpc.jl:303-339)
+    # transcription of the controllers (LinMPC keyword, linmpc.jl:205-216): MultipleShooting runs on the stage-structured
+    # kernel (include/mpcqp.h: mpcqp_set_transcription) when the handle qualifies, else the condensed kernels solve the
+    # same problem
+    if m.transcription isa MultipleShooting
+        check(ccall((:mpcqp_set_transcription, lib), Cint, (Ptr{Cvoid}, Cint), h[], 1))
+        if ccall((:mpcqp_transcription_supported, lib), Cint, (Ptr{Cvoid},), h[]) != 0
+            @warn "MultipleShooting kernel not available for these controllers: the SingleShooting kernels solve the same problem"
+            check(ccall((:mpcqp_set_transcription, lib), Cint, (Ptr{Cvoid}, Cint), h[], 0))
+        end
+    end
     kernel = ccall((:mpcqp_prepare, lib), Cint, (Ptr{Cvoid},), h[])
     kernel < 0 && check(kernel)
     b = BatchLinMPC(h[], mpcs, zeros(m.nϵ + nΔU, B), cat2(c -> c.lastu0, mpcs), kernel, Cuint(flags))

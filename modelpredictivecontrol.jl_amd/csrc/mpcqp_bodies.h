@@ -1101,7 +1101,7 @@ MPCQP_HD void predmat_body(W& w, const Dims& d, const Model& m, int b, double* s
                 for (int l = 0; l < nx; ++l) acc += T0[r + nx * l] * A[l + nx * k];
                 T1[i] = acc;
             }
-        w.sync();
+        w.sync_lds();          // (the recursion lives in LDS; the tables streamed to HBM above are never read back here)
         { double* t_ = W0; W0 = W1; W1 = t_; }
         { double* t_ = P0; P0 = P1; P1 = t_; }
         { double* t_ = v0; v0 = v1; v1 = t_; }

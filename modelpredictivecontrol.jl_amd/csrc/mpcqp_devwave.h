@@ -28,6 +28,13 @@ struct DevWave {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
+    // The same for LDS traffic ONLY: outstanding global stores are not waited for (a kernel that streams its results
+    // out and never reads them back -- K1 -- otherwise sits out a store round trip at every step of its recursion).
+    __device__ __forceinline__ void sync_lds() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+
     template <int CTRL>
     static __device__ __forceinline__ double dpp(double v) {
         int lo = __double2loint(v), hi = __double2hiint(v);

@@ -144,7 +144,10 @@ class MheConfig:
 # BASELINE.json configs[4]: He = 20, nx̂ = 12 (8 plant states + 4 output integrators), hard state bounds
 C5 = MheConfig("C5: linear MHE nx̂=12 (8+4 integrators) nu=4 nym=4 He=20, hard x̂ bounds", nx=8, nu=4, nym=4, nd=0,
                He=20, xabs=1.5)
-MHE_CONFIGS = {"C5": C5}
+# the same workload with the state bounds relaxed by the slack ε (finite Cwt, softness 1 on x̂min / x̂max): the soft kernel variant
+C5S = MheConfig("C5 soft: linear MHE nx̂=12 nu=4 nym=4 He=20, x̂ bounds relaxed by ε (Cwt = 1e5)", nx=8, nu=4, nym=4, nd=0,
+                He=20, xabs=1.5, Cwt=1e5)
+MHE_CONFIGS = {"C5": C5, "C5S": C5S}
 
 
 def get_mhe_config(name: str) -> MheConfig:

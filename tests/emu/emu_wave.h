@@ -21,6 +21,7 @@ struct EmuWave {
     int lane;
     EmuShared* sh;
     void sync() { sh->bar.arrive_and_wait(); }
+    void sync_lds() { sync(); }
     double sum(double v) {
         sh->xd[lane] = v; sync();
         double s = 0.0;

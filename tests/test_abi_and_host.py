@@ -381,3 +381,21 @@ def test_prebuild_manifest_is_read_and_built_without_a_gpu(tmp_path):
     assert "specialisation in the cache" in out.stdout
     objs = [f for f in os.listdir(cache) if f.endswith("_3_2_7_12_4_1_cf_1.so")]
     assert len(objs) == 1 and re.match(r"spec_r\d+_c[0-9a-f]+_", objs[0])
+    # a machine WITHOUT hipcc whose cache was filled by a build host with another compiler -- the object
+    # carries that host's compiler id in its name, the directory is read-only (the normal deployment).  The lookup takes any
+    # object of the same kernel revision and shape (mpcqp_prepare compares it with the runtime-dimension kernel before a
+    # step may run it), and without one the error says what is missing.
+    shipped = re.sub(r"_c[0-9a-f]+_", "_c0badc0de_", objs[0], count=1)
+    os.rename(cache / objs[0], cache / shipped)
+    os.chmod(cache, 0o500)
+    try:
+        env2 = dict(env, HIPCC=str(tmp_path / "no-such-compiler"), HOME=str(tmp_path), XDG_CACHE_HOME=str(tmp_path / "xdg"))
+        out2 = subprocess.run([os.sys.executable, "-m", "mpcqp.prebuild", str(one)], env=env2, capture_output=True, text=True,
+                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+        assert out2.returncode == 0 and "specialisation in the cache" in out2.stdout, (out2.stdout, out2.stderr[-1500:])
+    finally:
+        os.chmod(cache, 0o700)
+    os.remove(cache / shipped)
+    out3 = subprocess.run([os.sys.executable, "-m", "mpcqp.prebuild", str(one)], env=env2, capture_output=True, text=True,
+                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert out3.returncode != 0 and "no compiler" in out3.stderr, out3.stderr[-1500:]

@@ -113,3 +113,33 @@ def test_reference_setmodel_known_answers():
     from tests import mhe_util
     for k, (v, want) in mhe_util.reference_setmodel(oracle=True).items():
         assert abs(v - want) <= 1e-3 * max(1.0, abs(want)), (k, v, want)
+
+
+def test_c_port_matches_the_numpy_oracle():
+    """oracle/mhe_ref.c (the cpu_baseline of bench.py --config C5: the estimator period in the block-tridiagonal
+    state-sequence form, like the GPU kernel) against oracle/mhe.py (the reference's condensed Z̃ = [x̂0arr; Ŵ], dense) on
+    the same data: the estimate x̂0(k) of every period -- growing window, first full window, moving window with the arrival
+    covariance corrected and advanced -- with state bounds that become active."""
+    import numpy as np
+    from mpcqp import synth
+    from oracle import estim as es, mhe as om, mhe_cport
+    cfg = synth.MheConfig("c-port check", nx=3, nu=2, nym=2, nd=0, He=4, xabs=0.8)
+    B, nper = 3, 9
+    bt = synth.make_mhe_batch(cfg, B, seed=1)
+    Y, U, _ = synth.make_mhe_data(cfg, bt, nper, seed=1)
+    xh, it, st = mhe_cport.run(bt, Y, U, cfg.He, cfg.xabs)
+    assert np.all(st == 0)
+    on_bound = False
+    for b in range(B):
+        e = om.MHEOracle(es.LinModelOracle(bt["A"][b], bt["Bu"][b], bt["C"][b]), He=cfg.He, direct=True,
+                         sigmaQ=np.full(cfg.nx, cfg.sigmaQ), sigmaR=np.full(cfg.nym, cfg.sigmaR),
+                         sigmaQint_ym=np.full(cfg.nym, cfg.sigmaQint), sigmaP_0=np.full(cfg.nx, cfg.sigmaP0),
+                         sigmaPint_ym_0=np.full(cfg.nym, cfg.sigmaP0), nint_ym=[1] * cfg.nym)
+        e.setconstraint(xhatmin=np.full(cfg.nxh, -cfg.xabs), xhatmax=np.full(cfg.nxh, cfg.xabs))
+        for k in range(nper):
+            x = e.preparestate(Y[k][b])
+            e.updatestate(U[k][b], Y[k][b])
+            assert e.status == 0
+            assert np.abs(x - xh[k, b]).max() <= 1e-7, (b, k)
+            on_bound = on_bound or np.abs(x).max() >= cfg.xabs - 1e-9
+    assert on_bound
