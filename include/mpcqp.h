@@ -137,7 +137,12 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
  * Not every handle can run MultipleShooting: mpcqp_transcription_supported returns 0 when it can, else a bit mask
  * (1 block / dense weight matrices, 2 custom linear constraints, 4 stage data beyond 160 KB of LDS, 8 KEEP_QP / WARM_DUAL
  * flags); a step of an unsupported MultipleShooting handle returns MPCQP_ERR_UNSUPPORTED (the Python mirror then keeps
- * the SingleShooting kernels and says so). */
+ * the SingleShooting kernels and says so).
+ *
+ * Size: a SingleShooting handle with nZ̃ = nu Hc + nϵ > 256 has no condensed kernel (its Newton matrix does not fit the
+ * LDS); it runs the same QP on the stage-structured kernel, whose cost is linear in the horizons -- the reference has no
+ * size limit (transcription.jl:2-4).  mpcqp_kernel_kind reports MPCQP_KERNEL_MS for it; the condensed tables
+ * (MPCQP_GET_HESSIAN, _STEPRESP, _KMAT, _BVEC) do not exist for such a handle (MPCQP_ERR_UNSUPPORTED). */
 #define MPCQP_SINGLE_SHOOTING    0
 #define MPCQP_MULTIPLE_SHOOTING  1
 int mpcqp_set_transcription(mpcqp_handle h, int32_t transcription);

@@ -892,6 +892,7 @@ class BatchLinMPC:
                 else:
                     self._ms_kernel = True
             self.kernel = KERNEL_MS if self._ms_kernel else self.hd.prepare()
+            self._ms_kernel = self.kernel == KERNEL_MS       # (also: nZ̃ > 256, which only the stage-structured kernel takes)
             self._prepared = True
         out = self.hd.step(xhat0, lastu0, (ry - self.yop) if held else (Rhaty - self.Yop), self.Z,
                            Ru=None if Rhatu is None else Rhatu - self.Uop, d0=d0, Dhat0=Dh0,

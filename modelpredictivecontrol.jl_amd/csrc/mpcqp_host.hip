@@ -49,6 +49,7 @@ struct mpcqp_handle_s {
     bool have_kf = false;
     // MultipleShooting transcription (mpcqp_set_transcription): the stage-structured kernel of ms_bodies.h
     int transcription = MPCQP_SINGLE_SHOOTING;
+    bool stage_only = false;         // nZ~ > 256: only the stage-structured kernel can take this handle (nothing is condensed)
     bool dual_reg_given = false;     // mpcqp_dims.dual_reg > 0 (else each kernel's own default)
     DBuf ms_X, ms_defect, ms_scratch;
 };
@@ -152,7 +153,11 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     const int nZ = in->nu * in->Hc + in->neps;
     // nZ~ <= 64: one Cholesky row per lane (specialised kernels); above that the runtime-dims kernel
     // gives every lane several rows, as long as the problem fits the 160 KB of LDS (checked in layout_rows)
-    if (nZ > 4 * WAVE) return MPCQP_ERR_UNSUPPORTED;
+    // Beyond nZ~ = 256 (the reference has no size limit: transcription.jl:2-4) there is no condensed kernel -- the Newton
+    // matrix alone would not fit the LDS.  Such handles run the SAME QP on the stage-structured kernel of ms_bodies.h
+    // (cost linear in the horizon, no nZ~ limit), whatever their transcription: `stage_only`.  Nothing is condensed for
+    // them (no K1 / K2 tables, no packed H~).
+    const bool stage_only = nZ > 4 * WAVE;
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (in->device < 0 || in->device >= ndev) return MPCQP_ERR_ARG;
@@ -173,6 +178,7 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
     d.res_tol = in->res_tol > 0 ? in->res_tol : 1e-11;
     d.dual_reg = in->dual_reg > 0 ? in->dual_reg : 1e-12;
     h->dual_reg_given = in->dual_reg > 0;
+    h->stage_only = stage_only;
     d.gmask = d.neps ? 1u : 0u;                        // ϵ >= 0 is always there
     layout_rows(h);
     h->device = in->device;
@@ -203,11 +209,13 @@ int mpcqp_create(const mpcqp_dims* in, mpcqp_handle* out) {
         return (double*)b.p;
     };
     const size_t B = d.B;
-    h->m.Stab = mk(B * d.Hp * d.ny * d.nu);
-    h->m.Ktab = mk(B * d.nxh * d.nY);
-    h->m.Bvec = mk(B * d.nY);
-    h->m.Hpk = mk(B * d.npk);
-    if (d.nd > 0) h->m.Gdtab = mk(B * d.Hp * d.ny * d.nd);
+    if (!stage_only) {
+        h->m.Stab = mk(B * d.Hp * d.ny * d.nu);
+        h->m.Ktab = mk(B * d.nxh * d.nY);
+        h->m.Bvec = mk(B * d.nY);
+        h->m.Hpk = mk(B * d.npk);
+        if (d.nd > 0) h->m.Gdtab = mk(B * d.Hp * d.ny * d.nd);
+    }
     if (!rc) {
         DBuf bj, bb;
         rc = dev_alloc(h, bj, (d.Hc + 1) * sizeof(int));
@@ -250,7 +258,7 @@ static bool terminal_on(const Dims& d) { return (d.gmask >> (2 * P_X)) & 3u; }
 
 static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
     const Dims& d = h->d;
-    if (!h->have_model) return MPCQP_OK;
+    if (!h->have_model || h->stage_only) return MPCQP_OK;
     const bool term = terminal_on(d);
     if (term && !h->m.exT) {
         DBuf a, b, c, x;
@@ -314,7 +322,7 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
     h->m.Ldiag = (const double*)h->Ldiag.p;
     h->m.Cwt = d.neps ? (const double*)h->Cwt.p : nullptr;
     h->have_weights = true;
-    if (h->have_model) {
+    if (h->have_model && !h->stage_only) {
         HIPCHK(launch_hessian(d, h->m, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -333,7 +341,7 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
     } else {
         h->m.Mblk = nullptr;
     }
-    if (h->have_model) {
+    if (h->have_model && !h->stage_only) {
         HIPCHK(launch_hessian(d, h->m, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -358,7 +366,7 @@ int mpcqp_set_dense_weights(mpcqp_handle h, const double* M_Hp, const double* N_
         }
     }
     d.dense_w = (h->m.Mfull || h->m.Ldense) ? 1 : 0;     // (a dense N_Hc only changes H̃: any step kernel serves it)
-    if (h->have_model) HIPCHK(launch_hessian(d, h->m, h->stream));
+    if (h->have_model && !h->stage_only) HIPCHK(launch_hessian(d, h->m, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -524,7 +532,7 @@ int mpcqp_set_transcription(mpcqp_handle h, int32_t transcription) {
 
 int mpcqp_transcription_supported(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
-    return h->transcription == MPCQP_MULTIPLE_SHOOTING ? ms_unsupported(h) : 0;
+    return (h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only) ? ms_unsupported(h) : 0;
 }
 
 // shared by mpcqp_step_device (kf = false) and mpcqp_loop_device
@@ -549,7 +557,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     const Dims& d = h->d;
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
-    if (h->transcription != MPCQP_MULTIPLE_SHOOTING && step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
+    if (h->transcription != MPCQP_MULTIPLE_SHOOTING && !h->stage_only && step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
     ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     StepIO io{};
@@ -587,7 +595,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     }
 #endif
     HIPCHK(hipEventRecord(h->ev_s0, st));
-    if (h->transcription == MPCQP_MULTIPLE_SHOOTING) {
+    if (h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only) {
         // the stage-structured kernel: model as equality constraints, Riccati recursion, H~ and E never formed
         const int why = ms_unsupported(h);
         if (why || y0m || predict) return MPCQP_ERR_UNSUPPORTED;
@@ -689,6 +697,7 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
     std::vector<double> tmp;
     switch (which) {
         case MPCQP_GET_HESSIAN: {
+            if (h->stage_only) return MPCQP_ERR_UNSUPPORTED;       // (nothing is condensed for nZ~ > 256)
             if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
             int rc = fetch(h->m.Hpk, B * d.npk, tmp);
             if (rc) return rc;
@@ -702,6 +711,7 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
             return MPCQP_OK;
         }
         case MPCQP_GET_STEPRESP: {
+            if (h->stage_only) return MPCQP_ERR_UNSUPPORTED;
             if (!h->have_model) return MPCQP_ERR_ORDER;
             int rc = fetch(h->m.Stab, B * d.Hp * d.ny * d.nu, tmp);
             if (rc) return rc;
@@ -714,10 +724,12 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
             return MPCQP_OK;
         }
         case MPCQP_GET_KMAT:
+            if (h->stage_only) return MPCQP_ERR_UNSUPPORTED;
             if (!h->have_model) return MPCQP_ERR_ORDER;
             HIPCHK(hipMemcpy(out, h->m.Ktab, B * d.nxh * d.nY * sizeof(double), hipMemcpyDeviceToHost));
             return MPCQP_OK;
         case MPCQP_GET_BVEC:
+            if (h->stage_only) return MPCQP_ERR_UNSUPPORTED;
             if (!h->have_model) return MPCQP_ERR_ORDER;
             HIPCHK(hipMemcpy(out, h->m.Bvec, B * d.nY * sizeof(double), hipMemcpyDeviceToHost));
             return MPCQP_OK;
@@ -940,6 +952,10 @@ static int self_test_spec_impl(mpcqp_handle h, double* worst, std::string* why, 
 int mpcqp_prepare(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
     g_build_err.clear();
+    if (h->stage_only || h->transcription == MPCQP_MULTIPLE_SHOOTING) {
+        if (!ms_unsupported(h)) return MPCQP_KERNEL_MS;            // nothing to build: the stage-structured kernel is in the library
+        if (h->stage_only) return MPCQP_ERR_UNSUPPORTED;
+    }
     int kind = prepare_step(h->d, h->m, &g_build_err);
     // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
     // it with the runtime-dimension kernel once; needs the model and weights (BatchLinMPC prepares before its first step)
@@ -987,7 +1003,7 @@ int mpcqp_lds_bytes(mpcqp_handle h) {
 
 int mpcqp_kernel_kind(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
-    if (h->transcription == MPCQP_MULTIPLE_SHOOTING && !ms_unsupported(h)) return MPCQP_KERNEL_MS;
+    if ((h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only) && !ms_unsupported(h)) return MPCQP_KERNEL_MS;
     return step_kernel_kind(h->d, h->m);
 }
 

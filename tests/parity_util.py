@@ -775,3 +775,32 @@ def run_unstable_plant(lib=None, B=4, transcription="MultipleShooting", rho=(1.1
     if g.kernel == mpcqp.api.KERNEL_MS:
         out["defect"] = g.hd.get(mpcqp.api.GET_MS_DEFECT)
     return out
+
+
+def large_problem_case(lib=None, B=2, nu=8, Hp=32):
+    """A SingleShooting controller with nZ̃ = nu Hc + 1 > 256 (nu = 8, Hp = Hc = 32: 257 variables, 512 + 512 + 32 rows): no
+    condensed kernel exists for it, the stage-structured kernel takes the handle whatever its transcription.  Returns
+    (worst relative ΔU error vs the dense SingleShooting oracle over two periods, kernel kind, statuses)."""
+    rng = np.random.default_rng(11)
+    nx, ny = 1, 1
+    A = np.array([[0.85]]); Bu = rng.standard_normal((nx, nu)) / np.sqrt(nu); C = np.array([[1.2]])
+    Ah = np.block([[A, np.zeros((nx, ny))], [np.zeros((ny, nx)), np.eye(ny)]])
+    Bhu = np.vstack([Bu, np.zeros((ny, nu))]); Ch = np.hstack([C, np.eye(ny)])
+    kw = dict(Hp=Hp, Hc=Hp, Mwt=[1.0], Nwt=rng.uniform(0.05, 0.3, nu), Cwt=1e5)
+    con = dict(umin=[-0.3] * nu, umax=[0.3] * nu, ymax=[0.5], dumin=[-0.1] * nu, dumax=[0.1] * nu)
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    g = mpcqp.BatchLinMPC(rep(Ah), rep(Bhu), rep(Ch), lib=lib, **kw)
+    g.setconstraint(umin=con["umin"], umax=con["umax"], ymax=con["ymax"], Δumin=con["dumin"], Δumax=con["dumax"])
+    assert g.nZ > 256
+    o = cd.LinMPCOracle(Ah, Bhu, Ch, **kw).setconstraint(**con)
+    x0 = rng.standard_normal(nx + ny)
+    worst, sts = 0.0, []
+    for k in range(2):
+        ry = [1.0 if k == 0 else -0.4]
+        g.moveinput(rep(x0), ry)
+        uo = o.moveinput(x0, ry)
+        assert o.status == 0
+        worst = max(worst, float(rel_err(g.Z[:1], o.Zt[None, :], o.nDU).max()))
+        sts.append(g.status.copy())
+        x0 = Ah @ x0 + Bhu @ uo
+    return worst, g.kernel, np.concatenate(sts)

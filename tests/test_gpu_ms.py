@@ -131,3 +131,11 @@ def test_ill_conditioned_instances_against_extended_precision_optimum(hiplib):
             seen += 1
         assert np.sum(mpc.status != 0) <= 2, np.flatnonzero(mpc.status)
     assert seen == len(cases)
+
+
+def test_problems_beyond_256_variables_on_gpu(hiplib):
+    """nZ̃ = 257 > 256 (SingleShooting): served by the stage-structured kernel; two periods against the dense oracle."""
+    from tests.parity_util import large_problem_case
+    worst, kind, st = large_problem_case(B=64)
+    assert kind == api.KERNEL_MS and np.all(st == 0)
+    assert worst <= TOL, worst

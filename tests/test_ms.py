@@ -118,3 +118,14 @@ def test_multiple_shooting_fallback_is_announced(emulib):
     o.moveinput(x0, ry)
     assert np.abs(mpc.Z[0, :o.nDU] - o.Zt[:o.nDU]).max() <= 1e-8
     assert mpc.getinfo()["Z̃"].shape[1] == o.nDU + 5 * Hp + 1          # [ΔU; X̂0; ϵ]: the MultipleShooting layout all the same
+
+
+@pytest.mark.slow
+def test_problems_beyond_256_variables_run_on_the_stage_structured_kernel(emulib):
+    """nZ̃ = 257: the condensed kernels end at 256 variables (the Newton matrix must fit the LDS), the reference has no size
+    limit (transcription.jl:2-4).  A SingleShooting handle of that size is served by the stage-structured kernel -- same QP,
+    same optimal ΔU as the dense oracle -- and nothing is condensed for it."""
+    from tests.parity_util import large_problem_case
+    worst, kind, st = large_problem_case(lib=emulib, B=1)
+    assert kind == api.KERNEL_MS and np.all(st == 0)
+    assert worst <= TOL, worst
