@@ -51,7 +51,7 @@ struct mpcqp_handle_s {
     int transcription = MPCQP_SINGLE_SHOOTING;
     bool stage_only = false;         // nZ~ > 256: only the stage-structured kernel can take this handle (nothing is condensed)
     bool dual_reg_given = false;     // mpcqp_dims.dual_reg > 0 (else each kernel's own default)
-    DBuf ms_X, ms_defect, ms_scratch;
+    DBuf ms_X, ms_defect, ms_scratch, ms_next;
 };
 
 static int dev_alloc(mpcqp_handle h, DBuf& b, size_t bytes) {
@@ -611,6 +611,9 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
                 rc = dev_alloc(h, h->ms_scratch, sb);
                 if (rc) return rc;
                 ms.scratch = (double*)h->ms_scratch.p; ms.nslots = nslots;
+                rc = dev_alloc(h, h->ms_next, sizeof(int));
+                if (rc) return rc;
+                ms.next = (int*)h->ms_next.p;
             }
         }
         // (dual regularisation: the handle's, default 1e-12 like the condensed kernels.  Measured on 8192 C3 controllers

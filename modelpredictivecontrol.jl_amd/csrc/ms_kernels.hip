@@ -15,15 +15,23 @@ namespace mpcqp {
 
 __global__ __launch_bounds__(64) void k_ms_step(Dims d, Model m, StepIO io, MsIO ms) {
     DevWave w{(int)threadIdx.x};
-    ms_step_body(w, d, m, io, ms, (int)blockIdx.x, mpcqp_smem, (double*)nullptr);
+    ms_step_body<false>(w, d, m, io, ms, (int)blockIdx.x, mpcqp_smem, (double*)nullptr);
 }
 
 // (two wavefronts per SIMD: without the attribute the compiler takes 372 registers and leaves one)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ms_step_g(Dims d, Model m, StepIO io, MsIO ms, size_t big) {
     DevWave w{(int)threadIdx.x};
     double* scratch = ms.scratch + (size_t)blockIdx.x * big;
-    for (int b = (int)blockIdx.x; b < d.B; b += (int)gridDim.x) {
-        ms_step_body(w, d, m, io, ms, b, mpcqp_smem, scratch);
+    // controllers are handed out one at a time (ms.next: a counter in HBM, zeroed before the launch): a solve that runs to
+    // its iteration limit (80 iterations against a mean of 13) then delays its own wavefront, not a fixed share of the
+    // batch -- with the static assignment b = blockIdx + k gridDim one such controller set the time of the whole launch
+    // (measured: 131 ms for 2048 C3 controllers of which one is at the limit, 25 ms of work per wavefront otherwise)
+    for (;;) {
+        int b = 0;
+        if (threadIdx.x == 0) b = atomicAdd(ms.next, 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= d.B) break;
+        ms_step_body<true>(w, d, m, io, ms, b, mpcqp_smem, scratch);
         w.sync();
     }
 }
@@ -38,8 +46,15 @@ size_t ms_scratch_bytes(const Dims& d, const Model& m, int* nslots) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     const size_t lds = (size_t)c.small * sizeof(double);
-    int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
-    per_cu = per_cu > 8 ? 8 : per_cu < 1 ? 1 : per_cu;          // (the kernel's register budget: two wavefronts per SIMD)
+    // resident wavefronts per CU: what the runtime says for this kernel and this much LDS (registers, LDS allocation
+    // granularity).  A persistent grid larger than that runs its surplus workgroups as a SECOND round (measured: 2048
+    // launched where 1792 fit cost 2x).
+    int per_cu = 0;
+    if (ensure_lds((const void*)k_ms_step_g, lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_step_g, WAVE, lds) != hipSuccess || per_cu < 1) {
+        per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+        per_cu = per_cu > 8 ? 8 : per_cu < 1 ? 1 : per_cu;
+    }
     int n = cus * per_cu;
     if (n > d.B) n = d.B;
     if (nslots) *nslots = n;
@@ -56,6 +71,9 @@ hipError_t launch_ms_step(const Dims& d, const Model& m, const StepIO& io, const
     } else {
         if (!ms.scratch || ms.nslots < 1) return hipErrorInvalidValue;
         hipError_t e = ensure_lds((const void*)k_ms_step_g, lds);
+        if (e != hipSuccess) return e;
+        if (!ms.next) return hipErrorInvalidValue;
+        e = hipMemsetAsync(ms.next, 0, sizeof(int), st);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_ms_step_g, dim3(ms.nslots), dim3(WAVE), lds, st, d, m, io, ms, (size_t)c.big);
     }

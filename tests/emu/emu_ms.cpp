@@ -7,7 +7,8 @@ namespace mpcqp {
 hipError_t launch_ms_step(const Dims& d, const Model& m, const StepIO& io, const MsIO& ms, hipStream_t) {
     const MsCarve c = make_ms_carve(d, m);
     // (both placements of the horizon-long data: behind the small block in "LDS", or in the scratch the host allocated)
-    run_waves(d.B, c.total, [&](EmuWave& w, int b, double* sm) { ms_step_body(w, d, m, io, ms, b, sm, c.big_in_lds ? (double*)nullptr : ms.scratch); });
+    if (c.big_in_lds) run_waves(d.B, c.total, [&](EmuWave& w, int b, double* sm) { ms_step_body<false>(w, d, m, io, ms, b, sm, (double*)nullptr); });
+    else run_waves(d.B, c.total, [&](EmuWave& w, int b, double* sm) { ms_step_body<true>(w, d, m, io, ms, b, sm, ms.scratch); });
     return hipSuccess;
 }
 size_t ms_lds_bytes(const Dims& d, const Model& m) { return (size_t)make_ms_carve(d, m).total * sizeof(double); }
