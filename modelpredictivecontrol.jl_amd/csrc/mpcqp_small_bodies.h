@@ -289,7 +289,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             const double zm = w.rmax(isdu ? fmax(1.0, fabs(z)) : 1.0), dm = w.rmax(isdu ? fabs(al * dz) : 0.0);
             if (isvar && !done) z += al * dz;
             if (!done) {
-                laststep = dm / zm;
+                laststep = alpha >= 0.5 ? dm / zm : 1e300;      // (a blocked step says nothing about convergence: Step::run)
                 lastscale = 1.0 - alpha;
                 if (norows) { st = 0; done = true; it = 0; }
             }
