@@ -701,7 +701,9 @@ class BatchLinMPC:
                       Deltaumin=None, Deltaumax=None, xhatmin=None, xhatmax=None,
                       DeltaUmin=None, DeltaUmax=None, c_Deltaumin=None, c_Deltaumax=None,
                       c_xhatmin=None, c_xhatmax=None, wmin=None, wmax=None, Wmin=None, Wmax=None,
-                      c_wmin=None, c_wmax=None, C_wmin=None, C_wmax=None):
+                      c_wmin=None, c_wmax=None, C_wmin=None, C_wmax=None,
+                      C_umin=None, C_umax=None, C_Δumin=None, C_Δumax=None, C_ymin=None, C_ymax=None,
+                      C_Deltaumin=None, C_Deltaumax=None):
         """`setconstraint!` (src/controller/construct.jl:324-559), with the ASCII
         aliases.  Bounds are engineering values (operating points are subtracted here, :356-435);
         per-channel vectors (n,) or (B,n) are repeated over the horizon, capitalised keywords take
@@ -759,20 +761,26 @@ class BatchLinMPC:
             new["x0min"] = full(x̂min, nxh, "x̂min") - self.xhop
         if x̂max is not None:
             new["x0max"] = full(x̂max, nxh, "x̂max") - self.xhop
-        ecr = dict(C_umin=(c_umin, nu, Hp), C_umax=(c_umax, nu, Hp), C_dumin=(c_Δumin, nu, Hc),
-                   C_dumax=(c_Δumax, nu, Hc), C_ymin=(c_ymin, ny, Hp), C_ymax=(c_ymax, ny, Hp),
-                   c_x0min=(c_x̂min, nxh, 1), c_x0max=(c_x̂max, nxh, 1))
-        if any(v[0] is not None for v in ecr.values()):
+        # softness: per channel (repeated over the horizon) or horizon-long `C_umin` ... `C_ymax` (construct.jl:446-509).  A
+        # C_umin / C_umax that varies inside a move-blocking interval sends the handle to the stage-structured kernel
+        # (mpcqp_set_bounds), which keeps one input row per step.
+        C_Δumin = C_Deltaumin if C_Δumin is None else C_Δumin
+        C_Δumax = C_Deltaumax if C_Δumax is None else C_Δumax
+        ecr = dict(C_umin=(c_umin, nu, Hp, C_umin), C_umax=(c_umax, nu, Hp, C_umax), C_dumin=(c_Δumin, nu, Hc, C_Δumin),
+                   C_dumax=(c_Δumax, nu, Hc, C_Δumax), C_ymin=(c_ymin, ny, Hp, C_ymin), C_ymax=(c_ymax, ny, Hp, C_ymax),
+                   c_x0min=(c_x̂min, nxh, 1, None), c_x0max=(c_x̂max, nxh, 1, None))
+        if any(v[0] is not None or v[3] is not None for v in ecr.values()):
             if self.neps != 1:
                 raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
             if self.solved_once:
                 raise RuntimeError("Cannot set softness parameters after calling moveinput!")
-        for k, (v, n, reps) in ecr.items():
-            if v is not None:
-                a = rep(v, n, reps, k)
+        for k, (v, n, reps, whole) in ecr.items():
+            if whole is not None or v is not None:
+                a = full(whole, n * reps, k) if whole is not None else rep(v, n, reps, k)
                 if np.any(a < 0):
                     raise ValueError(f"{k} weights should be non-negative")
                 new[k] = a
+                self._prepared = False         # (the kernel that takes the handle may change, see above)
         if self.solved_once:
             # src/controller/construct.jl:541-551: the ±Inf pattern is frozen after the first solve
             for k in BOUND_FIELDS[:8]:

@@ -50,6 +50,8 @@ struct mpcqp_handle_s {
     // MultipleShooting transcription (mpcqp_set_transcription): the stage-structured kernel of ms_bodies.h
     int transcription = MPCQP_SINGLE_SHOOTING;
     bool stage_only = false;         // nZ~ > 256: only the stage-structured kernel can take this handle (nothing is condensed)
+    bool stage_rows = false;         // C_umin / C_umax vary inside a move-blocking interval: the U rows cannot be merged, the
+                                     // stage-structured kernel (one U row per step) takes the handle
     bool dual_reg_given = false;     // mpcqp_dims.dual_reg > 0 (else each kernel's own default)
     DBuf ms_X, ms_defect, ms_scratch, ms_next;
 };
@@ -460,17 +462,20 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
         return MPCQP_ERR_ARG;   // "Cwt must be finite to set softness parameters", construct.jl:441
     // U rows of one move-blocking interval are merged into their tightest one (mpcqp_bodies.h);
     // exact as long as the softness of those rows is the same -- true for every `c_umin`/`c_umax`
-    // keyword of setconstraint! (repeated per channel); a C_umin/C_umax vector that varies inside
-    // an interval is not supported by this build.
+    // keyword of setconstraint! (repeated per channel).  A horizon-long C_umin/C_umax vector
+    // (construct.jl:454-463) that varies inside an interval leaves rows u - c_t eps <= Umax_t of different
+    // slopes that no single row replaces: such a handle is served by the stage-structured kernel, which
+    // keeps one U row per step (ms_bodies.h) -- if that kernel can take it (ms_unsupported at the step).
+    bool varies = false;
     for (const double* cu : {bin->C_umin, bin->C_umax}) {
         if (!cu) continue;
-        for (size_t b = 0; b < (size_t)d.B; ++b)
-            for (int j = 0; j < d.Hc; ++j)
-                for (int t = h->jl[j] + 1; t < h->jl[j + 1]; ++t)
+        for (size_t b = 0; b < (size_t)d.B && !varies; ++b)
+            for (int j = 0; j < d.Hc && !varies; ++j)
+                for (int t = h->jl[j] + 1; t < h->jl[j + 1] && !varies; ++t)
                     for (int c = 0; c < d.nu; ++c)
-                        if (cu[b * d.nU + t * d.nu + c] != cu[b * d.nU + h->jl[j] * d.nu + c])
-                            return MPCQP_ERR_UNSUPPORTED;
+                        if (cu[b * d.nU + t * d.nu + c] != cu[b * d.nU + h->jl[j] * d.nu + c]) { varies = true; break; }
     }
+    h->stage_rows = varies;
     ON_DEVICE(h);
     const double* src[16] = {bin->U0min, bin->U0max, bin->DUmin, bin->DUmax, bin->Y0min, bin->Y0max,
                              bin->x0min, bin->x0max, bin->C_umin, bin->C_umax, bin->C_dumin,
@@ -512,6 +517,9 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
     return MPCQP_OK;
 }
 
+// the handle is routed to the stage-structured kernel: asked for (MultipleShooting), or the condensed kernels cannot take it
+static bool uses_stage_kernel(mpcqp_handle h) { return h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only || h->stage_rows; }
+
 // 0 when the MultipleShooting kernel takes this handle; else the reason (bit mask): 1 dense / block weights, 2 custom
 // linear constraints, 4 the stage data does not fit the 160 KB of LDS, 8 flags of the condensed kernels only
 static int ms_unsupported(mpcqp_handle h) {
@@ -532,7 +540,7 @@ int mpcqp_set_transcription(mpcqp_handle h, int32_t transcription) {
 
 int mpcqp_transcription_supported(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
-    return (h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only) ? ms_unsupported(h) : 0;
+    return uses_stage_kernel(h) ? ms_unsupported(h) : 0;
 }
 
 // shared by mpcqp_step_device (kf = false) and mpcqp_loop_device
@@ -557,7 +565,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     const Dims& d = h->d;
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
-    if (h->transcription != MPCQP_MULTIPLE_SHOOTING && !h->stage_only && step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
+    if (!uses_stage_kernel(h) && step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
     ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     StepIO io{};
@@ -595,7 +603,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     }
 #endif
     HIPCHK(hipEventRecord(h->ev_s0, st));
-    if (h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only) {
+    if (uses_stage_kernel(h)) {
         // the stage-structured kernel: model as equality constraints, Riccati recursion, H~ and E never formed
         const int why = ms_unsupported(h);
         if (why || y0m || predict) return MPCQP_ERR_UNSUPPORTED;
@@ -955,9 +963,9 @@ static int self_test_spec_impl(mpcqp_handle h, double* worst, std::string* why, 
 int mpcqp_prepare(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
     g_build_err.clear();
-    if (h->stage_only || h->transcription == MPCQP_MULTIPLE_SHOOTING) {
+    if (uses_stage_kernel(h)) {
         if (!ms_unsupported(h)) return MPCQP_KERNEL_MS;            // nothing to build: the stage-structured kernel is in the library
-        if (h->stage_only) return MPCQP_ERR_UNSUPPORTED;
+        if (h->stage_only || h->stage_rows) return MPCQP_ERR_UNSUPPORTED;
     }
     int kind = prepare_step(h->d, h->m, &g_build_err);
     // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
@@ -1006,7 +1014,7 @@ int mpcqp_lds_bytes(mpcqp_handle h) {
 
 int mpcqp_kernel_kind(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
-    if ((h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only) && !ms_unsupported(h)) return MPCQP_KERNEL_MS;
+    if (uses_stage_kernel(h) && !ms_unsupported(h)) return MPCQP_KERNEL_MS;
     return step_kernel_kind(h->d, h->m);
 }
 

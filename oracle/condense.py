@@ -396,8 +396,9 @@ class LinMPCOracle:
                       Ymin=None, Ymax=None, c_umin=None, c_umax=None, c_dumin=None, c_dumax=None,
                       c_ymin=None, c_ymax=None, c_xhatmin=None, c_xhatmax=None,
                       wmin=None, wmax=None, Wmin=None, Wmax=None, c_wmin=None, c_wmax=None,
-                      C_wmin=None, C_wmax=None):
-        """`setconstraint!` -- src/controller/construct.jl:324-559."""
+                      C_wmin=None, C_wmax=None, C_umin=None, C_umax=None, C_dumin=None, C_dumax=None,
+                      C_ymin=None, C_ymax=None):
+        """`setconstraint!` -- src/controller/construct.jl:324-559 (horizon-long softness `C_umin` ... `C_ymax`: :446-483)."""
         Hp, Hc = self.Hp, self.Hc
         f = lambda v: np.asarray(v, float).ravel()
         for v, name in ((wmin, "wmin"), (wmax, "wmax"), (c_wmin, "c_wmin"), (c_wmax, "c_wmax")):
@@ -440,7 +441,7 @@ class LinMPCOracle:
         if xhatmax is not None:
             self.x0max = f(xhatmax) - self.xhop
         ecrs = (c_umin, c_umax, c_dumin, c_dumax, c_ymin, c_ymax, c_xhatmin, c_xhatmax,
-                c_wmin, c_wmax, C_wmin, C_wmax)
+                c_wmin, c_wmax, C_wmin, C_wmax, C_umin, C_umax, C_dumin, C_dumax, C_ymin, C_ymax)
         if any(e is not None for e in ecrs):
             if self.neps != 1:
                 raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
@@ -458,6 +459,14 @@ class LinMPCOracle:
             self.C_ymin = np.tile(f(c_ymin), Hp)
         if c_ymax is not None:
             self.C_ymax = np.tile(f(c_ymax), Hp)
+        for whole, name, n in ((C_umin, "C_umin", self.nu * Hp), (C_umax, "C_umax", self.nu * Hp), (C_dumin, "C_dumin", self.nu * Hc),
+                               (C_dumax, "C_dumax", self.nu * Hc), (C_ymin, "C_ymin", self.ny * Hp), (C_ymax, "C_ymax", self.ny * Hp)):
+            if whole is not None:                       # construct.jl:454-483
+                if f(whole).shape != (n,):
+                    raise ValueError(f"{name} size must be ({n},)")
+                if np.any(f(whole) < 0):
+                    raise ValueError(f"{name} weights should be non-negative")
+                setattr(self, name, f(whole))
         if c_xhatmin is not None:
             self.c_xmin = f(c_xhatmin)
         if c_xhatmax is not None:

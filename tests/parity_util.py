@@ -804,3 +804,42 @@ def large_problem_case(lib=None, B=2, nu=8, Hp=32):
         sts.append(g.status.copy())
         x0 = Ah @ x0 + Bhu @ uo
     return worst, g.kernel, np.concatenate(sts)
+
+
+def varying_softness_case(lib=None, B=2):
+    """Horizon-long softness vectors (`C_umax`, `C_umin`, `C_ymax`, `C_Δumax`; construct.jl:446-483) on a controller with a
+    move-blocking vector: `C_umax` VARIES inside the blocking intervals, so the input rows of an interval cannot be merged into
+    their tightest one -- the handle is served by the stage-structured kernel (one input row per step), whatever its
+    transcription.  The set point drives the inputs into their (soft) bounds.  Returns (worst relative ΔU error vs the dense
+    oracle over two periods, kernel kind, statuses, ϵ of the first period)."""
+    rng = np.random.default_rng(23)
+    nx, nu, ny, Hp, Hc = 3, 2, 2, 10, [1, 2, 3, 4]
+    lam = rng.uniform(0.5, 0.95, nx)
+    Q, _ = np.linalg.qr(rng.standard_normal((nx, nx)))
+    A = Q @ np.diag(lam) @ Q.T
+    Bu = rng.standard_normal((nx, nu)); C = rng.standard_normal((ny, nx))
+    Ah = np.block([[A, np.zeros((nx, ny))], [np.zeros((ny, nx)), np.eye(ny)]])
+    Bhu = np.vstack([Bu, np.zeros((ny, nu))]); Ch = np.hstack([C, np.eye(ny)])
+    kw = dict(Hp=Hp, Hc=Hc, Mwt=[1.0, 1.5], Nwt=[0.05, 0.1], Cwt=2e3)
+    C_umax = rng.uniform(0.0, 1.5, nu * Hp) * (rng.random(nu * Hp) < 0.8)       # some steps hard, the others of different softness
+    C_umin = rng.uniform(0.2, 1.0, nu * Hp)
+    C_ymax = rng.uniform(0.5, 2.0, ny * Hp)
+    C_dumax = rng.uniform(0.0, 1.0, nu * len(Hc))
+    con = dict(umin=[-0.4, -0.5], umax=[0.35, 0.45], ymax=[0.8, 0.9], dumax=[0.3, 0.3])
+    rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
+    g = mpcqp.BatchLinMPC(rep(Ah), rep(Bhu), rep(Ch), lib=lib, **kw)
+    g.setconstraint(umin=con["umin"], umax=con["umax"], ymax=con["ymax"], Δumax=con["dumax"],
+                    C_umax=C_umax, C_umin=C_umin, C_ymax=C_ymax, C_Δumax=C_dumax)
+    o = cd.LinMPCOracle(Ah, Bhu, Ch, **kw).setconstraint(**con, C_umax=C_umax, C_umin=C_umin, C_ymax=C_ymax, C_dumax=C_dumax)
+    x0 = 0.3 * rng.standard_normal(nx + ny)
+    worst, sts, eps0 = 0.0, [], None
+    for k in range(2):
+        ry = [3.0, -2.5] if k == 0 else [-2.0, 2.0]
+        g.moveinput(rep(x0), ry)
+        uo = o.moveinput(x0, ry)
+        assert o.status == 0
+        worst = max(worst, float(rel_err(g.Z[:1], o.Zt[None, :], o.nDU).max()))
+        sts.append(g.status.copy())
+        eps0 = o.Zt[-1] if eps0 is None else eps0
+        x0 = Ah @ x0 + Bhu @ uo
+    return worst, g.kernel, np.concatenate(sts), eps0

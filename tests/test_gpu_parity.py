@@ -461,8 +461,8 @@ def test_abi_error_codes(hiplib):
         H(4, 3, 1, 1, 0, Hp=5, Hc=6)                    # Hc > Hp
     with pytest.raises(mpcqp.MpcqpError, match="dimension"):
         H(4, 3, 1, 1, 0, Hp=5, Hc=2, nb=[1, 2])         # sum(nb) != Hp
-    with pytest.raises(mpcqp.MpcqpError, match="not supported"):
-        H(4, 3, 4, 1, 0, Hp=80, Hc=70)                  # nZ > 256
+    big = H(4, 3, 4, 1, 0, Hp=80, Hc=70)                # nZ > 256: no condensed kernel, the stage-structured kernel takes it
+    assert big.nZ > 256 and big.kernel_kind() == mpcqp.api.KERNEL_MS
     h = H(4, 3, 1, 1, 0, Hp=5, Hc=2)
     with pytest.raises(mpcqp.MpcqpError, match="must be set before"):
         h.step(np.zeros((4, 3)), np.zeros((4, 1)), np.zeros((4, 5)), np.zeros((4, 3)))
