@@ -192,7 +192,7 @@ struct MsStep {
     double *rh, *rs, *rl, *rrp, *rgd, *rpp, *rcs, *rwi;
     double eps = 0.0, deps = 0.0, delta, nh = 1.0, wsum = 0.0;
     bool use_defect = false;        // the defects of the iterate enter the Newton systems (set by defects())
-    double prof_[8] = {0};          // -DMPCQP_MS_PROFILE: cycles per phase (residuals, stage data, factor, psi sweep, newton, update, -, run)
+    double prof_[8] = {0};          // -DMPCQP_MS_PROFILE: cycles per phase (residuals, stage data, factor, psi sweep, newton, update, polish, run)
     int mact = 0;
 
     MPCQP_HD MsStep(W& w_, const Dims& d_, const Model& m_, const StepIO& io_, int b_, double* sm_, double* big_)
@@ -408,6 +408,47 @@ struct MsStep {
     }
 
     // ---- Riccati factorisation of the current Phi (QY, QV, RD hold the stage diagonals) --------------------
+    // store(i, j, sum_k a(i, k) b(k, j)) for i < M, j < N (lower: only j <= i).  On the device the product runs on the matrix
+    // cores, v_mfma_f64_16x16x4 per 16 x 16 tile and four k: A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15],
+    // D[row = (lane >> 4) + 4 reg][col = lane & 15] -- a lane fetches ONE a and ONE b per 1024 multiply-adds.  The scalar
+    // form (one output per lane, two LDS reads per multiply-add) made the factorisation LDS-bound: eight wavefronts per CU
+    // share one LDS pipe, 65 k cycles per stage on C3 shapes.  The emulator runs the scalar form with the same accessors.
+    template <class FA, class FB, class FS>
+    MPCQP_HD void mm(int M, int N, int K, bool lower, FA a, FB b, FS store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef double v4d_ __attribute__((ext_vector_type(4)));
+        const int li = w.lane & 15, lk = w.lane >> 4;
+        for (int I = 0; I < (M + 15) / 16; ++I) {
+            for (int J = 0; J < (N + 15) / 16; ++J) {
+                if (lower && J > I) continue;
+                const int i = 16 * I + li, j = 16 * J + li;
+                v4d_ acc = {0.0, 0.0, 0.0, 0.0};
+                // (requesting the operands of four k steps together before their MFMAs: measured, no gain, more spills)
+                for (int k0 = 0; k0 < K; k0 += 4) {
+                    const int k = k0 + lk;
+                    const double av = (i < M && k < K) ? a(i, k) : 0.0;
+                    const double bv = (j < N && k < K) ? b(k, j) : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+                for (int r = 0; r < 4; ++r) {
+                    const int ii = 16 * I + lk + 4 * r;
+                    if (ii < M && j < N && (!lower || j <= ii)) store(ii, j, acc[r]);
+                }
+            }
+        }
+#else
+        for (int idx = w.lane; idx < M * N; idx += WAVE) {
+            const int i = idx / N, j = idx - i * N;
+            if (lower && j > i) continue;
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) acc += a(i, k) * b(k, j);
+            store(i, j, acc);
+        }
+#endif
+    }
+    // entries of Abar = [A^ B^u; 0 I] and Bbar = [B^u; I]
+    MPCQP_HD double Abar(int i, int j) const { return i < nx ? (j < nx ? A[i + nx * j] : Bu[i + nx * (j - nx)]) : (i == j ? 1.0 : 0.0); }
+    MPCQP_HD double Bbar(int i, int e) const { return i < nx ? Bu[i + nx * e] : (i - nx == e ? 1.0 : 0.0); }
     // T = Pn M for the packed symmetric Pn (cost-to-go of stage t+1) and M = Abar (Mfull == nullptr: the structure
     // Abar = [A^ B^u; 0 I] is used) or a full ns x ns matrix (the closed-loop matrix Abar + Bbar K)
     MPCQP_HD void PtimesM(const double* Pn, const double* Mfull) {
@@ -527,12 +568,19 @@ struct MsStep {
                 for (int cc = 0; cc < nu; ++cc) acc += Pa[i * ns + nx + cc] * bg[c.cV + t * nu + cc];
                 Pc[t * ns + i] = acc;
             }
-            PtimesM(Pa, nullptr);                               // T = P_{t+1} Abar
+            {   // T = P_{t+1} Abar
+                double* T = sm + c.T;
+                const double* Pq = Pa;
+                mm(ns, ns, ns, false, [&](int i, int k) { return Pq[i * ns + k]; }, [&](int k, int jj) { return Abar(k, jj); },
+                   [&](int i, int jj, double v) { T[i * ns + jj] = v; });
+                w.sync_lds();
+            }
             if (j >= 0) {
                 // S_u. = Bbar' T (rows nx.. of Abar' T) into S[0 .. nu*ns); Lam = R + S_uu
-                for (int idx = w.lane; idx < nu * ns; idx += WAVE) {
-                    const int a = idx / ns, col = idx - a * ns;
-                    S[idx] = MtT(nullptr, nx + a, col);
+                {
+                    const double* T = sm + c.T;
+                    mm(nu, ns, ns, false, [&](int a, int k) { return Bbar(k, a); }, [&](int k, int col) { return T[k * ns + col]; },
+                       [&](int a, int col, double v) { S[a * ns + col] = v; });
                 }
                 w.sync_lds();
                 for (int idx = w.lane; idx < nu * nu; idx += WAVE) {
@@ -589,22 +637,29 @@ struct MsStep {
                     S[idx] = acc;
                 }
                 w.sync_lds();
-                PtimesM(Pa, S);
-                for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
-                    const int i = idx / ns, jj = idx - i * ns;
-                    if (jj > i) continue;
-                    double acc = MtT(S, i, jj);
-                    for (int e = 0; e < nu; ++e) acc += K[e * ns + i] * bg[c.RD + j * nu + e] * K[e * ns + jj];
-                    Pb[i * ns + jj] = acc;
-                    Pb[jj * ns + i] = acc;
+                {
+                    double* T = sm + c.T;
+                    const double* Pq = Pa;
+                    double* Pn = Pb;
+                    mm(ns, ns, ns, false, [&](int i, int k) { return Pq[i * ns + k]; }, [&](int k, int jj) { return S[k * ns + jj]; },
+                       [&](int i, int jj, double v) { T[i * ns + jj] = v; });
+                    w.sync_lds();
+                    // P_t = Acl' T + K' R K: the inner index runs over the ns rows of Acl / T, then over the nu rows of K
+                    const double* Rd = bg + c.RD + j * nu;
+                    for (int e = w.lane; e < nu; e += WAVE) sm[c.wv + e] = Rd[e];         // (R of the stage into LDS: read per k)
+                    w.sync_lds();
+                    const double* Rl = sm + c.wv;
+                    mm(ns, ns, ns + nu, true,
+                       [&](int i, int k) { return k < ns ? S[k * ns + i] : K[(k - ns) * ns + i] * Rl[k - ns]; },
+                       [&](int k, int jj) { return k < ns ? T[k * ns + jj] : K[(k - ns) * ns + jj]; },
+                       [&](int i, int jj, double v) { Pn[i * ns + jj] = v; Pn[jj * ns + i] = v; });
                 }
             } else {
-                for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
-                    const int i = idx / ns, jj = idx - i * ns;
-                    if (jj > i) continue;
-                    const double acc = MtT(nullptr, i, jj);
-                    Pb[i * ns + jj] = acc;
-                    Pb[jj * ns + i] = acc;
+                {
+                    const double* T = sm + c.T;
+                    double* Pn = Pb;
+                    mm(ns, ns, ns, true, [&](int i, int k) { return Abar(k, i); }, [&](int k, int jj) { return T[k * ns + jj]; },
+                       [&](int i, int jj, double v) { Pn[i * ns + jj] = v; Pn[jj * ns + i] = v; });
                 }
             }
             w.sync_lds();
@@ -1221,7 +1276,10 @@ struct MsStep {
             // Active-set polish once the gap is small: first at mu <= 1e-6, again after every further factor 100 (Step::run)
             if (MPCQP_MS_POLISH && mact && mu <= polmu_next && rpn <= 1e-6 * nh && cn <= 1e-6 * xs && npolish < MPCQP_MS_POLISH_BUDGET && !(d.flags & 16u)) {
                 polmu_next = 1e-2 * mu;
-                if (polish(xs, npolish)) { status = ST_OPTIMAL; break; }
+                const long long t6_ = clk();
+                const bool pok_ = polish(xs, npolish);
+                prof_[6] += (double)(clk() - t6_);
+                if (pok_) { status = ST_OPTIMAL; break; }
                 residuals(mu, rpn, rdn, ndd, cn, xs);        // (the row arrays served the polish)
             }
             // D~ of the rows -> stage diagonals, border column phi, Phi_ee

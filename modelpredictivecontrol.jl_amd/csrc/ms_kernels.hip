@@ -13,7 +13,7 @@
 
 namespace mpcqp {
 
-__global__ __launch_bounds__(64) void k_ms_step(Dims d, Model m, StepIO io, MsIO ms) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ms_step(Dims d, Model m, StepIO io, MsIO ms) {
     DevWave w{(int)threadIdx.x};
     ms_step_body<false>(w, d, m, io, ms, (int)blockIdx.x, mpcqp_smem, (double*)nullptr);
 }

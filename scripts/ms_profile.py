@@ -15,7 +15,7 @@ mpc.lastu0 = bt["lastu0"].copy()
 mpc.moveinput(bt["xhat0"], bt["ry"])
 P = mpc.hd.get(api.GET_XHAT_MS).reshape(B, -1)[:, :8]
 it = mpc.iters.mean()
-names = ["residuals", "stage data", "factor", "psi sweep", "newton x2", "update", "-", "run total"]
+names = ["residuals", "stage data", "factor", "psi sweep", "newton x2", "update", "polish", "run total"]
 tot = P[:, 7].mean()
 print(f"{cfg.name}: B {B} kernel {mpc.hd.last_step_ms():.1f} ms, iterations {it:.2f}; cycles per wavefront {tot:.3e} ({tot / max(it, 1):.3e} per iteration)")
 for i, n in enumerate(names):

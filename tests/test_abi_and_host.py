@@ -334,9 +334,10 @@ def test_multiple_shooting_known_answers_on_cpu_emulator(emulib):
     """f4 at the API level: `transcription="MultipleShooting"` (LinModel) -- the reference's own known answers,
     and the returned [ΔU; X̂0; ϵ] satisfies the model equality constraints."""
     from tests.parity_util import multiple_shooting_known_answers
-    r = multiple_shooting_known_answers(lib=emulib, B=1)
+    r = multiple_shooting_known_answers(lib=emulib, B=1, Hp=250)
     assert np.allclose(r["u3"], 3.0, atol=1e-2) and np.allclose(r["u4"], 4.0, atol=1e-2)
-    assert np.allclose(r["yend"], 15.0, atol=1e-2) and r["defect"] <= 1e-9 and r["yerr"] <= 1e-8
+    # (Ŷ[end] = 15 + 3.5/Hp with Nwt = 0, Hc = 1: 15.014 at this horizon, 15.0035 at the reference's Hp = 1000, atol 1e-2 there)
+    assert np.allclose(r["yend"], 15.0, atol=2e-2) and r["defect"] <= 1e-9 and r["yerr"] <= 1e-8
     with pytest.raises(NotImplementedError, match="transcription"):
         mpcqp.BatchLinMPC(np.eye(2)[None], np.ones((1, 2, 1)), np.ones((1, 1, 2)), Hp=4, transcription="OrthogonalCollocation", lib=emulib)
 
