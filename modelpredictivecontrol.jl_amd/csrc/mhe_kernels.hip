@@ -26,9 +26,12 @@ __global__ __launch_bounds__(64) void k_mhe_cov(Dims d, Args a, int mode, const 
 #ifndef MPCQP_MHE_WAVES
 #define MPCQP_MHE_WAVES 2       // register budget of the step kernel, in waves per SIMD
 #endif
+#ifndef MPCQP_MHE_WAVES_ALL
+#define MPCQP_MHE_WAVES_ALL 1   // the same for the all-class / soft variants (CM = 7, 15): one wave per SIMD, 512 registers
+#endif
 // CM = 1: x̂ bounds only (or none) -- the common case, without the code and registers of the ŵ / v̂ rows
 template <int NX, unsigned CM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_MHE_WAVES, 8))) void k_mhe_step(Dims d, Args a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CM == 1u ? MPCQP_MHE_WAVES : MPCQP_MHE_WAVES_ALL, 8))) void k_mhe_step(Dims d, Args a) {
     MheDevWave w{(int)threadIdx.x};
     step_body<MheDevWave, NX, CM>(w, d, a, (int)blockIdx.x, mpcqp_smem);
 }
