@@ -17,8 +17,8 @@
  * Supported: nx̂ <= 16, nym <= 16 (one estimator per 16-lane DPP row), any nu, nd, He; both forms
  * (direct = true/false); growing and moving windows; hard bounds on x̂ (arrival state and window), ŵ, v̂
  * given per channel, hard (Cwt = Inf, the reference's default) or relaxed by one slack variable ε (finite Cwt and
- * softness c per channel, mpcqp_mhe_set_softness).  Bounds that change along the window (X̂min / Ŵmin / V̂min vectors):
- * not supported.
+ * softness c per channel, mpcqp_mhe_set_softness, or per channel and stage, mpcqp_mhe_set_softness_window).  Bounds that
+ * change along the window (X̂min / Ŵmin / V̂min vectors): mpcqp_mhe_set_bounds_window.
  * There is no CPU fallback: every compute entry point needs a HIP device. */
 #ifndef MPCQP_MHE_H
 #define MPCQP_MHE_H
@@ -67,7 +67,8 @@ int mpcqp_mhe_set_bounds(mpcqp_mhe h, const double* xmin, const double* xmax, co
  * channel AND stage.  Xmin / Xmax (nx̂ (He+1), B): the arrival state first, then the He window states oldest first;
  * Wmin / Wmax (nx̂ He, B); Vmin / Vmax (nym He, B); deviation variables, +-Inf = no bound, NULL = class absent.  A window
  * that is not full yet (Nk < He) uses the LAST Nk blocks, like the reference (trunc_bounds).  Replaces the bounds of
- * mpcqp_mhe_set_bounds (and vice versa).  Softness stays per channel (mpcqp_mhe_set_softness).                      */
+ * mpcqp_mhe_set_bounds (and vice versa).  Softness: per channel (mpcqp_mhe_set_softness) or per channel and stage
+ * (mpcqp_mhe_set_softness_window).                                                                                  */
 int mpcqp_mhe_set_bounds_window(mpcqp_mhe h, const double* Xmin, const double* Xmax, const double* Wmin, const double* Wmax,
                                 const double* Vmin, const double* Vmax);
 
@@ -77,6 +78,15 @@ int mpcqp_mhe_set_bounds_window(mpcqp_mhe h, const double* Xmin, const double* X
  * slack ε >= 0 per estimator.  Softness without a finite Cwt: MPCQP_ERR_ARG (ArgumentError in the reference).      */
 int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin, const double* c_xmax, const double* c_wmin,
                            const double* c_wmax, const double* c_vmin, const double* c_vmax);
+
+/* Window-long softness, setconstraint!(estim; C_x̂min, C_x̂max, C_ŵmin, C_ŵmax, C_v̂min, C_v̂max) (construct.jl:937-1020):
+ * one softness per channel AND stage, same shapes as the window-long bounds (C_xmin / C_xmax (nx̂ (He+1), B): arrival
+ * state first; C_wmin / C_wmax (nx̂ He, B); C_vmin / C_vmax (nym He, B)); >= 0 and finite, NULL = 0 (hard).  Cwt (B) must
+ * be given and finite (MPCQP_ERR_ARG otherwise).  The softness is a column of the reference's constraint matrices, which
+ * are not truncated while the window grows: the rows of window entry j use block j whatever Nk (the BOUNDS of a growing
+ * window use the last Nk blocks; transcription.jl:737-752).  Replaces the softness of mpcqp_mhe_set_softness (and vice versa). */
+int mpcqp_mhe_set_softness_window(mpcqp_mhe h, const double* Cwt, const double* C_xmin, const double* C_xmax, const double* C_wmin,
+                                  const double* C_wmax, const double* C_vmin, const double* C_vmax);
 
 /* init_estimate_cov!: empties the data windows (Nk = 0), x̂0 <- xhat0 (nx̂,B; NULL: zeros), arrival
  * covariance P̄ <- P0 (nx̂,nx̂,B; required), d0(-1) <- d0_prev (nd,B; NULL: zeros), lastu0 (nu,B; NULL: zeros). */

@@ -353,6 +353,7 @@ struct Solver {
     bool hxlo, hxhi, hwlo, hwhi, hvlo, hvhi;
     bool cS;                                   // a slack variable ε >= 0 relaxes the rows with softness c > 0
     bool cL;                                   // window-long bounds (CLS_L): xlo .. vhi are re-read for every stage
+    bool cC;                                   // window-long softness (CLS_C): cx0 .. cv1 are re-read for every stage
     double cx0, cx1, cw0, cw1, cv0, cv1;       // softness of this lane's rows (0: hard)
 
     MPCQP_HD Solver(W& w_, const Dims& d_, const Args& a_, double* smem, int wave_id)
@@ -367,6 +368,7 @@ struct Solver {
         cX = (CM & CLS_X) && (d.cls & CLS_X); cW = (CM & CLS_W) && (d.cls & CLS_W); cV = (CM & CLS_V) && (d.cls & CLS_V);
         cS = (CM & CLS_S) && (d.cls & CLS_S);
         cL = (CM & (CLS_W | CLS_V)) && (d.cls & CLS_L);      // (served by the all-class variants only)
+        cC = cS && (d.cls & CLS_C);
     }
     // Scratch accesses are raw buffer loads / stores: the slot offset is the instruction's scalar offset, the lane's
     // byte offset ONE register for the whole kernel, and the idle lanes carry an out-of-range offset -- the
@@ -391,6 +393,7 @@ struct Solver {
     // x(s) (s = 0: the arrival state's own bound), ŵ(s), v̂ of the measurement attached to s -- take their bounds from
     // block (He - N + .) of the He-long vectors: a window of N < He periods uses the LAST N blocks (trunc_bounds).
     MPCQP_HD void stage_bounds(int s) {
+        if (cC) stage_softness(s);
         if (!cL) return;
         const int He = d.He, blk = He - N;
         auto at = [&](const double* p_, int nblk, int j, double dflt) {
@@ -410,6 +413,18 @@ struct Solver {
             vlo = at(a.vmin, He, blk + im, -BIG); vhi = at(a.vmax, He, blk + im, BIG);
             hvlo = vlo > -BIG; hvhi = vhi < BIG;
         }
+    }
+
+    // Window-long softness (setconstraint!(estim; C_x̂min, ..., C_v̂max), construct.jl:937-1020).  The softness is a column of
+    // the constraint matrices, which the reference does NOT truncate while the window grows (only the bound vectors go
+    // through trunc_bounds, transcription.jl:750-752): the rows of window entry j take softness block j, whatever Nk.
+    MPCQP_HD void stage_softness(int s) {
+        const int He = d.He;
+        auto at = [&](const double* p_, int nblk, int j) { return p_ ? p_[((size_t)b * nblk + j) * RL + r] : 0.0; };
+        if (cX) { cx0 = at(a.cxmin, He + 1, s); cx1 = at(a.cxmax, He + 1, s); }        // block 0: the arrival state
+        if (cW && s < N) { cw0 = at(a.cwmin, He, s); cw1 = at(a.cwmax, He, s); }
+        const int im = meas_of(s);
+        if (cV && im >= 0) { cv0 = at(a.cvmin, He, im); cv1 = at(a.cvmax, He, im); }
     }
 
     // O(j) = Oc - D̃w(j) Â: sub-diagonal block (j+1, j) of the Newton matrix (D̃w(j) from the forward sweep of phase 0)
@@ -576,7 +591,7 @@ struct Solver {
         wlo = bnd(a.wmin, cW, nx, -BIG); whi = bnd(a.wmax, cW, nx, BIG);
         vlo = bnd(a.vmin, cV, nym, -BIG); vhi = bnd(a.vmax, cV, nym, BIG);
         hxlo = xlo > -BIG; hxhi = xhi < BIG; hwlo = wlo > -BIG; hwhi = whi < BIG; hvlo = vlo > -BIG; hvhi = vhi < BIG;
-        auto sft = [&](const double* p_, bool on, int n) { return (cS && on && p_ && r < n) ? p_[(size_t)b * RL + r] : 0.0; };
+        auto sft = [&](const double* p_, bool on, int n) { return (cS && on && p_ && r < n && !cC) ? p_[(size_t)b * RL + r] : 0.0; };
         cx0 = sft(a.cxmin, cX, nx); cx1 = sft(a.cxmax, cX, nx); cw0 = sft(a.cwmin, cW, nx); cw1 = sft(a.cwmax, cW, nx);
         cv0 = sft(a.cvmin, cV, nym); cv1 = sft(a.cvmax, cV, nym);
         const double Cw = cS ? a.Cwt[b] : 0.0;

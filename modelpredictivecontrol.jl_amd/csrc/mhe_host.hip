@@ -32,6 +32,7 @@ struct mpcqp_mhe_s {
     double* bnd[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* bndw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // window-long bound arrays (CLS_L)
     double* sft[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* sftw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // window-long softness arrays (CLS_C)
     double* Cwt = nullptr;
     bool soft = false;       // finite Cwt: a slack variable exists
     double *s_y = nullptr, *s_u = nullptr, *s_d = nullptr;      // staging of the host-pointer entry points
@@ -273,6 +274,19 @@ int mpcqp_mhe_set_bounds_window(mpcqp_mhe h, const double* Xmin, const double* X
     return MPCQP_OK;
 }
 
+static int set_cwt(mpcqp_mhe h, const double* Cwt) {        // finite weights of ε², the slack's output array
+    mhe::Dims& d = h->d;
+    for (size_t b = 0; b < (size_t)d.B; ++b)
+        if (!(Cwt[b] >= 0.0) || std::isinf(Cwt[b])) return MPCQP_ERR_ARG;
+    if (!h->Cwt) { int rc = dalloc_t(h, &h->Cwt, (size_t)d.B); if (rc) return rc; }
+    int rc = up(h, h->Cwt, Cwt, (size_t)d.B);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->a.Cwt = h->Cwt;
+    if (!h->a.eps_out) { rc = dalloc_t(h, &h->a.eps_out, (size_t)d.B); if (rc) return rc; }
+    return MPCQP_OK;
+}
+
 int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin, const double* c_xmax, const double* c_wmin,
                            const double* c_wmax, const double* c_vmin, const double* c_vmax) {
     if (!h) return MPCQP_ERR_NULL;
@@ -290,18 +304,13 @@ int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin,
             }
     if (!Cwt) {                       // Cwt = Inf: hard constraints only
         if (any_c) return MPCQP_ERR_ARG;     // (the reference: "Cwt must be finite to set softness parameters")
-        d.cls &= ~mhe::CLS_S;
+        d.cls &= ~(mhe::CLS_S | mhe::CLS_C);
         h->soft = false;
         for (int k = 0; k < 6; ++k) *dst[k] = nullptr;
         return MPCQP_OK;
     }
-    for (size_t b = 0; b < (size_t)d.B; ++b)
-        if (!(Cwt[b] >= 0.0) || std::isinf(Cwt[b])) return MPCQP_ERR_ARG;
-    if (!h->Cwt) { int rc = dalloc_t(h, &h->Cwt, (size_t)d.B); if (rc) return rc; }
-    int rc = up(h, h->Cwt, Cwt, (size_t)d.B);
+    int rc = set_cwt(h, Cwt);
     if (rc) return rc;
-    h->a.Cwt = h->Cwt;
-    if (!h->a.eps_out) { rc = dalloc_t(h, &h->a.eps_out, (size_t)d.B); if (rc) return rc; }
     std::vector<double> buf((size_t)d.B * mhe::RL);
     for (int k = 0; k < 6; ++k) {
         if (!src[k]) { *dst[k] = nullptr; continue; }
@@ -314,7 +323,41 @@ int mpcqp_mhe_set_softness(mpcqp_mhe h, const double* Cwt, const double* c_xmin,
         *dst[k] = h->sft[k];
     }
     HIPCHK(hipStreamSynchronize(h->stream));
-    d.cls |= mhe::CLS_S;
+    d.cls = (d.cls | mhe::CLS_S) & ~mhe::CLS_C;
+    h->soft = true;
+    return MPCQP_OK;
+}
+
+int mpcqp_mhe_set_softness_window(mpcqp_mhe h, const double* Cwt, const double* C_xmin, const double* C_xmax, const double* C_wmin,
+                                  const double* C_wmax, const double* C_vmin, const double* C_vmax) {
+    if (!h) return MPCQP_ERR_NULL;
+    if (!Cwt) return MPCQP_ERR_ARG;          // (the reference: "Cwt must be finite to set softness parameters")
+    ON_DEVICE(h);
+    mhe::Dims& d = h->d;
+    const double* src[6] = {C_xmin, C_xmax, C_wmin, C_wmax, C_vmin, C_vmax};
+    const int n[6] = {d.nx, d.nx, d.nx, d.nx, d.nym, d.nym};
+    const int nblk[6] = {d.He + 1, d.He + 1, d.He, d.He, d.He, d.He};
+    const double** dst[6] = {&h->a.cxmin, &h->a.cxmax, &h->a.cwmin, &h->a.cwmax, &h->a.cvmin, &h->a.cvmax};
+    for (int k = 0; k < 6; ++k)
+        if (src[k])
+            for (size_t i = 0; i < (size_t)d.B * nblk[k] * n[k]; ++i)
+                if (!(src[k][i] >= 0.0) || std::isinf(src[k][i])) return MPCQP_ERR_ARG;      // softness is >= 0 and finite
+    int rc = set_cwt(h, Cwt);
+    if (rc) return rc;
+    for (int k = 0; k < 6; ++k) {
+        if (!src[k]) { *dst[k] = nullptr; continue; }
+        std::vector<double> buf((size_t)d.B * nblk[k] * mhe::RL);
+        for (size_t b = 0; b < (size_t)d.B; ++b)
+            for (int j = 0; j < nblk[k]; ++j)
+                for (int r = 0; r < mhe::RL; ++r)
+                    buf[(b * nblk[k] + j) * mhe::RL + r] = r < n[k] ? src[k][(b * nblk[k] + j) * n[k] + r] : 0.0;
+        if (!h->sftw[k]) { rc = dalloc_t(h, &h->sftw[k], buf.size()); if (rc) return rc; }
+        rc = up(h, h->sftw[k], buf.data(), buf.size());
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *dst[k] = h->sftw[k];
+    }
+    d.cls |= mhe::CLS_S | mhe::CLS_C;
     h->soft = true;
     return MPCQP_OK;
 }

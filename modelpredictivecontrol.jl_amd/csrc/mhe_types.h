@@ -19,8 +19,9 @@ namespace mhe {
 
 constexpr int RL = 16;    // lanes per estimator: one DPP row
 constexpr int GPW = 4;    // estimators per wavefront
-enum { CLS_X = 1u, CLS_W = 2u, CLS_V = 4u, CLS_S = 8u, CLS_L = 16u };   // bound classes; CLS_S: a slack variable ε relaxes some rows;
-                                                                        // CLS_L: the bound arrays are window-long (one row per stage)
+enum { CLS_X = 1u, CLS_W = 2u, CLS_V = 4u, CLS_S = 8u, CLS_L = 16u, CLS_C = 32u };   // bound classes; CLS_S: a slack variable ε relaxes some rows;
+                                                                        // CLS_L: the bound arrays are window-long (one row per stage);
+                                                                        // CLS_C: the softness arrays are window-long (C_x̂min ... C_v̂max)
 
 struct Dims {
     int B, nx, nu, nym, nd, He;
@@ -92,7 +93,8 @@ struct Args {
     const double *xmin, *xmax, *wmin, *wmax, *vmin, *vmax;   // [B][RL] per channel, |v| >= BIG: absent (null: class absent);
                                                              // with CLS_L: x [B][He+1][RL] (arrival state, then the window blocks
                                                              // oldest first), w and v [B][He][RL]; a window of Nk < He uses the LAST Nk blocks
-    const double *cxmin, *cxmax, *cwmin, *cwmax, *cvmin, *cvmax;   // [B][RL] softness c >= 0 of the rows (null: hard), CLS_S
+    const double *cxmin, *cxmax, *cwmin, *cwmax, *cvmin, *cvmax;   // [B][RL] softness c >= 0 of the rows (null: hard), CLS_S;
+                                                             // with CLS_C: laid out like the window-long bounds (x [B][He+1][RL], w / v [B][He][RL])
     const double* Cwt;           // [B] weight of ε² (CLS_S)
     double* eps_out;             // [B] optimal slack ε (CLS_S)
     double *Y0m, *U0, *D0, *X0old;   // data windows (rings): [B][He][nym], [B][He][nu], [B][He+1][nd], [B][He][nx]

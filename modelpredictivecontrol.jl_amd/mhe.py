@@ -19,7 +19,7 @@ import numpy as np
 from . import api
 from .api import MpcqpError, _chk, _f64, _ptr, colmajor
 
-EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_set_bounds_window", "mpcqp_mhe_set_softness", "mpcqp_mhe_init", "mpcqp_mhe_set_state", "mpcqp_mhe_shift_windows",
+EXPORTS = ("mpcqp_mhe_create", "mpcqp_mhe_destroy", "mpcqp_mhe_set_model", "mpcqp_mhe_set_bounds", "mpcqp_mhe_set_bounds_window", "mpcqp_mhe_set_softness", "mpcqp_mhe_set_softness_window", "mpcqp_mhe_init", "mpcqp_mhe_set_state", "mpcqp_mhe_shift_windows",
            "mpcqp_mhe_prepare", "mpcqp_mhe_update", "mpcqp_mhe_prepare_device", "mpcqp_mhe_update_device",
            "mpcqp_mhe_sync", "mpcqp_mhe_get", "mpcqp_mhe_device_ptr", "mpcqp_mhe_nk", "mpcqp_mhe_last_ms",
            "mpcqp_mhe_register_columns")
@@ -43,6 +43,7 @@ def _bind(lib):
     lib.mpcqp_mhe_set_bounds.argtypes = [C.c_void_p] * 7
     lib.mpcqp_mhe_set_bounds_window.argtypes = [C.c_void_p] * 7
     lib.mpcqp_mhe_set_softness.argtypes = [C.c_void_p] * 8
+    lib.mpcqp_mhe_set_softness_window.argtypes = [C.c_void_p] * 8
     lib.mpcqp_mhe_init.argtypes = [C.c_void_p] * 5
     lib.mpcqp_mhe_set_state.argtypes = [C.c_void_p] * 2
     lib.mpcqp_mhe_shift_windows.argtypes = [C.c_void_p] * 5
@@ -112,6 +113,11 @@ class MheHandle:
 
     def set_state(self, xhat0):
         _chk(self.lib, self.lib.mpcqp_mhe_set_state(self._h, _ptr(_f64(xhat0))))
+
+    def set_softness_window(self, Cwt, C_xmin=None, C_xmax=None, C_wmin=None, C_wmax=None, C_vmin=None, C_vmax=None):
+        """Window-long softness: Cwt (B,) finite; (B, (He+1) nx̂) [arrival; window oldest first], (B, He nx̂), (B, He nym); None = 0."""
+        arrs = [None if a is None else _f64(a) for a in (Cwt, C_xmin, C_xmax, C_wmin, C_wmax, C_vmin, C_vmax)]
+        _chk(self.lib, self.lib.mpcqp_mhe_set_softness_window(self._h, *[_ptr(a) for a in arrs]))
 
     def shift_windows(self, dy0m=None, du0=None, dd0=None, dx0=None):
         arrs = [None if a is None else _f64(a) for a in (dy0m, du0, dd0, dx0)]
@@ -233,9 +239,7 @@ class BatchMHE:
     # -- setconstraint! (construct.jl:858-1049): per-channel hard bounds --------------------------------
     def setconstraint(self, *, x̂min=None, x̂max=None, ŵmin=None, ŵmax=None, v̂min=None, v̂max=None, c_x̂min=None, c_x̂max=None,
                       c_ŵmin=None, c_ŵmax=None, c_v̂min=None, c_v̂max=None, **other):
-        full = [k for k in other if k in ("C_x̂min", "C_x̂max", "C_ŵmin", "C_ŵmax", "C_v̂min", "C_v̂max")]
-        if full:
-            raise MpcqpError(f"window-long softness vectors {full} are not supported by this build")
+        cwin = {k: other.pop(k) for k in ("C_x̂min", "C_x̂max", "C_ŵmin", "C_ŵmax", "C_v̂min", "C_v̂max") if k in other}
         win = {k: other.pop(k) for k in ("X̂min", "X̂max", "Ŵmin", "Ŵmax", "V̂min", "V̂max") if k in other}
         if other:
             raise TypeError(f"unknown setconstraint keywords {sorted(other)}")
@@ -273,9 +277,39 @@ class BatchMHE:
             if not self.nϵ:
                 raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
             self._soft[key] = np.broadcast_to(v, (B, n)).copy()
-        if self.nϵ:
+        if cwin or getattr(self, "_cwin", None):
+            self._setconstraint_softness_window(cwin, dict(c_x̂min=c_x̂min, c_x̂max=c_x̂max, c_ŵmin=c_ŵmin, c_ŵmax=c_ŵmax,
+                                                           c_v̂min=c_v̂min, c_v̂max=c_v̂max))
+        elif self.nϵ:
             self.handle.set_softness(np.full(B, self.Cwt), **self._soft)
         return self
+
+    def _setconstraint_softness_window(self, cwin, chan):
+        """Window-long softness C_x̂min ... C_v̂max (construct.jl:937-1020): (n (He+1),) / (n He,) vectors (or (B, .)) >= 0; a
+        per-channel keyword of the same or a later call fills its whole vector (`repeat(c_x̂min, He+1)`, construct.jl:958-963).
+        Once a window-long vector has been given the estimator stays on window-long softness."""
+        B, nx, nym, He = self.B, self.nx̂, self.nym, self.He
+        if not self.nϵ:
+            raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
+        cur = dict(getattr(self, "_cwin", None) or {})
+        spec = {"C_x̂min": (nx, He + 1, "c_x̂min", "c_xmin"), "C_x̂max": (nx, He + 1, "c_x̂max", "c_xmax"),
+                "C_ŵmin": (nx, He, "c_ŵmin", "c_wmin"), "C_ŵmax": (nx, He, "c_ŵmax", "c_wmax"),
+                "C_v̂min": (nym, He, "c_v̂min", "c_vmin"), "C_v̂max": (nym, He, "c_v̂max", "c_vmax")}
+        for K, (n, nblk, k, old) in spec.items():
+            if K in cwin and cwin[K] is not None:
+                v = np.asarray(cwin[K], float)
+                if v.shape not in ((n * nblk,), (B, n * nblk)):
+                    raise ValueError(f"{K} size must be ({n * nblk},)")                     # DimensionMismatch
+                if np.any(v < 0):
+                    raise ValueError(f"{K} weights should be non-negative")
+                cur[K] = np.broadcast_to(v, (B, n * nblk)).copy()
+            elif chan.get(k) is not None:
+                cur[K] = np.tile(self._soft[old], (1, nblk))
+            elif K not in cur:          # first window-long call: start from the per-channel softness in force
+                cur[K] = np.tile(self._soft[old], (1, nblk)) if old in self._soft else np.zeros((B, n * nblk))
+        self._cwin = cur
+        self.handle.set_softness_window(np.full(B, self.Cwt), cur["C_x̂min"], cur["C_x̂max"], cur["C_ŵmin"], cur["C_ŵmax"],
+                                        cur["C_v̂min"], cur["C_v̂max"])
 
     def _setconstraint_window(self, win, chan):
         """Window-long bounds X̂min ... V̂max (construct.jl:858-935): (n (He+1),) / (n He,) vectors (or (B, .)), a bound per

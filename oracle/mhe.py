@@ -246,7 +246,8 @@ class MHEOracle:
 
     def setconstraint(self, xhatmin=None, xhatmax=None, whatmin=None, whatmax=None, vhatmin=None, vhatmax=None,
                       c_xhatmin=None, c_xhatmax=None, c_whatmin=None, c_whatmax=None, c_vhatmin=None, c_vhatmax=None,
-                      Xhatmin=None, Xhatmax=None, Whatmin=None, Whatmax=None, Vhatmin=None, Vhatmax=None):
+                      Xhatmin=None, Xhatmax=None, Whatmin=None, Whatmax=None, Vhatmin=None, Vhatmax=None,
+                      C_xhatmin=None, C_xhatmax=None, C_whatmin=None, C_whatmax=None, C_vhatmin=None, C_vhatmax=None):
         """setconstraint! -- construct.jl:858-1049 (per-channel bounds repeated over the window; the
         arrival state takes the same x̂ bounds)."""
         He, nx = self.He, self.nxh
@@ -276,6 +277,21 @@ class MHEOracle:
         for key, v in (("C_wmin", c_whatmin), ("C_wmax", c_whatmax), ("C_vmin", c_vhatmin), ("C_vmax", c_vhatmax)):
             if v is not None:
                 self.soft[key] = np.tile(np.asarray(v, float), He)
+        # window-long softness (construct.jl:964-1000): C_x̂ = [arrival; He window states], C_ŵ and C_v̂ He blocks
+        for k0, k1, v in (("c_x0min", "C_xmin", C_xhatmin), ("c_x0max", "C_xmax", C_xhatmax)):
+            if v is not None:
+                v = np.asarray(v, float)
+                assert v.shape == (nx * (He + 1),)
+                if np.any(v < 0):
+                    raise ValueError(f"{k1} weights should be non-negative")
+                self.soft[k0], self.soft[k1] = v[:nx].copy(), v[nx:].copy()
+        for key, v, n in (("C_wmin", C_whatmin, nx), ("C_wmax", C_whatmax, nx), ("C_vmin", C_vhatmin, self.nym), ("C_vmax", C_vhatmax, self.nym)):
+            if v is not None:
+                v = np.asarray(v, float)
+                assert v.shape == (n * He,)
+                if np.any(v < 0):
+                    raise ValueError(f"{key} weights should be non-negative")
+                self.soft[key] = v.copy()
         if any(np.any(self.soft[k] != 0) for k in self.soft) and not self.neps:
             raise ValueError("Slack variable weight Cwt must be finite to set softness parameters")
         return self
@@ -331,6 +347,7 @@ class MHEOracle:
             q = np.concatenate([[0.0], q])
         FX = BX + GX @ U0 + (JX @ D0 if nd else 0.0)
         tr = lambda v, n: v[len(v) - n * Nk:]                        # trunc_bounds: the LAST Nk blocks
+        hd = lambda v, n: v[:n * Nk]        # softness = a column of A_X̂min ... A_V̂max, which is NOT truncated: the FIRST Nk blocks
         X0min, X0max = tr(self.con["X0min"], nx), tr(self.con["X0max"], nx)
         Wmin, Wmax = tr(self.con["Wmin"], nx), tr(self.con["Wmax"], nx)
         Vmin, Vmax = tr(self.con["Vmin"], nym), tr(self.con["Vmax"], nym)
@@ -338,9 +355,9 @@ class MHEOracle:
         col = lambda c: c.reshape(-1, 1)
         ex = -exb                                                     # x̂0arr = ex̂ Z
         blocks = [(-ex, -self.con["x0min"], s["c_x0min"]), (ex, self.con["x0max"], s["c_x0max"]),
-                  (-EX, -X0min + FX, tr(s["C_xmin"], nx)), (EX, X0max - FX, tr(s["C_xmax"], nx)),
-                  (-Tw, -Wmin, tr(s["C_wmin"], nx)), (Tw, Wmax, tr(s["C_wmax"], nx)),
-                  (-E, -Vmin + F, tr(s["C_vmin"], nym)), (E, Vmax - F, tr(s["C_vmax"], nym))]
+                  (-EX, -X0min + FX, hd(s["C_xmin"], nx)), (EX, X0max - FX, hd(s["C_xmax"], nx)),
+                  (-Tw, -Wmin, hd(s["C_wmin"], nx)), (Tw, Wmax, hd(s["C_wmax"], nx)),
+                  (-E, -Vmin + F, hd(s["C_vmin"], nym)), (E, Vmax - F, hd(s["C_vmax"], nym))]
         A = np.vstack([np.hstack([-col(c), a]) if ne else a for a, _, c in blocks])
         b = np.concatenate([bb for _, bb, _ in blocks])
         fin = np.isfinite(b)

@@ -301,11 +301,11 @@ def reference_setmodel(lib=None, B=2, oracle=False):
     return out
 
 
-def window_long_bounds(lib=None, B=3, seed=21, soft=False, nper=9):
+def window_long_bounds(lib=None, B=3, seed=21, soft=False, nper=9, csoft=False, eps_seen=None):
     """setconstraint!(estim; X̂min, ..., V̂max): a bound per channel AND stage (construct.jl:858-935), product against
     oracle over a growing and then moving window.  Returns the worst relative errors (x̂, Ŵ) and the number of periods in
     which some stage bound of the oracle's optimum was active."""
-    cfg = synth.MheConfig("winlong", nx=3, nu=1, nym=2, nd=0, He=5, **({"Cwt": 1e4} if soft else {}))
+    cfg = synth.MheConfig("winlong", nx=3, nu=1, nym=2, nd=0, He=5, **({"Cwt": 1e4} if (soft or csoft) else {}))
     bt = synth.make_mhe_batch(cfg, B, seed=seed)
     Y, U, D = synth.make_mhe_data(cfg, bt, nper, seed=seed)
     rng = np.random.default_rng(seed)
@@ -320,6 +320,19 @@ def window_long_bounds(lib=None, B=3, seed=21, soft=False, nper=9):
         bm.setconstraint(c_x̂max=np.full(nx, 0.5), c_v̂min=np.ones(nym))
         for e in ors:
             e.setconstraint(c_xhatmax=np.full(nx, 0.5), c_vhatmin=np.ones(nym))
+    if csoft:
+        # window-long SOFTNESS (C_x̂min ... C_v̂max, construct.jl:937-1020): a softness per channel and stage, zero (hard) on some
+        # rows; a per-channel keyword given first is overwritten where a window-long vector follows
+        Cx0 = rng.uniform(0.1, 1.0, nx * (He + 1)); Cx0[rng.random(Cx0.size) < 0.4] = 0.0
+        Cx1 = rng.uniform(0.1, 1.0, nx * (He + 1)); Cx1[rng.random(Cx1.size) < 0.4] = 0.0
+        Cw1 = rng.uniform(0.1, 1.0, nx * He); Cw1[rng.random(Cw1.size) < 0.4] = 0.0
+        Cv0 = rng.uniform(0.1, 1.0, nym * He); Cv0[rng.random(Cv0.size) < 0.4] = 0.0
+        bm.setconstraint(c_ŵmin=np.full(nx, 0.3), c_x̂min=np.full(nx, 9.0))
+        bm.setconstraint(C_x̂min=Cx0, C_x̂max=Cx1, C_ŵmax=Cw1, C_v̂min=Cv0)
+        for e in ors:
+            e.setconstraint(c_whatmin=np.full(nx, 0.3), c_xhatmin=np.full(nx, 9.0))
+            e.setconstraint(C_xhatmin=Cx0, C_xhatmax=Cx1, C_whatmax=Cw1, C_vhatmin=Cv0)
+        Xw = np.where(np.isinf(Xw), Xw, 0.6 * Xw); Ww = np.where(np.isinf(Ww), Ww, 0.6 * Ww)     # tighter: the slack is used
     bm.setconstraint(X̂min=-Xw, X̂max=Xw, Ŵmin=-Ww, Ŵmax=Ww, V̂min=-Vw, V̂max=Vw)
     for e in ors:
         e.setconstraint(Xhatmin=-Xw, Xhatmax=Xw, Whatmin=-Ww, Whatmax=Ww, Vhatmin=-Vw, Vhatmax=Vw)
@@ -338,6 +351,8 @@ def window_long_bounds(lib=None, B=3, seed=21, soft=False, nper=9):
         sc = max(1.0, np.abs(xo).max())
         ex = max(ex, np.abs(xg - xo).max() / sc)
         ew = max(ew, np.abs(info["Ŵ"] - Wo).max() / sc)
+        if eps_seen is not None and np.isfinite(cfg.Cwt):
+            eps_seen.append(max(float(e.Zt[0]) for e in ors))
         for e in ors:
             Xb = Xw[nx:][(He - Nk) * nx:]
             active += int(np.any(np.abs(np.abs(e.X0[:Nk * nx]) - Xb) <= 1e-6) or np.any(np.abs(np.abs(Wo) - Ww[(He - Nk) * nx:]) <= 1e-6))

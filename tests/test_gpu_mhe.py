@@ -268,6 +268,15 @@ def test_window_long_bounds(soft):
     assert ex <= TOL and ew <= TOL, (ex, ew)
 
 
+def test_window_long_softness():
+    """setconstraint!(estim; C_x̂min, ..., C_v̂max) (construct.jl:937-1020): a softness per channel and stage, zero (hard) on
+    some rows; the softness column of the constraint matrices is not truncated while the window grows."""
+    eps = []
+    ex, ew, active = mhe_util.window_long_bounds(B=6, nper=10, csoft=True, eps_seen=eps)
+    assert active > 0 and max(eps) > 1e-6
+    assert ex <= TOL and ew <= TOL, (ex, ew)
+
+
 def test_reference_setmodel_through_the_product():
     """setmodel!(::MovingHorizonEstimator, model), test/2_test_state_estim.jl:1668-1718."""
     for k, (v, want) in mhe_util.reference_setmodel(B=3).items():

@@ -72,8 +72,13 @@ def test_batchmhe_argument_checks(emulib):
         bm.setconstraint(c_x̂min=np.ones(4))
     with pytest.raises(ValueError, match="non-negative"):
         pm.BatchMHE(*args, He=3, Cwt=1e3, lib=emulib).setconstraint(c_v̂max=[-1.0, 0.0])
-    with pytest.raises(mpcqp.MpcqpError, match="window-long softness"):
+    with pytest.raises(ValueError, match="Cwt must be finite"):        # window-long softness needs the slack variable too
         bm.setconstraint(C_x̂min=np.zeros(16))
+    bs = pm.BatchMHE(*args, He=3, Cwt=1e3, lib=emulib)
+    with pytest.raises(ValueError, match="size must be"):               # nx̂ (He + 1) = 16
+        bs.setconstraint(C_x̂min=np.zeros(12))
+    with pytest.raises(ValueError, match="non-negative"):
+        bs.setconstraint(C_v̂max=-np.ones(6))
     with pytest.raises(ValueError, match="size"):
         bm.setconstraint(X̂min=np.zeros(12))                     # nx̂ (He + 1) = 16
     with pytest.raises(ValueError, match="ym size"):
@@ -194,6 +199,15 @@ def test_window_long_bounds_on_emulator(emulib):
     """setconstraint!(estim; X̂min, ..., V̂max): stage-dependent bounds, growing then moving window, against the oracle."""
     ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=2, nper=7)
     assert active > 0
+    assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
+
+
+def test_window_long_softness_on_emulator(emulib):
+    """setconstraint!(estim; C_x̂min, ..., C_v̂max) (construct.jl:937-1020): a softness per channel and stage (zero = hard on
+    some rows), growing then moving window (the softness column is not truncated, transcription.jl:737-752), vs the oracle."""
+    eps = []
+    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=2, nper=7, csoft=True, eps_seen=eps)
+    assert active > 0 and max(eps) > 1e-6, (active, eps)
     assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
 
 
