@@ -1111,6 +1111,122 @@ MPCQP_HD void predmat_body(W& w, const Dims& d, const Model& m, int b, double* s
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 on the matrix cores (nx̂ <= 16, ny <= 16, nu + 1 + nd <= 16): the recursions of init_predmat
+// (transcription.jl:115-194) are chains of small dense products with one common factor,
+//   [W | v | X](t+1) = Â [W | v | X](t) + [B̂u | dop | 0]      W = S(t) B̂u, v = S(t) dop, X = Â^t B̂d
+//   P'(t+1) = Â' P'(t)  (P = Ĉ Â^(t+1)),   T'(t+1) = Â' T'(t)  (T = Â^(t+1), terminal rows only)
+//   [Σ_t | B_t | Gd_t] = Ĉ [W | v | X](t)
+// i.e. 16 x 16 x 16 tiles = four v_mfma_f64_16x16x4 each, the constant factor as operand A.  The contraction
+// index is ordered so that K step kk covers the rows lk + 4 kk (lk = lane >> 4): the operand B of K step kk is then
+// register kk of the previous product's accumulator -- the state never leaves the accumulator registers: no LDS, no
+// barrier, no lane traffic; a wavefront's only memory traffic are the model (once) and the tables it emits.
+// Replaces the LDS loops of predmat_body below for these shapes (2.1 ms of dependent LDS round trips per 65536
+// controllers at C3, occupancy-bound: the time was inversely proportional to the resident wavefronts).
+// ------------------------------------------------------------------------------------------
+MPCQP_HD inline bool predmat_mfma_ok(const Dims& d) {
+    return d.nxh <= 16 && d.ny <= 16 && d.nu + 1 + d.nd <= 16;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void predmat_mfma(int lane, const Dims& d, const Model& m, int b, bool terminal) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    const int nx = d.nxh, nu = d.nu, ny = d.ny, nd = d.nd, Hp = d.Hp;
+    const int li = lane & 15, lk = lane >> 4;
+    const double* gA = m.Ahat + (size_t)b * nx * nx;          // A[i + nx*k]
+    const double* gB = m.Bu + (size_t)b * nx * nu;            // B[i + nx*c]
+    const double* gC = m.C + (size_t)b * ny * nx;             // C[a + ny*k]
+    const double* gD = m.dop ? m.dop + (size_t)b * nx : nullptr;
+    const double* gBd = nd > 0 ? m.Bd + (size_t)b * nx * nd : nullptr;
+    double aA[4], aAt[4], aC[4];
+    v4d_ Wf, Cw, Pt, Tt;
+    MPCQP_UNROLL
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = lk + 4 * kk;                            // contraction index / state row of this (lane, register)
+        const bool in = li < nx && k < nx;
+        aA[kk] = in ? gA[li + nx * k] : 0.0;                  // Â[li][k]
+        aAt[kk] = in ? gA[k + nx * li] : 0.0;                 // Â'[li][k]
+        aC[kk] = (li < ny && k < nx) ? gC[li + ny * k] : 0.0; // Ĉ[li][k]
+        double c0 = 0.0, w0 = 0.0;
+        if (k < nx) {
+            if (li < nu) c0 = w0 = gB[k + nx * li];
+            else if (li == nu) c0 = w0 = gD ? gD[k] : 0.0;
+            else if (li <= nu + nd) w0 = gBd[k + nx * (li - nu - 1)];
+        }
+        Cw[kk] = c0; Wf[kk] = w0;
+        Tt[kk] = aA[kk];                                      // T'(0)[k][li] = Â[li][k]
+    }
+    {   // P'(0) = Â' Ĉ'   (operand B: Ĉ'[k][li] = Ĉ[li][k] = aC)
+        v4d_ acc = {0.0, 0.0, 0.0, 0.0};
+        MPCQP_UNROLL
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aAt[kk], aC[kk], acc, 0, 0, 0);
+        Pt = acc;
+    }
+    double* Stab = m.Stab + (size_t)b * Hp * ny * nu;
+    double* Ktab = m.Ktab + (size_t)b * nx * d.nY;
+    double* Bvec = m.Bvec + (size_t)b * d.nY;
+    double* Gd = nd > 0 ? m.Gdtab + (size_t)b * Hp * ny * nd : nullptr;
+    for (int t = 0; t < Hp; ++t) {
+        // [Σ_t | B_t | Gd_t] = Ĉ [W | v | X](t): register r holds row a = lk + 4 r, column li
+        v4d_ sg = {0.0, 0.0, 0.0, 0.0};
+        MPCQP_UNROLL
+        for (int kk = 0; kk < 4; ++kk) sg = __builtin_amdgcn_mfma_f64_16x16x4f64(aC[kk], Wf[kk], sg, 0, 0, 0);
+        // the recursions (independent chains: issued together)
+        v4d_ wn = Cw, pn = {0.0, 0.0, 0.0, 0.0}, tn = {0.0, 0.0, 0.0, 0.0};
+        if (t + 1 < Hp) {
+            MPCQP_UNROLL
+            for (int kk = 0; kk < 4; ++kk) {
+                wn = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[kk], Wf[kk], wn, 0, 0, 0);
+                pn = __builtin_amdgcn_mfma_f64_16x16x4f64(aAt[kk], Pt[kk], pn, 0, 0, 0);
+            }
+            if (terminal) {
+                MPCQP_UNROLL
+                for (int kk = 0; kk < 4; ++kk) tn = __builtin_amdgcn_mfma_f64_16x16x4f64(aAt[kk], Tt[kk], tn, 0, 0, 0);
+            }
+        }
+        // ---- tables of step t
+        MPCQP_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            const int a = lk + 4 * r;           // output row of sg; state row k of Wf / Pt / Tt
+            if (a < ny) {
+                if (li < nu) Stab[(t * ny + a) * nu + li] = sg[r];
+                else if (li == nu) Bvec[t * ny + a] = sg[r];
+                else if (li <= nu + nd) Gd[(t * ny + a) * nd + (li - nu - 1)] = sg[r];
+            }
+            // K block t = P(t): P[li][k = a].  (32-byte pieces at a stride of nY doubles; collecting several steps in LDS for
+            // longer pieces was measured and is slower, 1.13 vs 0.95 ms at C3: the stores are a third of the time by their
+            // volume -- 1.0 GB of K per 65536 controllers -- not by their shape.)
+            if (li < ny && a < nx) Ktab[(size_t)a * d.nY + t * ny + li] = Pt[r];
+        }
+        if (terminal) {
+            for (int j = 0; j < d.Hc; ++j)
+                if (t == Hp - m.jl[j] - 1) {                  // ex̂ block j = S(Hp - j_j - 1) B̂u = W(t)
+                    double* ex = m.exT + ((size_t)b * d.Hc + j) * nx * nu;
+                    MPCQP_UNROLL
+                    for (int r = 0; r < 4; ++r)
+                        if (li < nu && lk + 4 * r < nx) ex[(lk + 4 * r) * nu + li] = Wf[r];
+                }
+            if (nd > 0) {
+                double* Xd = m.Xdtab + ((size_t)b * Hp + t) * nx * nd;
+                MPCQP_UNROLL
+                for (int r = 0; r < 4; ++r)
+                    if (li > nu && li <= nu + nd && lk + 4 * r < nx) Xd[(lk + 4 * r) * nd + (li - nu - 1)] = Wf[r];
+            }
+            if (t == Hp - 1) {
+                MPCQP_UNROLL
+                for (int r = 0; r < 4; ++r) {
+                    const int k = lk + 4 * r;
+                    if (li == nu && k < nx) m.bxv[(size_t)b * nx + k] = Wf[r];
+                    if (li < nx && k < nx) m.kxT[(size_t)b * nx * nx + li + nx * k] = Tt[r];      // T[li][k] = Â^Hp
+                }
+            }
+        }
+        Wf = wn; Pt = pn; Tt = tn;
+    }
+#endif
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
 // K2: H̃ = 2(Ẽ'MẼ + P̃Δu'ÑP̃Δu + P̃u'LP̃u), diagonal weights, packed lower triangle.
 // ------------------------------------------------------------------------------------------
 template <class W, class DM>

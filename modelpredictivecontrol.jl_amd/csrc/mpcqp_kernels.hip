@@ -30,9 +30,26 @@ extern char** environ;      // (the specialisation compiler inherits the environ
 
 namespace mpcqp {
 
+#ifndef MPCQP_K1_MFMA
+#define MPCQP_K1_MFMA 1           // 0: the LDS loops for every shape (timing experiments)
+#endif
+#ifndef MPCQP_K1_MFMA_MIN_NX
+#define MPCQP_K1_MFMA_MIN_NX 10   // below, the 16-wide tiles are mostly padding and the LDS loops are faster (C2, nx̂ = 6: 0.55 vs 0.66 ms)
+#endif
+static bool predmat_on_mfma(const Dims& d) {
+    static const int min_nx = [] {          // (MPCQP_K1_MFMA_MIN_NX=1 in the environment: every eligible shape, for the tests)
+        const char* e = getenv("MPCQP_K1_MFMA_MIN_NX");
+        return e && atoi(e) > 0 ? atoi(e) : MPCQP_K1_MFMA_MIN_NX;
+    }();
+    return MPCQP_K1_MFMA && predmat_mfma_ok(d) && d.nxh >= min_nx;
+}
 __global__ __launch_bounds__(64) void k_predmat(Dims d, Model m, int terminal) {
     DevWave w{(int)threadIdx.x};
     predmat_body(w, d, m, (int)blockIdx.x, mpcqp_smem, terminal != 0);
+}
+// the same tables from chains of v_mfma_f64_16x16x4 (predmat_mfma: no LDS, the state stays in the accumulators)
+__global__ __launch_bounds__(64) void k_predmat_mfma(Dims d, Model m, int terminal) {
+    predmat_mfma((int)threadIdx.x, d, m, (int)blockIdx.x, terminal != 0);
 }
 
 __global__ __launch_bounds__(64) void k_hessian(Dims d, Model m) {
@@ -60,6 +77,10 @@ __global__ __launch_bounds__(256) void k_kf_predict(Dims d, Model m, double* xha
 
 // ---- launchers (host) ------------------------------------------------------------------------
 hipError_t launch_predmat(const Dims& d, const Model& m, bool terminal, hipStream_t st) {
+    if (predmat_on_mfma(d)) {
+        hipLaunchKernelGGL(k_predmat_mfma, dim3(d.B), dim3(WAVE), 0, st, d, m, terminal ? 1 : 0);
+        return hipGetLastError();
+    }
     size_t lds = (size_t)predmat_lds_doubles(d) * sizeof(double);
     hipError_t e = ensure_lds((const void*)k_predmat, lds);
     if (e != hipSuccess) return e;

@@ -609,6 +609,24 @@ def test_random_controller_families_on_gpu(seed, hiplib):
     assert_specialised(kinds)
 
 
+def test_prediction_tables_on_the_matrix_cores_for_every_eligible_shape(hiplib):
+    """K1 has two forms: LDS loops, and chains of v_mfma_f64_16x16x4 whose state stays in the accumulators (predmat_mfma,
+    nx̂ >= 10 by default: C3 -- test_condensation_tables_match_oracle pins its tables at 1e-12).  The randomised families
+    have nx̂ <= 9; here they run with MPCQP_K1_MFMA_MIN_NX=1 (own process: the threshold is read once), so the terminal
+    tables (ex̂, kx̂, bx̂), the measured-disturbance tables (Gd, Xd) and ragged dimensions go through the matrix-core form."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, '.')\n"
+            "from tests.parity_util import run_random_case\n"
+            "errs = [run_random_case(s, B=4) for s in range(12)]\n"
+            "assert all(e is not None for e in errs), errs\n"
+            "print('WORST', max(errs))\n")
+    env = dict(os.environ, MPCQP_K1_MFMA_MIN_NX="1")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    worst = float(out.stdout.split("WORST")[1].split()[0])
+    assert worst <= TOL, worst
+
+
 @pytest.mark.parametrize("seed", [2000, 2004, 2014, 2021, 2028, 2083])
 def test_families_near_wave_limit(seed, hiplib):
     """Families drawn at 49 <= nZ̃ <= 64 (four 16-wide tiles on the matrix-core paths, the largest
