@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 import ctypes as C
 import mpcqp
 from mpcqp import synth
-cfg = synth.get_config(os.environ.get('AB_CFG', 'C3')); B = 65536
+cfg = synth.get_config(os.environ.get('AB_CFG', 'C3')); B = int(os.environ.get('AB_B', 65536))
 bt = synth.make_batch(cfg, B, seed=0)
 Zref = None
 for path in sys.argv[1:]:
