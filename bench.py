@@ -371,7 +371,9 @@ def secondary(args, local):
     recs = []
     # (third record: a problem beyond one variable per lane, nZ~ = 106 -- the on-demand specialisation of
     #  spec_manifest.txt with several rows per lane; VERDICT r2 item 5 quotes this shape at B = 8192)
-    for name, B in (("C2", 1024), ("C2", 65536), ("12,3,3,40,35", 8192)):
+    # (fourth record: C2 dimensions with C3's constraint pattern -- soft ymax + hard umin / umax -- i.e. output-bound rows on
+    #  the small-problem kernel, k_step_small_y)
+    for name, B in (("C2", 1024), ("C2", 65536), ("12,3,3,40,35", 8192), ("4,2,2,20,5", 65536)):
         cfg = synth.get_config(name)
         sh = Shard(cfg, 0, B, args.seed, local)
         elapsed, kern_ms = timed_run(sh, args.steps, args.warmup, None)

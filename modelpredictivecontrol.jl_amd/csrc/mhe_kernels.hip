@@ -8,7 +8,6 @@
 #include "mhe_devwave.h"
 #include "mhe_launch.h"
 #include "mpcqp_launch.h"
-#include "mpcqp_small_bodies.h"
 
 namespace mpcqp {
 namespace mhe {
@@ -66,23 +65,6 @@ hipError_t launch_step(const Dims& d, const Args& a, hipStream_t st) {
 }
 
 }  // namespace mhe
-
-#ifndef MPCQP_SMALL_WAVES
-#define MPCQP_SMALL_WAVES 2      // register budget of the small-problem step kernel, in waves per SIMD
-#endif
-template <int NX>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_SMALL_WAVES, 8))) void k_step_small(Dims d, Model m, StepIO io) {
-    mhe::MheDevWave w{(int)threadIdx.x};
-    step_small_body<mhe::MheDevWave, NX>(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
-}
-
-hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
-    const size_t lds = small_lds_doubles(d) * sizeof(double);
-    const unsigned grid = (unsigned)((d.B + SMALL_GPW - 1) / SMALL_GPW);
-    const int NXv = 4 * ((d.nZ + 3) / 4);
-    MHE_DISPATCH(NXv, hipLaunchKernelGGL(k_step_small<NX>, dim3(grid), dim3(WAVE), lds, st, d, m, io));
-    return hipGetLastError();
-}
 
 namespace mhe {
 

@@ -8,10 +8,16 @@
 //
 // Same step as Step::build / Step::run of mpcqp_bodies.h (initpred!, linconstraint!, optim_objective!, getinput!:
 // src/controller/execute.jl:247-277, 466-505, 536-546; transcription.jl:811-848, 997-1007) for the handles that
-// qualify (small_eligible() in mpcqp_kernels.hip): constraint groups box (hard ΔU bounds, ϵ >= 0) and U (hard or soft
-// input bounds, one merged row per interval and channel with its multiplicity as barrier weight), diagonal weights, no
-// output / terminal / custom rows.  Dual-regularised Mehrotra predictor-corrector as everywhere else, without the
-// active-set polish.
+// qualify (small_eligible() in mpcqp_launch.h): constraint groups box (hard ΔU bounds, ϵ >= 0), U (hard or soft
+// input bounds, one merged row per interval and channel with its multiplicity as barrier weight) and -- variant
+// HASY, nY <= 64 -- Y (hard or soft output bounds, any horizon-long pattern with +-Inf holes: setconstraint!(ymin, ymax,
+// Ymin, Ymax, c_ymin, ...), construct.jl:324-509), diagonal weights, no terminal / custom rows.  Dual-regularised Mehrotra
+// predictor-corrector as everywhere else, without the active-set polish.
+//
+// Y rows (HASY): row r = (step t, output a) of  -E z - c0 ϵ <= -Y0min + F,  E z - c1 ϵ <= Y0max - F  belongs to lane r % 16
+// of its controller, slot r / 16 (up to four slots per lane: s, λ of both sides in registers).  The dense E (nY x NX,
+// block (t, j) = Σ_(t - j_j), transcription.jl:134-165) is laid out once per step in LDS: E v reads the lane's own rows
+// against row-broadcasts of v, Eᵀw and EᵀD̃E read its columns against LDS vectors of the row values.
 #pragma once
 #include <math.h>
 
@@ -20,13 +26,21 @@
 
 namespace mpcqp {
 
-constexpr int SMALL_GPW = 4, SMALL_RL = 16;
+constexpr int SMALL_GPW = 4, SMALL_RL = 16, SMALL_KY = 4;      // SMALL_KY: Y-row slots per lane (nY <= 64)
 
-// per group: M(F - R̂y) and F (nY each) and the optimum (16) for the optional Ŷ output
-MPCQP_HD inline size_t small_lds_doubles(const Dims& d) { return (size_t)SMALL_GPW * (2 * d.nY + SMALL_RL); }
+// per group: M(F - R̂y) and F (nY each) and the optimum (16) for the optional Ŷ output; with Y rows the dense E
+// (nY x NX, NX = nZ̃ rounded up to a multiple of four) and two row vectors
+MPCQP_HD inline int small_row_slots(const Dims& d) { return d.nY <= 32 ? 2 : d.nY <= 48 ? 3 : 4; }      // KYS of the Y variant
+MPCQP_HD inline size_t small_group_doubles(const Dims& d, bool hasy) {
+    const int NXv = 4 * ((d.nZ + 3) / 4);
+    return (size_t)(2 * d.nY + SMALL_RL) + (hasy ? (size_t)d.nY * NXv + 2 * d.nY + 4 * small_row_slots(d) * SMALL_RL : 0);
+}
+MPCQP_HD inline size_t small_lds_doubles(const Dims& d, bool hasy = false) { return (size_t)SMALL_GPW * small_group_doubles(d, hasy); }
 
-template <class W, int NX>
+// KYS: Y-row slots per lane (0: the variant without output-bound rows; 2, 3, 4: nY <= 16 KYS)
+template <class W, int NX, int KYS = 0>
 MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO& io, int wg, double* smem) {
+    constexpr bool HASY = KYS > 0;
     using O = mhe::Ops<W, NX>;
     using Row = typename O::Row;
     O op{w};
@@ -37,9 +51,13 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     const int nx = d.nxh, nu = d.nu, ny = d.ny, nd = d.nd, nY = d.nY, nDU = d.nDU, nZ = d.nZ, Hp = d.Hp, Hc = d.Hc;
     const int e = nDU;                         // index of ϵ (when neps)
     const bool isvar = l < nZ, isdu = l < nDU, iseps = d.neps && l == e;
-    double* cyv = smem + (size_t)g * (2 * nY + SMALL_RL);
+    double* cyv = smem + (size_t)g * small_group_doubles(d, HASY);
     double* Fv = cyv + nY;          // F, kept for the optional Ŷ output
     double* zv = Fv + nY;           // the optimum, for the same
+    double* Ed = zv + SMALL_RL;     // (HASY) E[r][c], r < nY, c < NX (the ϵ column and the pad columns are zero)
+    double* dv = Ed + (HASY ? (size_t)nY * NX : 0);      // (HASY) row vector: D̃lo + D̃hi
+    double* wv = dv + (HASY ? nY : 0);                   // (HASY) row vector: multiplier-like values of the rows
+    double* yk = wv + (HASY ? nY : 0) + l;               // (HASY) this lane's row constants [4 KYS][16]: h lower, h upper, c lower, c upper
     const double* x0 = io.xhat0 + (size_t)b * nx;
     const double* lu = io.lastu0 + (size_t)b * nu;
     const double* Stab = m.Stab + (size_t)b * Hp * ny * nu;          // Σ_t [Hp][ny][nu]
@@ -70,6 +88,17 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             const double ry = rconst ? io.Ry[(size_t)b * ny + a] : io.Ry[(size_t)b * nY + r];
             cyv[r] = Md[r] * (acc - ry);
             Fv[r] = acc;
+        }
+    }
+    if constexpr (HASY) {
+        for (int idx = l; idx < nY * NX; idx += SMALL_RL) {
+            const int r = idx / NX, c = idx - r * NX, t = r / ny, a = r - t * ny;
+            double val = 0.0;
+            if (c < nDU) {
+                const int jc = c / nu, cc = c - jc * nu, t0 = jl(jc);
+                if (t0 <= t) val = Stab[((t - t0) * ny + a) * nu + cc];
+            }
+            Ed[idx] = val;
         }
     }
     w.sync();
@@ -121,6 +150,76 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         const double se_ = d.neps ? w.rsum(cs0 * w2 + cs1 * w3) : 0.0;
         return iseps ? -se_ : x;
     };
+    // ---- Y rows of this lane (HASY): slot q holds row r = l + 16 q
+    constexpr int KYM = HASY ? KYS : 1;
+    bool yp0[KYM], yp1[KYM];                   // lower / upper row present (finite bound)
+    // right-hand sides and softness of the lane's rows: read-only after the set-up, kept in LDS (64 registers otherwise)
+    auto yh0 = [&](int q) { return yk[(0 * KYM + q) * SMALL_RL]; };
+    auto yh1 = [&](int q) { return yk[(1 * KYM + q) * SMALL_RL]; };
+    auto yc0 = [&](int q) { return yk[(2 * KYM + q) * SMALL_RL]; };
+    auto yc1 = [&](int q) { return yk[(3 * KYM + q) * SMALL_RL]; };
+    double ys0[KYM], ys1[KYM], yl0[KYM], yl1[KYM];       // slacks, multipliers
+    int yr[KYM];
+    mhe::sfor<KYM>([&](auto iq) {
+        constexpr int q = decltype(iq)::v;
+        const int r = l + SMALL_RL * q;
+        const bool has = HASY && r < nY;
+        yr[q] = has ? r : 0;
+        double h0_ = 2.0 * BIG, h1_ = 2.0 * BIG, c0_ = 0.0, c1_ = 0.0;
+        if (has) {
+            const size_t o = (size_t)b * nY + r;
+            if (m.Y0min) h0_ = -m.Y0min[o] + Fv[r];
+            if (m.Y0max) h1_ = m.Y0max[o] - Fv[r];
+            if (d.neps) { c0_ = m.C_ymin ? m.C_ymin[o] : 1.0; c1_ = m.C_ymax ? m.C_ymax[o] : 1.0; }
+        }
+        if constexpr (HASY) {
+            yk[(0 * KYM + q) * SMALL_RL] = h0_; yk[(1 * KYM + q) * SMALL_RL] = h1_;
+            yk[(2 * KYM + q) * SMALL_RL] = c0_; yk[(3 * KYM + q) * SMALL_RL] = c1_;
+        }
+        yp0[q] = fabs(h0_) < BIG && h0_ == h0_; yp1[q] = fabs(h1_) < BIG && h1_ == h1_;
+        ys0[q] = ys1[q] = 1.0; yl0[q] = yl1[q] = 0.0;
+    });
+    // (E v)[r] for the lane's rows: v is one entry per lane, the row reads it through row broadcasts
+    auto ymul = [&](double v, double (&gy)[KYM]) {
+        if constexpr (HASY) {
+            double acc[KYM];
+            mhe::sfor<KYM>([&](auto iq) { acc[decltype(iq)::v] = 0.0; });
+            mhe::sfor<NX>([&](auto ic) {
+                constexpr int c = decltype(ic)::v;
+                const double vc = w.template rowbc<c>(v);
+                mhe::sfor<KYM>([&](auto iq) { constexpr int q = decltype(iq)::v; acc[q] = fma(Ed[yr[q] * NX + c], vc, acc[q]); });
+            });
+            mhe::sfor<KYM>([&](auto iq) { constexpr int q = decltype(iq)::v; gy[q] = acc[q]; });
+        }
+    };
+    // (Ey' w)[l]: w = whi - wlo on the ΔU part, -(c0 wlo + c1 whi) summed on ϵ  (absent rows pass zeros)
+    auto ytmul = [&](const double (&wlo)[KYM], const double (&whi)[KYM]) {
+        if constexpr (HASY) {
+            double se = 0.0;
+            mhe::sfor<KYM>([&](auto iq) {
+                constexpr int q = decltype(iq)::v;
+                if (l + SMALL_RL * q < nY) wv[yr[q]] = whi[q] - wlo[q];
+                se += yc0(q) * wlo[q] + yc1(q) * whi[q];
+            });
+            w.sync();
+            // (one wave per SIMD: nothing hides an LDS round trip but the loop's own independent work -- four rows in flight)
+            double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+            const double* Ec = Ed + (isvar ? l : 0);
+            int r = 0;
+            for (; r + 4 <= nY; r += 4) {
+                const double e0_ = Ec[r * NX], e1_ = Ec[(r + 1) * NX], e2_ = Ec[(r + 2) * NX], e3_ = Ec[(r + 3) * NX];
+                const double v0_ = wv[r], v1_ = wv[r + 1], v2_ = wv[r + 2], v3_ = wv[r + 3];
+                acc4[0] = fma(e0_, v0_, acc4[0]); acc4[1] = fma(e1_, v1_, acc4[1]); acc4[2] = fma(e2_, v2_, acc4[2]); acc4[3] = fma(e3_, v3_, acc4[3]);
+            }
+            for (; r < nY; ++r) acc4[0] = fma(Ec[r * NX], wv[r], acc4[0]);
+            const double acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+            const double set = d.neps ? w.rsum(se) : 0.0;
+            w.sync();
+            return iseps ? -set : (isdu ? acc : 0.0);
+        } else {
+            return 0.0;
+        }
+    };
     // ---- rows of this lane: 0 box lower, 1 box upper, 2 merged Umin, 3 merged Umax          (i_b: finite only)
     double h0 = 2.0 * BIG, h1 = 2.0 * BIG, h2 = 2.0 * BIG, h3 = 2.0 * BIG, wt = 1.0;
     if (isdu) {
@@ -145,9 +244,15 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     auto fin = [](double h) { return fabs(h) < BIG && h == h; };
     const bool p0 = fin(h0), p1 = fin(h1), p2 = fin(h2), p3 = fin(h3);
     const double w0 = 1.0, w1 = 1.0, w2 = wt, w3 = wt;
-    const double wsum = w.rsum((p0 ? w0 : 0.0) + (p1 ? w1 : 0.0) + (p2 ? w2 : 0.0) + (p3 ? w3 : 0.0));
+    double ycnt = 0.0, yhm = 0.0;
+    mhe::sfor<KYM>([&](auto iq) {
+        constexpr int q = decltype(iq)::v;
+        ycnt += (yp0[q] ? 1.0 : 0.0) + (yp1[q] ? 1.0 : 0.0);
+        yhm = fmax(yhm, fmax(yp0[q] ? fabs(yh0(q)) : 0.0, yp1[q] ? fabs(yh1(q)) : 0.0));
+    });
+    const double wsum = w.rsum((p0 ? w0 : 0.0) + (p1 ? w1 : 0.0) + (p2 ? w2 : 0.0) + (p3 ? w3 : 0.0) + ycnt);
     const bool norows = !(wsum > 0.0);
-    const double nh = 1.0 + w.rmax(fmax(fmax(p0 ? fabs(h0) : 0.0, p1 ? fabs(h1) : 0.0), fmax(p2 ? fabs(h2) : 0.0, p3 ? fabs(h3) : 0.0)));
+    const double nh = 1.0 + w.rmax(fmax(fmax(fmax(p0 ? fabs(h0) : 0.0, p1 ? fabs(h1) : 0.0), fmax(p2 ? fabs(h2) : 0.0, p3 ? fabs(h3) : 0.0)), yhm));
 
     // ---- warm start  Z̃s = [Z̃prev[nu+1:nΔU]; 0; ϵprev]                             transcription.jl:1001-1004
     const double* Zg = io.Z + (size_t)b * nZ;
@@ -163,6 +268,18 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         s0 = fmax(h0 + z, 1.0); s1 = fmax(h1 - z, 1.0); s2 = fmax(h2 - g2, 1.0); s3 = fmax(h3 - g3, 1.0);
         if (!p0) s0 = 1.0; if (!p1) s1 = 1.0; if (!p2) s2 = 1.0; if (!p3) s3 = 1.0;
         l0 = p0 ? 10.0 * w0 * mhe::recip(s0) : 0.0; l1 = p1 ? 10.0 * w1 * mhe::recip(s1) : 0.0; l2 = p2 ? 10.0 * w2 * mhe::recip(s2) : 0.0; l3 = p3 ? 10.0 * w3 * mhe::recip(s3) : 0.0;
+        if constexpr (HASY) {
+            double gy[KYM];
+            ymul(z, gy);
+            const double ze = epsof(z);
+            mhe::sfor<KYM>([&](auto iq) {
+                constexpr int q = decltype(iq)::v;
+                ys0[q] = yp0[q] ? fmax(yh0(q) + gy[q] + yc0(q) * ze, 1.0) : 1.0;
+                ys1[q] = yp1[q] ? fmax(yh1(q) - gy[q] + yc1(q) * ze, 1.0) : 1.0;
+                yl0[q] = yp0[q] ? 10.0 * mhe::recip(ys0[q]) : 0.0;
+                yl1[q] = yp1[q] ? 10.0 * mhe::recip(ys1[q]) : 0.0;
+            });
+        }
     }
     const double delta = d.dual_reg;
     int st = 1, it = 0;
@@ -183,12 +300,26 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         gmul(z, g2, g3);
         const double rp0 = -z + s0 - h0, rp1 = z + s1 - h1, rp2 = g2 + s2 - h2, rp3 = g3 + s3 - h3;
         const double hz = op.mv(H, z);
-        const double gl = (p1 ? l1 : 0.0) - (p0 ? l0 : 0.0) + gtmul(p2 ? l2 : 0.0, p3 ? l3 : 0.0);
+        double yrp0[KYM], yrp1[KYM];             // primal residuals of the Y rows:  G z + s - h
+        double yrpm = 0.0, ymus = 0.0;
+        if constexpr (HASY) {
+            double gy[KYM];
+            ymul(z, gy);
+            const double ze = epsof(z);
+            mhe::sfor<KYM>([&](auto iq) {
+                constexpr int q = decltype(iq)::v;
+                yrp0[q] = -gy[q] - yc0(q) * ze + ys0[q] - yh0(q);
+                yrp1[q] = gy[q] - yc1(q) * ze + ys1[q] - yh1(q);
+                yrpm = fmax(yrpm, fmax(yp0[q] ? fabs(yrp0[q]) : 0.0, yp1[q] ? fabs(yrp1[q]) : 0.0));
+                ymus += (yp0[q] ? ys0[q] * yl0[q] : 0.0) + (yp1[q] ? ys1[q] * yl1[q] : 0.0);
+            });
+        }
+        const double gl = (p1 ? l1 : 0.0) - (p0 ? l0 : 0.0) + gtmul(p2 ? l2 : 0.0, p3 ? l3 : 0.0) + ytmul(yl0, yl1);
         const double rd = isvar ? hz + qv + gl : 0.0;
-        rpn = w.rmax(fmax(fmax(p0 ? fabs(rp0) : 0.0, p1 ? fabs(rp1) : 0.0), fmax(p2 ? fabs(rp2) : 0.0, p3 ? fabs(rp3) : 0.0)));
+        rpn = w.rmax(fmax(fmax(fmax(p0 ? fabs(rp0) : 0.0, p1 ? fabs(rp1) : 0.0), fmax(p2 ? fabs(rp2) : 0.0, p3 ? fabs(rp3) : 0.0)), yrpm));
         const double rdn = w.rmax(fabs(rd));
         const double ndd = w.rmax(isvar ? fmax(fabs(qv), fmax(fabs(hz), fabs(gl))) : 0.0) + 1.0;
-        const double musum = w.rsum((p0 ? s0 * l0 : 0.0) + (p1 ? s1 * l1 : 0.0) + (p2 ? s2 * l2 : 0.0) + (p3 ? s3 * l3 : 0.0));
+        const double musum = w.rsum((p0 ? s0 * l0 : 0.0) + (p1 ? s1 * l1 : 0.0) + (p2 ? s2 * l2 : 0.0) + (p3 ? s3 * l3 : 0.0) + ymus);
         const double mu = norows ? 0.0 : musum / wsum;
 #ifdef MHE_DEBUG_PRINT
         if (l == 0) printf("[b%d] pass %d mu %.3e rpn %.3e rdn %.3e ndd %.3e laststep %.3e lastscale %.3e done %d\n", b, pass, mu, rpn, rdn, ndd, laststep, lastscale, (int)done);
@@ -229,11 +360,57 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
                 Phi[c] += iseps ? (c == e ? dee : (c < nDU ? rowv : 0.0)) : ((c == e && isdu) ? col : 0.0);
             });
         }
+        RowD yd0[KYM], yd1[KYM];
+        if constexpr (HASY) {      // + Ey' (D̃lo + D̃hi) Ey, the ϵ column Ey'(D̃lo c0 - D̃hi c1) and Φ[ϵ][ϵ] += sum D̃lo c0² + D̃hi c1²
+            double dee = 0.0;
+            mhe::sfor<KYM>([&](auto iq) {
+                constexpr int q = decltype(iq)::v;
+                yd0[q] = rowd(yp0[q], ys0[q], yl0[q]); yd1[q] = rowd(yp1[q], ys1[q], yl1[q]);
+                if (l + SMALL_RL * q < nY) {
+                    dv[yr[q]] = yd0[q].Dt + yd1[q].Dt;
+                    wv[yr[q]] = yd0[q].Dt * yc0(q) - yd1[q].Dt * yc1(q);
+                }
+                dee += yd0[q].Dt * yc0(q) * yc0(q) + yd1[q].Dt * yc1(q) * yc1(q);
+            });
+            w.sync();
+            double col = 0.0;
+            const int lc = isvar ? l : 0;
+            auto rank1 = [&](int r, double el, double dr, double wr, const Row& Er) {
+                el = isdu ? el : 0.0;
+                const double tt = el * dr;
+                col = fma(el, wr, col);
+                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = fma(tt, Er[c], Phi[c]); });
+            };
+            int r = 0;
+            for (; r + 2 <= nY; r += 2) {          // two rows in flight: the loads of both are issued before either update
+                Row Ea, Eb;
+                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; Eb[c] = Ed[(r + 1) * NX + c]; });
+                const double ela = Ed[r * NX + lc], elb = Ed[(r + 1) * NX + lc], da = dv[r], db = dv[r + 1], wa = wv[r], wb = wv[r + 1];
+                rank1(r, ela, da, wa, Ea);
+                rank1(r + 1, elb, db, wb, Eb);
+            }
+            for (; r < nY; ++r) {
+                Row Ea;
+                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; });
+                rank1(r, Ed[r * NX + lc], dv[r], wv[r], Ea);
+            }
+            if (d.neps) {
+                const double des = w.rsum(dee);
+                mhe::sfor<NX>([&](auto ic) {
+                    constexpr int c = decltype(ic)::v;
+                    const double rowv = w.template rowbc<c>(col);
+                    Phi[c] += iseps ? (c == e ? des : (c < nDU ? rowv : 0.0)) : ((c == e && isdu) ? col : 0.0);
+                });
+            }
+            w.sync();
+        }
         const bool ok = op.gj(Phi, l);
         if (!done && !ok) { st = 2; done = true; }
         // ---- predictor, corrector
         double smu = 0.0, alpha = 1.0, dz = 0.0;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;            // Δs Δλ of the affine step
+        double ya0[KYM], ya1[KYM], yds0[KYM], yds1[KYM], ydl0[KYM], ydl1[KYM];
+        mhe::sfor<KYM>([&](auto iq) { constexpr int q = decltype(iq)::v; ya0[q] = ya1[q] = yds0[q] = yds1[q] = ydl0[q] = ydl1[q] = 0.0; });
         double ds0 = 0, ds1 = 0, ds2 = 0, ds3 = 0, dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0;
         for (int phase = 0; phase < 2; ++phase) {
             auto cof = [&](bool has, const RowD& rr, double sv, double lv, double rp, double ex) {
@@ -243,11 +420,21 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             const double e2 = phase ? a2 - w2 * smu : 0.0, e3 = phase ? a3 - w3 * smu : 0.0;
             const double c0 = cof(p0, d0, s0, l0, rp0, e0), c1 = cof(p1, d1, s1, l1, rp1, e1);
             const double c2 = cof(p2, d2, s2, l2, rp2, e2), c3 = cof(p3, d3, s3, l3, rp3, e3);
-            const double gtc = gtmul(c2, c3);                           // (every lane takes part in the mat-vecs)
+            double ye0[KYM], ye1[KYM], ycf0[KYM], ycf1[KYM];
+            mhe::sfor<KYM>([&](auto iq) {
+                constexpr int q = decltype(iq)::v;
+                ye0[q] = phase ? ya0[q] - smu : 0.0; ye1[q] = phase ? ya1[q] - smu : 0.0;
+                ycf0[q] = HASY ? cof(yp0[q], yd0[q], ys0[q], yl0[q], yrp0[q], ye0[q]) : 0.0;
+                ycf1[q] = HASY ? cof(yp1[q], yd1[q], ys1[q], yl1[q], yrp1[q], ye1[q]) : 0.0;
+            });
+            const double gtc = gtmul(c2, c3) + ytmul(ycf0, ycf1);       // (every lane takes part in the mat-vecs)
             const double rhs = isvar ? -rd + (c1 - c0) + gtc : 0.0;
             dz = op.mv(Phi, rhs);
             double gd2, gd3;
             gmul(dz, gd2, gd3);
+            double gdy[KYM];
+            double dze = 0.0;
+            if constexpr (HASY) { ymul(dz, gdy); dze = epsof(dz); }
             auto dir = [&](bool has, const RowD& rr, double sv, double lv, double rp, double gd, double ex, double& ds, double& dl) {
                 const double rc = fma(sv, lv, ex), a = rp + gd;
                 dl = has ? rr.wi * fma(lv, a, -rc) : 0.0;
@@ -256,13 +443,29 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             dir(p0, d0, s0, l0, rp0, -dz, e0, ds0, dl0); dir(p1, d1, s1, l1, rp1, dz, e1, ds1, dl1);
             dir(p2, d2, s2, l2, rp2, gd2, e2, ds2, dl2); dir(p3, d3, s3, l3, rp3, gd3, e3, ds3, dl3);
             double am = 1e300;
+            if constexpr (HASY) {
+                mhe::sfor<KYM>([&](auto iq) {
+                    constexpr int q = decltype(iq)::v;
+                    dir(yp0[q], yd0[q], ys0[q], yl0[q], yrp0[q], -gdy[q] - yc0(q) * dze, ye0[q], yds0[q], ydl0[q]);
+                    dir(yp1[q], yd1[q], ys1[q], yl1[q], yrp1[q], gdy[q] - yc1(q) * dze, ye1[q], yds1[q], ydl1[q]);
+                    am = fmin(am, fmin(fmin(mhe::ratio(ys0[q], yds0[q]), mhe::ratio(yl0[q], ydl0[q])),
+                                       fmin(mhe::ratio(ys1[q], yds1[q]), mhe::ratio(yl1[q], ydl1[q]))));
+                });
+            }
             am = fmin(am, fmin(fmin(mhe::ratio(s0, ds0), mhe::ratio(l0, dl0)), fmin(mhe::ratio(s1, ds1), mhe::ratio(l1, dl1))));
             am = fmin(am, fmin(fmin(mhe::ratio(s2, ds2), mhe::ratio(l2, dl2)), fmin(mhe::ratio(s3, ds3), mhe::ratio(l3, dl3))));
             const double amin = w.rmin(am);
             if (!phase) {
                 const double aaff = fmin(1.0, amin);
+                double ymas = 0.0;
+                mhe::sfor<KYM>([&](auto iq) {
+                    constexpr int q = decltype(iq)::v;
+                    ymas += (yp0[q] ? (ys0[q] + aaff * yds0[q]) * (yl0[q] + aaff * ydl0[q]) : 0.0) +
+                            (yp1[q] ? (ys1[q] + aaff * yds1[q]) * (yl1[q] + aaff * ydl1[q]) : 0.0);
+                    ya0[q] = yds0[q] * ydl0[q]; ya1[q] = yds1[q] * ydl1[q];
+                });
                 const double mas = w.rsum((s0 + aaff * ds0) * (l0 + aaff * dl0) * (p0 ? 1.0 : 0.0) + (s1 + aaff * ds1) * (l1 + aaff * dl1) * (p1 ? 1.0 : 0.0) +
-                                          (s2 + aaff * ds2) * (l2 + aaff * dl2) * (p2 ? 1.0 : 0.0) + (s3 + aaff * ds3) * (l3 + aaff * dl3) * (p3 ? 1.0 : 0.0));
+                                          (s2 + aaff * ds2) * (l2 + aaff * dl2) * (p2 ? 1.0 : 0.0) + (s3 + aaff * ds3) * (l3 + aaff * dl3) * (p3 ? 1.0 : 0.0) + ymas);
                 const double sig = (mas / wsum) / mu;
                 smu = sig * sig * sig * mu;
                 a0 = ds0 * dl0; a1 = ds1 * dl1; a2 = ds2 * dl2; a3 = ds3 * dl3;
@@ -273,9 +476,16 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
                 alpha = fmin(1.0, 0.9999 * amin);
                 auto pr = [&](bool has, double sv, double ds, double lv, double dl) { return has ? (sv + alpha * ds) * (lv + alpha * dl) : 0.0; };
                 const double q0 = pr(p0, s0, ds0, l0, dl0), q1 = pr(p1, s1, ds1, l1, dl1), q2 = pr(p2, s2, ds2, l2, dl2), q3 = pr(p3, s3, ds3, l3, dl3);
-                const double psum = w.rsum(q0 + q1 + q2 + q3);
+                double yps = 0.0, ypm = 1e300;
+                mhe::sfor<KYM>([&](auto iq) {
+                    constexpr int q = decltype(iq)::v;
+                    const double y0_ = pr(yp0[q], ys0[q], yds0[q], yl0[q], ydl0[q]), y1_ = pr(yp1[q], ys1[q], yds1[q], yl1[q], ydl1[q]);
+                    yps += y0_ + y1_;
+                    ypm = fmin(ypm, fmin(yp0[q] ? y0_ : 1e300, yp1[q] ? y1_ : 1e300));
+                });
+                const double psum = w.rsum(q0 + q1 + q2 + q3 + yps);
                 const double iwt = mhe::recip_fast(wt);         // (w0 = w1 = 1, w2 = w3 = wt)
-                const double pmin = w.rmin(fmin(fmin(p0 ? q0 : 1e300, p1 ? q1 : 1e300), fmin(p2 ? q2 * iwt : 1e300, p3 ? q3 * iwt : 1e300)));
+                const double pmin = w.rmin(fmin(fmin(fmin(p0 ? q0 : 1e300, p1 ? q1 : 1e300), fmin(p2 ? q2 * iwt : 1e300, p3 ? q3 * iwt : 1e300)), ypm));
                 if (!(pmin * wsum >= 0.01 * psum)) alpha = fmin(1.0, 0.99 * amin);
             }
         }
@@ -286,6 +496,11 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             if (p1) { s1 += al * ds1; l1 += al * dl1; }
             if (p2) { s2 += al * ds2; l2 += al * dl2; }
             if (p3) { s3 += al * ds3; l3 += al * dl3; }
+            mhe::sfor<KYM>([&](auto iq) {
+                constexpr int q = decltype(iq)::v;
+                if (yp0[q]) { ys0[q] += al * yds0[q]; yl0[q] += al * ydl0[q]; }
+                if (yp1[q]) { ys1[q] += al * yds1[q]; yl1[q] += al * ydl1[q]; }
+            });
             const double zm = w.rmax(isdu ? fmax(1.0, fabs(z)) : 1.0), dm = w.rmax(isdu ? fabs(al * dz) : 0.0);
             if (isvar && !done) z += al * dz;
             if (!done) {

@@ -8,5 +8,5 @@ OBJ=$ROOT/modelpredictivecontrol.jl_amd/lib/obj
 mkdir -p $ROOT/modelpredictivecontrol.jl_amd/lib/ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -w -DMPCQP_MS_PROFILE "$@" -c $CS/ms_kernels.hip -o /tmp/ms_kernels_prof.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/modelpredictivecontrol.jl_amd/lib/ab/libmpcqp_msprof.so \
-  /tmp/ms_kernels_prof.o $OBJ/mpcqp_kernels.hip.o $OBJ/mpcqp_host.hip.o $OBJ/mhe_kernels.hip.o $OBJ/mhe_host.hip.o -ldl
+  /tmp/ms_kernels_prof.o $OBJ/mpcqp_kernels.hip.o $OBJ/mpcqp_host.hip.o $OBJ/mhe_kernels.hip.o $OBJ/small_kernels.hip.o $OBJ/mhe_host.hip.o -ldl
 echo built

@@ -143,7 +143,15 @@ hipError_t launch_step(const Dims& d, const Args& a, hipStream_t) {
 hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hipStream_t) {
     using namespace mhe;
     const int grid = (d.B + SMALL_GPW - 1) / SMALL_GPW, NXv = 4 * ((d.nZ + 3) / 4);
-    MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX>(w, d, m, io, wv, sm); }));
+    if (small_has_y(d)) {
+        switch (small_row_slots(d)) {
+            case 2: MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d, true), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 2>(w, d, m, io, wv, sm); })); break;
+            case 3: MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d, true), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 3>(w, d, m, io, wv, sm); })); break;
+            default: MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d, true), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 4>(w, d, m, io, wv, sm); })); break;
+        }
+    } else {
+        MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 0>(w, d, m, io, wv, sm); }));
+    }
     return hipSuccess;
 }
 

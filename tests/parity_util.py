@@ -74,7 +74,10 @@ def fused_loop_vs_separate_steps(lib=None, B=3, periods=4, torch_device=None):
     K = mpcqp.steady_kalman_gain(bt["Ahat"], bt["Chat"], np.eye(cfg.nxh), np.eye(cfg.ny))
 
     def make():
-        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=1, flags=mpcqp.FLAG_RY_CONSTANT, lib=lib)
+        # (FLAG_KEEP_QP: a step that keeps q̃ / F runs on the one-controller-per-wavefront kernel like the fused loop does; without
+        #  it the separate step of this nZ̃ = 7 controller takes the small-problem kernel -- output-bound rows included since round
+        #  4 -- whose arithmetic differs in the last bits)
+        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=1, flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_KEEP_QP, lib=lib)
         hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
         hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt))
         hd.set_bounds(U0min=np.full((B, hd.nU), cfg.umin), U0max=np.full((B, hd.nU), cfg.umax), Y0max=np.full((B, hd.nY), cfg.ymax))
@@ -652,7 +655,7 @@ def dense_weight_case(lib=None, B=3, which=("M", "N", "L"), seed=0):
     return worst, mpc.hd.kernel_kind()
 
 
-def small_kernel_cases(lib=None, B=6):
+def small_kernel_cases(lib=None, B=6, with_y=False):
     """The small-problem step kernel (nZ̃ <= 16, box + input-bound rows, four controllers per wavefront:
     csrc/mpcqp_small_bodies.h) against the oracle, member by member, over two periods (cold, then warm started):
     hard u / Δu box (C2), soft input bounds with an active ϵ, measured disturbances with a D̂ preview, a non-default
@@ -660,6 +663,7 @@ def small_kernel_cases(lib=None, B=6):
     Returns the worst relative ΔU error and the kernel kinds."""
     rng = np.random.default_rng(0)
     worst, kinds = 0.0, []
+    yact = []                 # (with_y) per case: output-bound rows on their bound at the oracle's optima, largest slack ϵ
     cases = [
         dict(cfg=synth.C2, kw={}, con=constraint_kwargs(synth.C2)),
         dict(cfg=synth.Config("soft-u", nx=3, nu=2, ny=2, Hp=12, Hc=4, Cwt=1e3), kw={},
@@ -667,6 +671,21 @@ def small_kernel_cases(lib=None, B=6):
         dict(cfg=synth.Config("nb", nx=3, nu=2, ny=2, Hp=9, Hc=[2, 1, 3, 3], Cwt=np.inf), kw={}, con=dict(umin=[-0.5, -0.4], umax=[0.5, 0.6])),
         dict(cfg=synth.Config("free", nx=3, nu=3, ny=2, Hp=8, Hc=4, Cwt=np.inf), kw={}, con={}),
     ]
+    if with_y:
+        # output-bound rows on the small-problem kernel (variant HASY): soft band on C2 shapes with an active ϵ, a hard
+        # horizon-long upper bound with +-Inf holes next to hard input bounds, soft y + soft u sharing the slack, ymin only
+        inf = np.inf
+        Ymax_holes = np.tile([0.8, inf], 10); Ymax_holes[[4, 5, 12]] = inf
+        cases = [
+            dict(cfg=synth.Config("C2-soft-y", nx=4, nu=2, ny=2, Hp=20, Hc=5, Cwt=1e5), kw={},
+                 con=dict(umin=[-1.0, -1.0], umax=[1.0, 1.0], Δumin=[-0.5, -0.5], Δumax=[0.5, 0.5], ymin=[-0.15, -0.2], ymax=[0.15, 0.2])),
+            dict(cfg=synth.Config("hard-Y-holes", nx=3, nu=2, ny=2, Hp=10, Hc=3, Cwt=np.inf), kw={},
+                 con=dict(umin=[-2.0, -2.0], umax=[2.0, 2.0], Ymax=Ymax_holes)),
+            dict(cfg=synth.Config("soft-y-soft-u", nx=3, nu=2, ny=3, Hp=12, Hc=4, Cwt=1e3), kw={},
+                 con=dict(umin=[-0.25, -0.3], umax=[0.25, 0.3], c_umin=[1.0, 0.5], c_umax=[0.5, 1.0], ymax=[0.1, 0.2, inf],
+                          c_ymax=[1.0, 0.3, 1.0], ymin=[-inf, -0.3, -0.2], c_ymin=[1.0, 2.0, 0.0])),
+            dict(cfg=synth.Config("ymin-nb", nx=3, nu=1, ny=1, Hp=16, Hc=[2, 2, 4, 8], Cwt=1e4), kw={}, con=dict(ymin=[-0.05], Δumax=[0.3])),
+        ]
     for case in cases:
         cfg, con = case["cfg"], case["con"]
         Hc = cfg.Hc
@@ -682,6 +701,7 @@ def small_kernel_cases(lib=None, B=6):
         lu = bt["lastu0"].copy()
         mpc.lastu0 = lu.copy()
         nDU = mpc.nDU
+        nact, epsmax = 0, 0.0
         for period in range(2):
             x0 = bt["xhat0"] * (1.0 - 0.2 * period)
             Ru = 0.2 * rng.standard_normal((B, mpc.nU))
@@ -693,11 +713,20 @@ def small_kernel_cases(lib=None, B=6):
                 z, st, _ = qp.solve_qp(*m.qp_data(), m.warmstart(), return_info=True)
                 assert st == 0
                 m.Zt = z
+                if with_y:
+                    ze = z[-1] if m.neps else 0.0
+                    Y0 = m.Et @ z + m.F
+                    lo = np.isfinite(m.Y0min) & (np.abs(Y0 - (m.Y0min - m.C_ymin * ze)) <= 1e-7)
+                    hi = np.isfinite(m.Y0max) & (np.abs(Y0 - (m.Y0max + m.C_ymax * ze)) <= 1e-7)
+                    nact += int(lo.sum() + hi.sum()); epsmax = max(epsmax, ze)
                 worst = max(worst, np.abs(mpc.Z[i, :nDU] - z[:nDU]).max() / max(1.0, np.abs(z[:nDU]).max()))
                 if mpc.neps:
                     worst = max(worst, abs(mpc.Z[i, -1] - z[-1]) / max(1.0, abs(z[-1])))
             lu = mpc.lastu0.copy()
         kinds.append(mpc.hd.kernel_kind())
+        yact.append((nact, epsmax))
+    if with_y:
+        return worst, kinds, yact
     return worst, kinds
 
 

@@ -687,7 +687,8 @@ def test_rejected_specialisation_falls_back_to_generic_kernel(hiplib, tmp_path, 
     import os
     monkeypatch.setenv("MPCQP_CACHE_DIR", str(tmp_path))
     monkeypatch.setenv("MPCQP_JIT_SELFTEST_TOL", "-1")
-    cfg = synth.Config("reject", nx=3, nu=2, ny=2, Hp=9, Hc=3, umin=-0.7, umax=0.7, ymax=0.8)
+    # (Hc = 8: nZ̃ = 17, beyond the small-problem kernel, which needs no specialisation)
+    cfg = synth.Config("reject", nx=3, nu=2, ny=2, Hp=9, Hc=8, umin=-0.7, umax=0.7, ymax=0.8)
     bt = synth.make_batch(cfg, 4, seed=5)
     got = run_batch(cfg, bt)
     assert got["mpc"].hd.kernel_kind() == mpcqp.api.KERNEL_GENERIC
@@ -699,7 +700,7 @@ def test_rejected_specialisation_falls_back_to_generic_kernel(hiplib, tmp_path, 
     monkeypatch.setenv("MPCQP_JIT_SELFTEST_TOL", "1e-6")
     for f in files:
         os.remove(os.path.join(tmp_path, f))
-    cfg2 = synth.Config("accept", nx=3, nu=2, ny=2, Hp=10, Hc=3, umin=-0.7, umax=0.7, ymax=0.8)
+    cfg2 = synth.Config("accept", nx=3, nu=2, ny=2, Hp=10, Hc=8, umin=-0.7, umax=0.7, ymax=0.8)
     bt2 = synth.make_batch(cfg2, 4, seed=5)
     got2 = run_batch(cfg2, bt2)
     assert got2["mpc"].hd.kernel_kind() == mpcqp.api.KERNEL_ONDEMAND and any(f.endswith(".ok") for f in os.listdir(tmp_path))
@@ -712,8 +713,9 @@ def test_dense_weight_matrices_on_gpu(hiplib, which):
     worst, kind = dense_weight_case(B=5, which=which)
     assert worst <= TOL, worst
     # (a dense M_Hp / L_Hp handle gets an on-demand variant of its own that carries the dense gradient products,
-    #  accepted by mpcqp_prepare's comparison with the runtime-dimension kernel)
-    assert kind == mpcqp.api.KERNEL_ONDEMAND
+    #  accepted by mpcqp_prepare's comparison with the runtime-dimension kernel; a dense N_Hc only enters H̃, so this
+    #  nZ̃ = 7 controller with its output bound runs on the small-problem kernel since round 4)
+    assert kind == (mpcqp.api.KERNEL_SMALL if which == ("N",) else mpcqp.api.KERNEL_ONDEMAND)
 
 
 def test_audit_of_the_convergence_test(hiplib):
@@ -737,6 +739,44 @@ def test_small_problem_kernel_on_gpu(hiplib):
     worst, kinds = small_kernel_cases(B=9)
     assert worst <= TOL, worst
     assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
+
+
+def test_small_problem_kernel_with_output_bounds_on_gpu(hiplib):
+    """Output-bound rows on the small-problem kernel (k_step_small_y: soft band with an active ϵ, hard horizon-long bound
+    with +-Inf holes, soft y + soft u, ymin with move blocking): every member vs the oracle, rows on their bounds."""
+    from tests.parity_util import small_kernel_cases
+    worst, kinds, yact = small_kernel_cases(B=9, with_y=True)
+    assert worst <= TOL, worst
+    assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
+    assert all(n > 0 for n, _ in yact) and max(e for _, e in yact) > 1e-3, yact
+
+
+def test_small_problem_kernel_with_soft_ymax_full_batch(hiplib):
+    """65536 C2-size controllers with a soft output band (the setconstraint!(ymax = ...) case that used to leave the
+    small-problem kernel): all solved, and the same optimum as the one-controller-per-wavefront kernels
+    (MPCQP_SMALL_Y=0 in a process of its own) on a strided sample."""
+    import subprocess, sys, json
+    code = ("import sys, json; sys.path.insert(0, '.')\n"
+            "import numpy as np, mpcqp\nfrom mpcqp import synth\n"
+            "cfg = synth.Config('C2y', nx=4, nu=2, ny=2, Hp=20, Hc=5, Cwt=1e5)\n"
+            "B = 65536; bt = synth.make_batch(cfg, B, seed=0)\n"
+            "mpc = mpcqp.BatchLinMPC(bt['Ahat'], bt['Bhu'], bt['Chat'], Hp=20, Hc=5, Cwt=1e5, Mwt=np.ones(2), Nwt=np.full(2, 0.1), Lwt=np.zeros(2))\n"
+            "mpc.setconstraint(umin=[-1, -1], umax=[1, 1], Δumin=[-0.5, -0.5], Δumax=[0.5, 0.5], ymin=[-0.15, -0.2], ymax=[0.15, 0.2])\n"
+            "mpc.lastu0 = bt['lastu0'].copy(); mpc.moveinput(bt['xhat0'], bt['ry'])\n"
+            "print('RESULT', json.dumps(dict(kind=int(mpc.hd.kernel_kind()), ok=float(np.mean(mpc.status == 0)), ms=mpc.hd.last_step_ms(),"
+            " Z=mpc.Z[::257].tolist(), eps=float(mpc.Z[:, -1].max()))))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("small", {}), ("wave", {"MPCQP_SMALL_Y": "0"})):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        res[tag] = json.loads(out.stdout.split("RESULT")[1])
+    assert res["small"]["kind"] == mpcqp.api.KERNEL_SMALL and res["wave"]["kind"] != mpcqp.api.KERNEL_SMALL
+    assert res["small"]["ok"] == 1.0 and res["small"]["eps"] > 1e-3
+    Zs, Zw = np.array(res["small"]["Z"]), np.array(res["wave"]["Z"])
+    err = np.abs(Zs - Zw)[:, :-1].max(axis=1) / np.maximum(1.0, np.abs(Zw[:, :-1]).max(axis=1))
+    assert err.max() <= TOL, err.max()
+    print(f"soft-ymax C2 shapes, B = 65536: small-problem kernel {res['small']['ms']:.2f} ms, one controller per wavefront {res['wave']['ms']:.2f} ms")
 
 
 def test_small_problem_kernel_full_batch_C2(hiplib):
