@@ -206,7 +206,7 @@ def test_window_long_softness_on_emulator(emulib):
     """setconstraint!(estim; C_x̂min, ..., C_v̂max) (construct.jl:937-1020): a softness per channel and stage (zero = hard on
     some rows), growing then moving window (the softness column is not truncated, transcription.jl:737-752), vs the oracle."""
     eps = []
-    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=2, nper=7, csoft=True, eps_seen=eps)
+    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=1, nper=6, csoft=True, eps_seen=eps)      # (one estimator, growing then one moving period: a minute on the emulator)
     assert active > 0 and max(eps) > 1e-6, (active, eps)
     assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
 
