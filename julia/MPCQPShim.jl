@@ -212,18 +212,19 @@ function BatchMHE(estims::Vector{<:MovingHorizonEstimator}; device::Integer=0)
           Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[],
           cat3(c -> c.Â), cat3(c -> c.B̂u), cat3(c -> c.Ĉm), nd > 0 ? cat3(c -> c.B̂d) : C_NULL,
           nd > 0 ? cat3(c -> c.D̂dm) : C_NULL, cat2(c -> c.f̂op - c.x̂op), cat3(c -> c.cov.Q̂), cat3(c -> c.cov.R̂)))
-    # per-channel hard bounds (setconstraint! x̂min, ..., v̂max): the first block of the window-long vectors
-    nx̂, nym = e.nx̂, e.nym
-    first(v, n) = v[1:n]
-    check(ccall((:mpcqp_mhe_set_bounds, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+    # bounds of setconstraint! as the reference keeps them: window-long vectors (con.x̂0min for the arrival state, then
+    # con.X̂0min; con.Ŵmin; con.V̂min -- a per-channel keyword fills the whole vector, construct.jl:890-935), so the
+    # window-long entry points are the faithful binding whatever mix of keywords the user called
+    check(ccall((:mpcqp_mhe_set_bounds_window, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
           Ptr{Float64}, Ptr{Float64}), h[],
-          cat2(c -> c.con.x̂0min), cat2(c -> c.con.x̂0max), cat2(c -> first(c.con.Ŵmin, nx̂)), cat2(c -> first(c.con.Ŵmax, nx̂)),
-          cat2(c -> first(c.con.V̂min, nym)), cat2(c -> first(c.con.V̂max, nym))))
-    if !isinf(e.C)         # soft constraints: Cwt and the softness of each channel (first column block of the A_* matrices)
-        check(ccall((:mpcqp_mhe_set_softness, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+          cat2(c -> vcat(c.con.x̂0min, c.con.X̂0min)), cat2(c -> vcat(c.con.x̂0max, c.con.X̂0max)),
+          cat2(c -> Vector(c.con.Ŵmin)), cat2(c -> Vector(c.con.Ŵmax)), cat2(c -> Vector(c.con.V̂min)), cat2(c -> Vector(c.con.V̂max))))
+    if !isinf(e.C)         # soft constraints: Cwt and the softness of every row (first column of the A_* matrices = -C, construct.jl:964-1000)
+        check(ccall((:mpcqp_mhe_set_softness_window, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
               Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], [c.C for c in estims],
-              cat2(c -> -c.con.A_x̂min[:, 1]), cat2(c -> -c.con.A_x̂max[:, 1]), cat2(c -> -Vector(c.con.A_Ŵmin[1:nx̂, 1])),
-              cat2(c -> -Vector(c.con.A_Ŵmax[1:nx̂, 1])), cat2(c -> -c.con.A_V̂min[1:nym, 1]), cat2(c -> -c.con.A_V̂max[1:nym, 1])))
+              cat2(c -> vcat(-Vector(c.con.A_x̂min[:, 1]), c.con.C_x̂min)), cat2(c -> vcat(-Vector(c.con.A_x̂max[:, 1]), c.con.C_x̂max)),
+              cat2(c -> -Vector(c.con.A_Ŵmin[:, 1])), cat2(c -> -Vector(c.con.A_Ŵmax[:, 1])),
+              cat2(c -> Vector(c.con.C_v̂min)), cat2(c -> Vector(c.con.C_v̂max))))
     end
     x̂0 = cat2(c -> c.x̂0)
     check(ccall((:mpcqp_mhe_init, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[],
