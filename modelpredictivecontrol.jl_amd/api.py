@@ -97,6 +97,25 @@ def _share_hip_runtime_with_torch():
         C.CDLL(rt, mode=C.RTLD_GLOBAL)
 
 
+def _check_hip_runtime(lib):
+    """The library is built against the system ROCm; the process may run on another HIP runtime (the PyTorch wheel's copy,
+    see _share_hip_runtime_with_torch).  A different MAJOR version is worth a warning."""
+    import re
+    import warnings
+    m = re.search(r"HIP (\d+)\.(\d+)", lib.mpcqp_version().decode())
+    try:
+        rt = C.CDLL("libamdhip64.so")              # (already mapped: resolves to the copy this process uses)
+        v = C.c_int(0)
+        if not m or int(m.group(1)) == 0 or rt.hipRuntimeGetVersion(C.byref(v)) != 0:       # (0.0: the CPU emulator build)
+            return
+    except (OSError, AttributeError):
+        return
+    if v.value // 10000000 != int(m.group(1)):
+        warnings.warn(f"mpcqp: built against HIP {m.group(1)}.{m.group(2)}, running on HIP runtime {v.value // 10000000}."
+                      f"{v.value // 100000 % 100} (MPCQP_SYSTEM_HIP=1 keeps the system runtime in processes that never import torch)",
+                      RuntimeWarning, stacklevel=3)
+
+
 def load_library(path: str | None = None):
     """Load (once) the HIP shared library.  `path` is for tests only."""
     global _lib
@@ -111,6 +130,7 @@ def load_library(path: str | None = None):
     _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     lib.mpcqp_version.restype = C.c_char_p
+    _check_hip_runtime(lib)
     lib.mpcqp_strerror.restype = C.c_char_p
     lib.mpcqp_strerror.argtypes = [C.c_int]
     lib.mpcqp_last_hip_error.restype = C.c_char_p

@@ -102,7 +102,14 @@ struct mpcqp_multi_s {
 
 extern "C" {
 
-const char* mpcqp_version(void) { return "mpcqp 0.1.0 (gfx950)"; }
+#ifndef HIP_VERSION_MAJOR      // (the CPU wave emulator's stand-in runtime, tests/emu/fakehip)
+#define HIP_VERSION_MAJOR 0
+#define HIP_VERSION_MINOR 0
+#endif
+#define MPCQP_STR2(x) #x
+#define MPCQP_STR(x) MPCQP_STR2(x)
+// (the HIP version of the BUILD: the loader of api.py compares it with the runtime the process ends up with)
+const char* mpcqp_version(void) { return "mpcqp 0.1.0 (gfx950, HIP " MPCQP_STR(HIP_VERSION_MAJOR) "." MPCQP_STR(HIP_VERSION_MINOR) ")"; }
 
 const char* mpcqp_strerror(int code) {
     switch (code) {
