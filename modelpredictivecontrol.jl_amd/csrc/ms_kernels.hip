@@ -18,8 +18,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     ms_step_body<false>(w, d, m, io, ms, (int)blockIdx.x, mpcqp_smem, (double*)nullptr);
 }
 
+#ifndef MPCQP_MS_WAVES
+#define MPCQP_MS_WAVES 2
+#endif
 // (two wavefronts per SIMD: without the attribute the compiler takes 372 registers and leaves one)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ms_step_g(Dims d, Model m, StepIO io, MsIO ms, size_t big) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_MS_WAVES, 8))) void k_ms_step_g(Dims d, Model m, StepIO io, MsIO ms, size_t big) {
     DevWave w{(int)threadIdx.x};
     double* scratch = ms.scratch + (size_t)blockIdx.x * big;
     // controllers are handed out one at a time (ms.next: a counter in HBM, zeroed before the launch): a solve that runs to
