@@ -51,6 +51,19 @@ struct MheDevWave : DevWave {
             : "+v"(acc)
             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
     }
+    // a_i += (x of lane L_i of this lane's row) * y_i, four accumulators: a row of a rank-one update whose left factor is
+    // spread over the lanes (one v_fmac_f64_dpp per element instead of a broadcast move, selects and an add)
+    template <int L0, int L1, int L2, int L3>
+    __device__ __forceinline__ void rank1bc4(double& a0, double& a1, double& a2, double& a3, double x, double y0, double y1,
+                                             double y2, double y3) const {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+            : "v"(x), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
+    }
     // Gauss-Jordan row update of four elements: a_i <- m a_i + g (a_i of lane K)
     template <int K>
     __device__ __forceinline__ void gjrow4(double& a0, double& a1, double& a2, double& a3, double m, double g) const {

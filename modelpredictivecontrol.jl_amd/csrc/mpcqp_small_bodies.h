@@ -344,21 +344,29 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         // lane's own for the columns up to its own, the column's lane's (row broadcast) for the later columns.
         // (GU = 1 on the columns c <= l of the lane's channel, GUt = 1 on the columns c >= l: both include c = l.)
         const double suf = op.mv(GUt, d2.Dt + d3.Dt);
-        mhe::sfor<NX>([&](auto ic) {
-            constexpr int c = decltype(ic)::v;
-            const double later = w.template rowbc<c>(suf);
-            Phi[c] = fma(GU[c], suf, H[c]);
-            Phi[c] = fma(GUt[c], later - (l == c ? suf : 0.0), Phi[c]);
+        // (Φ[l][c] = H̃ + GU[c] suf(l) + GUt[c] suf(c): the second product takes its left factor from lane c -- the row
+        //  broadcast is the multiply-add's own DPP modifier; both count the diagonal, taken out again with the box rows' D̃)
+        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = fma(GU[c], suf, H[c]); });
+        mhe::sfor<NX / 4>([&](auto ij) {
+            constexpr int c = 4 * decltype(ij)::v;
+            w.template rank1bc4<c, c + 1, c + 2, c + 3>(Phi[c], Phi[c + 1], Phi[c + 2], Phi[c + 3], suf, GUt[c], GUt[c + 1], GUt[c + 2], GUt[c + 3]);
         });
-        O::add_diag(Phi, l, d0.Dt + d1.Dt);
+        O::add_diag(Phi, l, d0.Dt + d1.Dt - (isdu ? suf : 0.0));
+        // ϵ row and column of a group of soft rows: the row (lane ϵ) takes the column vector `col` of the ΔU lanes across the
+        // row -- zero on the other lanes by construction --, every ΔU lane its own entry into column ϵ, lane ϵ the diagonal
+        const double meps = iseps ? 1.0 : 0.0;
+        auto eps_border = [&](double col, double dee) {
+            mhe::sfor<NX / 4>([&](auto ij) {
+                constexpr int c = 4 * decltype(ij)::v;
+                w.template rank1bc4<c, c + 1, c + 2, c + 3>(Phi[c], Phi[c + 1], Phi[c + 2], Phi[c + 3], col, meps, meps, meps, meps);
+            });
+            const double xe = iseps ? dee : (isdu ? col : 0.0);
+            mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += (c == e) ? xe : 0.0; });
+        };
         if (d.neps) {      // ϵ column / row: Φ[k][ϵ] = sum_j P̃u[j][k] (D̃2 cs0 - D̃3 cs1)_j,  Φ[ϵ][ϵ] += sum_j D̃2 cs0² + D̃3 cs1²
             const double col = op.mv(GUt, d2.Dt * cs0 - d3.Dt * cs1);
             const double dee = w.rsum(d2.Dt * cs0 * cs0 + d3.Dt * cs1 * cs1);
-            mhe::sfor<NX>([&](auto ic) {
-                constexpr int c = decltype(ic)::v;
-                const double rowv = w.template rowbc<c>(col);          // Φ[ϵ][c] = Φ[c][ϵ]
-                Phi[c] += iseps ? (c == e ? dee : (c < nDU ? rowv : 0.0)) : ((c == e && isdu) ? col : 0.0);
-            });
+            eps_border(col, dee);
         }
         RowD yd0[KYM], yd1[KYM];
         if constexpr (HASY) {      // + Ey' (D̃lo + D̃hi) Ey, the ϵ column Ey'(D̃lo c0 - D̃hi c1) and Φ[ϵ][ϵ] += sum D̃lo c0² + D̃hi c1²
@@ -394,14 +402,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
                 mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; });
                 rank1(r, Ed[r * NX + lc], dv[r], wv[r], Ea);
             }
-            if (d.neps) {
-                const double des = w.rsum(dee);
-                mhe::sfor<NX>([&](auto ic) {
-                    constexpr int c = decltype(ic)::v;
-                    const double rowv = w.template rowbc<c>(col);
-                    Phi[c] += iseps ? (c == e ? des : (c < nDU ? rowv : 0.0)) : ((c == e && isdu) ? col : 0.0);
-                });
-            }
+            if (d.neps) eps_border(col, w.rsum(dee));
             w.sync();
         }
         const bool ok = op.gj(Phi, l);

@@ -58,6 +58,11 @@ struct EmuWave {
         acc = fma(rowbc<L0>(x0), y0, acc); acc = fma(rowbc<L1>(x1), y1, acc);
         acc = fma(rowbc<L2>(x2), y2, acc); acc = fma(rowbc<L3>(x3), y3, acc);
     }
+    template <int L0, int L1, int L2, int L3>
+    void rank1bc4(double& a0, double& a1, double& a2, double& a3, double x, double y0, double y1, double y2, double y3) {
+        const double b0 = rowbc<L0>(x), b1 = rowbc<L1>(x), b2 = rowbc<L2>(x), b3 = rowbc<L3>(x);
+        a0 = fma(b0, y0, a0); a1 = fma(b1, y1, a1); a2 = fma(b2, y2, a2); a3 = fma(b3, y3, a3);
+    }
     template <int K>
     void gjrow4(double& a0, double& a1, double& a2, double& a3, double m, double g) {
         const double b0 = rowbc<K>(a0), b1 = rowbc<K>(a1), b2 = rowbc<K>(a2), b3 = rowbc<K>(a3);
