@@ -18,6 +18,7 @@
     XNB(1, 1, 3, 6, 3, 1, 0x39Fu)    \
     XNB(1, 1, 3, 6, 3, 1, 0x08Du)
 
+#define MPCQP_EMU_FIBER_IMPL        // (the context switch of emu_fiber.h is assembled in this unit)
 #include "emu_wave.h"
 
 namespace mpcqp {

@@ -9,6 +9,7 @@
 #include <thread>
 #include <vector>
 
+#include "emu_fiber.h"
 #include "mhe_bodies.h"
 #include "mhe_launch.h"
 #include "mpcqp_launch.h"
@@ -18,7 +19,7 @@ namespace mpcqp {
 namespace mhe {
 
 struct EmuShared {
-    std::barrier<> bar{WAVE};
+    LaneFibers& bar = lane_fibers();
     double xd[2][WAVE];
     unsigned long calls[WAVE] = {};      // cross-lane operations of every lane (MPCQP_EMU_WATCHDOG)
 };
@@ -90,7 +91,6 @@ template <class F>
 static void run_waves(int nwaves, size_t lds_doubles, F body) {
     std::vector<double> smem(lds_doubles + 16, 0.0);
     EmuShared sh;
-    std::vector<std::thread> th;
     std::atomic<bool> stop{false};
     std::thread dog;
     if (getenv("MPCQP_EMU_WATCHDOG"))      // lanes that stopped agreeing on the number of cross-lane operations
@@ -109,15 +109,13 @@ static void run_waves(int nwaves, size_t lds_doubles, F body) {
                 last = mx;
             }
         });
-    for (int lane = 0; lane < WAVE; ++lane)
-        th.emplace_back([&, lane] {
-            EmuWave w{lane, &sh};
-            for (int wv = 0; wv < nwaves; ++wv) {
-                body(w, wv, smem.data());
-                w.sync();
-            }
-        });
-    for (auto& t : th) t.join();
+    sh.bar.run([&](int lane) {
+        EmuWave w{lane, &sh};
+        for (int wv = 0; wv < nwaves; ++wv) {
+            body(w, wv, smem.data());
+            w.sync();
+        }
+    });
     stop = true;
     if (dog.joinable()) dog.join();
 }

@@ -1,9 +1,9 @@
-// TEST INFRASTRUCTURE ONLY: the CPU "wavefront" of the emulator -- one host thread per lane, a barrier for every wave-level
-// operation.  Shared by emu_launch.cpp and emu_ms.cpp.
+// TEST INFRASTRUCTURE ONLY: the CPU "wavefront" of the emulator -- one cooperative fiber per lane (emu_fiber.h), a barrier for
+// every wave-level operation.  Shared by emu_launch.cpp and emu_ms.cpp.
 #pragma once
-#include <barrier>
-#include <thread>
 #include <vector>
+
+#include "emu_fiber.h"
 
 #include <math.h>
 
@@ -12,7 +12,7 @@
 namespace mpcqp {
 
 struct EmuShared {
-    std::barrier<> bar{WAVE};
+    LaneFibers& bar = lane_fibers();
     double xd[WAVE];
     int xi[WAVE];
 };
@@ -77,16 +77,13 @@ template <class F>
 inline void run_waves(int B, size_t lds_doubles, F body) {
     std::vector<double> smem(lds_doubles + 16, 0.0);
     EmuShared sh;
-    std::vector<std::thread> th;
-    for (int lane = 0; lane < WAVE; ++lane)
-        th.emplace_back([&, lane] {
-            EmuWave w{lane, &sh};
-            for (int b = 0; b < B; ++b) {
-                body(w, b, smem.data());
-                w.sync();
-            }
-        });
-    for (auto& t : th) t.join();
+    sh.bar.run([&](int lane) {
+        EmuWave w{lane, &sh};
+        for (int b = 0; b < B; ++b) {
+            body(w, b, smem.data());
+            w.sync();
+        }
+    });
 }
 
 }  // namespace mpcqp

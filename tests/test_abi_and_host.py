@@ -259,7 +259,7 @@ def test_kalman_steps_on_cpu_emulator(nd, emulib):
         assert np.abs(gpu.xhat0[0] - kf.x0).max() < 1e-6
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", list(range(12)))      # (the lanes of the emulator are fibers since round 4: a second per family)
 def test_random_controller_families_on_cpu_emulator(seed, emulib):
     """Randomly drawn dimensions / move blocking / bound patterns / softness / terminal bounds /
     measured disturbance, two periods, against the certified oracle optimum."""
@@ -313,7 +313,7 @@ def test_family_beyond_one_row_per_lane_on_cpu_emulator(emulib):
     assert e is not None and e <= 1e-5
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", list(range(6)))
 def test_random_horizon_wide_forms_on_cpu_emulator(seed, emulib):
     """Time-varying bound vectors with holes, R̂y / R̂u / D̂ trajectories, block-diagonal M_Hp and
     (odd seed) custom linear constraints, against the certified oracle optimum."""

@@ -197,16 +197,25 @@ def test_setstate_keeps_windows_and_arrival_covariance(emulib):
 
 def test_window_long_bounds_on_emulator(emulib):
     """setconstraint!(estim; X̂min, ..., V̂max): stage-dependent bounds, growing then moving window, against the oracle."""
-    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=1, nper=7)        # (one estimator: under a minute on the emulator; six at ten periods on the GPU)
+    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=2, nper=9)
     assert active > 0
     assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_randomised_families_on_emulator(seed, emulib):
+    """Randomised MovingHorizonEstimator families (dimensions, form, horizon, bound classes, hard / soft: tests/mhe_util.random_family,
+    the families of the GPU sweeps) through the product on the CPU wave emulator against oracle/mhe.py -- affordable since the
+    emulator's lanes are fibers (tests/emu/emu_fiber.h)."""
+    worst, compared, _ = mhe_util.random_family(seed, lib=emulib, B=2)
+    assert compared > 0 and worst <= 1e-5, (worst, compared)
 
 
 def test_window_long_softness_on_emulator(emulib):
     """setconstraint!(estim; C_x̂min, ..., C_v̂max) (construct.jl:937-1020): a softness per channel and stage (zero = hard on
     some rows), growing then moving window (the softness column is not truncated, transcription.jl:737-752), vs the oracle."""
     eps = []
-    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=1, nper=6, csoft=True, eps_seen=eps)      # (one estimator, growing then one moving period: a minute on the emulator)
+    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=2, nper=9, csoft=True, eps_seen=eps)
     assert active > 0 and max(eps) > 1e-6, (active, eps)
     assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
 
