@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY: runs the kernel bodies of csrc/mpcqp_bodies.h on the CPU, one host
-// thread per lane of a 64-wide "wavefront", problems one after the other.  See fakehip/.
+// fiber per lane of a 64-wide "wavefront" (emu_fiber.h), problems one after the other.  See fakehip/.
 #include <barrier>
 #include <thread>
 #include <vector>

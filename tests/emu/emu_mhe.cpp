@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY: runs the MovingHorizonEstimator kernel bodies (csrc/mhe_bodies.h) on the
-// CPU, one host thread per lane of a 64-wide "wavefront", wavefronts one after the other.
+// CPU, one cooperative fiber per lane of a 64-wide "wavefront" (emu_fiber.h), wavefronts one after the other.
 #include <algorithm>
 #include <atomic>
 #include <barrier>
