@@ -318,7 +318,7 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
 #define MPCQP_KERNEL_GENERIC   0
 #define MPCQP_KERNEL_AOT       1
 #define MPCQP_KERNEL_ONDEMAND  2
-#define MPCQP_KERNEL_SMALL     3   /* nZ~ <= 16 with box, input-bound and (nY <= 64) output-bound rows: four controllers per wavefront
+#define MPCQP_KERNEL_SMALL     3   /* nZ~ <= 16 with box, input-bound and (<= 64 in all) output-bound / terminal rows: four controllers per wavefront
                                     * (csrc/mpcqp_small_bodies.h); a step that fuses the Kalman steps (mpcqp_loop_device)
                                     * runs on the kernel the other rules select */
 #define MPCQP_KERNEL_MS        4   /* MultipleShooting handles (mpcqp_set_transcription): the stage-structured kernel

@@ -27,19 +27,23 @@ hipError_t launch_step_unverified_spec(const Dims& d, const Model& m, const Step
 // Small problems (nZ~ <= 16; box, input-bound and -- nY <= 64 -- output-bound rows): four controllers per wavefront
 // (mpcqp_small_bodies.h)
 hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);
-inline bool small_has_y(const Dims& d) { return ((d.gmask >> (2 * P_Y)) & 3u) != 0; }
+inline int small_dense_rows_(const Dims& d) {         // = small_dense_rows(d) of mpcqp_small_bodies.h: output-bound + terminal rows
+    return (((d.gmask >> (2 * P_Y)) & 3u) ? d.nY : 0) + (((d.gmask >> (2 * P_X)) & 3u) ? d.nxh : 0);
+}
+inline bool small_has_y(const Dims& d) { return small_dense_rows_(d) > 0; }       // the variant with dense rows (k_step_small_y)
 inline size_t small_lds_bytes(const Dims& d) {       // = small_lds_doubles(d, small_has_y(d)) * 8 (mpcqp_small_bodies.h)
-    const int NXv = 4 * ((d.nZ + 3) / 4);
-    const int kys = d.nY <= 32 ? 2 : d.nY <= 48 ? 3 : 4;
-    return (size_t)4 * ((size_t)(2 * d.nY + 16) + (small_has_y(d) ? (size_t)d.nY * NXv + 2 * d.nY + 64 * kys : 0)) * sizeof(double);
+    const int NXv = 4 * ((d.nZ + 3) / 4), nR = small_dense_rows_(d);
+    const int kys = nR <= 32 ? 2 : nR <= 48 ? 3 : 4;
+    return (size_t)4 * ((size_t)(2 * d.nY + 16) + (nR ? (size_t)nR * NXv + 2 * nR + 64 * kys + d.nxh : 0)) * sizeof(double);
 }
 inline bool small_eligible(const Dims& d, const Model& m, const StepIO& io) {
     static const bool on = [] { const char* e = getenv("MPCQP_SMALL"); return !(e && e[0] == '0'); }();
     static const bool ony = [] { const char* e = getenv("MPCQP_SMALL_Y"); return !(e && e[0] == '0'); }();
-    const uint32_t groups = 0xFu | (3u << (2 * P_Y));      // box, U, Y
-    return on && d.nZ <= 16 && (d.gmask & ~groups) == 0 && (!small_has_y(d) || (ony && d.nY <= 64)) && d.nw == 0 && !d.dense_w &&
-           !m.Mblk && !m.Mfull && !(d.flags & (4u | 8u)) && !io.kf_y0m && !io.kf_predict && !io.q_keep && !io.lam_out &&
-           small_lds_bytes(d) <= 64 * 1024;
+    const uint32_t groups = 0xFu | (3u << (2 * P_Y)) | (3u << (2 * P_X));      // box, U, Y, terminal
+    const bool termok = !((d.gmask >> (2 * P_X)) & 3u) || m.exT;               // (terminal tables built by K1)
+    return on && d.nZ <= 16 && (d.gmask & ~groups) == 0 && (!small_has_y(d) || (ony && small_dense_rows_(d) <= 64 && termok)) &&
+           d.nw == 0 && !d.dense_w && !m.Mblk && !m.Mfull && !(d.flags & (4u | 8u)) && !io.kf_y0m && !io.kf_predict && !io.q_keep &&
+           !io.lam_out && small_lds_bytes(d) <= 64 * 1024;
 }
 hipError_t launch_kf_correct(const Dims& d, const Model& m, const KfParams& kf, double* xhat0,
                              const double* y0m, const double* d0, hipStream_t st);

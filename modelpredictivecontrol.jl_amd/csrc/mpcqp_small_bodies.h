@@ -10,8 +10,9 @@
 // src/controller/execute.jl:247-277, 466-505, 536-546; transcription.jl:811-848, 997-1007) for the handles that
 // qualify (small_eligible() in mpcqp_launch.h): constraint groups box (hard ΔU bounds, ϵ >= 0), U (hard or soft
 // input bounds, one merged row per interval and channel with its multiplicity as barrier weight) and -- variant
-// HASY, nY <= 64 -- Y (hard or soft output bounds, any horizon-long pattern with +-Inf holes: setconstraint!(ymin, ymax,
-// Ymin, Ymax, c_ymin, ...), construct.jl:324-509), diagonal weights, no terminal / custom rows.  Dual-regularised Mehrotra
+// HASY, up to 64 dense rows -- Y (hard or soft output bounds, any horizon-long pattern with +-Inf holes: setconstraint!(ymin,
+// ymax, Ymin, Ymax, c_ymin, ...), construct.jl:324-509) and the terminal rows (x̂min, x̂max, c_x̂min, c_x̂max on x̂(k+Hp): the
+// rows ex̂ z of transcription.jl:815-821 appended to the same dense block), diagonal weights, no custom rows.  Dual-regularised Mehrotra
 // predictor-corrector as everywhere else, without the active-set polish.
 //
 // Y rows (HASY): row r = (step t, output a) of  -E z - c0 ϵ <= -Y0min + F,  E z - c1 ϵ <= Y0max - F  belongs to lane r % 16
@@ -30,10 +31,14 @@ constexpr int SMALL_GPW = 4, SMALL_RL = 16, SMALL_KY = 4;      // SMALL_KY: Y-ro
 
 // per group: M(F - R̂y) and F (nY each) and the optimum (16) for the optional Ŷ output; with Y rows the dense E
 // (nY x NX, NX = nZ̃ rounded up to a multiple of four) and two row vectors
-MPCQP_HD inline int small_row_slots(const Dims& d) { return d.nY <= 32 ? 2 : d.nY <= 48 ? 3 : 4; }      // KYS of the Y variant
+// dense rows of the variant with rows: the output-bound rows (nY, when the handle has any) and the terminal rows (nx̂)
+MPCQP_HD inline int small_dense_rows(const Dims& d) {
+    return (((d.gmask >> (2 * P_Y)) & 3u) ? d.nY : 0) + (((d.gmask >> (2 * P_X)) & 3u) ? d.nxh : 0);
+}
+MPCQP_HD inline int small_row_slots(const Dims& d) { const int n = small_dense_rows(d); return n <= 32 ? 2 : n <= 48 ? 3 : 4; }      // KYS
 MPCQP_HD inline size_t small_group_doubles(const Dims& d, bool hasy) {
-    const int NXv = 4 * ((d.nZ + 3) / 4);
-    return (size_t)(2 * d.nY + SMALL_RL) + (hasy ? (size_t)d.nY * NXv + 2 * d.nY + 4 * small_row_slots(d) * SMALL_RL : 0);
+    const int NXv = 4 * ((d.nZ + 3) / 4), nR = small_dense_rows(d);
+    return (size_t)(2 * d.nY + SMALL_RL) + (hasy ? (size_t)nR * NXv + 2 * nR + 4 * small_row_slots(d) * SMALL_RL + d.nxh : 0);
 }
 MPCQP_HD inline size_t small_lds_doubles(const Dims& d, bool hasy = false) { return (size_t)SMALL_GPW * small_group_doubles(d, hasy); }
 
@@ -54,10 +59,14 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     double* cyv = smem + (size_t)g * small_group_doubles(d, HASY);
     double* Fv = cyv + nY;          // F, kept for the optional Ŷ output
     double* zv = Fv + nY;           // the optimum, for the same
-    double* Ed = zv + SMALL_RL;     // (HASY) E[r][c], r < nY, c < NX (the ϵ column and the pad columns are zero)
-    double* dv = Ed + (HASY ? (size_t)nY * NX : 0);      // (HASY) row vector: D̃lo + D̃hi
-    double* wv = dv + (HASY ? nY : 0);                   // (HASY) row vector: multiplier-like values of the rows
-    double* yk = wv + (HASY ? nY : 0) + l;               // (HASY) this lane's row constants [4 KYS][16]: h lower, h upper, c lower, c upper
+    // (HASY) dense rows: the output-bound rows (nYr = nY or 0) followed by the terminal rows ex̂ z (nXr = nx̂ or 0)
+    const int nYr = (HASY && ((d.gmask >> (2 * P_Y)) & 3u)) ? nY : 0, nXr = (HASY && ((d.gmask >> (2 * P_X)) & 3u)) ? nx : 0, nR = nYr + nXr;
+    double* Ed = zv + SMALL_RL;     // (HASY) E[r][c], r < nR, c < NX (the ϵ column and the pad columns are zero)
+    double* dv = Ed + (HASY ? (size_t)nR * NX : 0);      // (HASY) row vector: D̃lo + D̃hi
+    double* wv = dv + (HASY ? nR : 0);                   // (HASY) row vector: multiplier-like values of the rows
+    double* ykb = wv + (HASY ? nR : 0);                  // (HASY) row constants [4 KYS][16] per lane: h lower, h upper, c lower, c upper
+    double* yk = ykb + l;
+    double* fxv = ykb + (HASY ? 4 * KYS * SMALL_RL : 0); // (HASY) terminal free response fx̂ (nx̂)
     const double* x0 = io.xhat0 + (size_t)b * nx;
     const double* lu = io.lastu0 + (size_t)b * nu;
     const double* Stab = m.Stab + (size_t)b * Hp * ny * nu;          // Σ_t [Hp][ny][nu]
@@ -91,14 +100,37 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         }
     }
     if constexpr (HASY) {
-        for (int idx = l; idx < nY * NX; idx += SMALL_RL) {
-            const int r = idx / NX, c = idx - r * NX, t = r / ny, a = r - t * ny;
+        const double* exT = nXr ? m.exT + (size_t)b * Hc * nx * nu : nullptr;          // ex̂ block j: [nx̂][nu]
+        for (int idx = l; idx < nR * NX; idx += SMALL_RL) {
+            const int r = idx / NX, c = idx - r * NX;
             double val = 0.0;
             if (c < nDU) {
-                const int jc = c / nu, cc = c - jc * nu, t0 = jl(jc);
-                if (t0 <= t) val = Stab[((t - t0) * ny + a) * nu + cc];
+                const int jc = c / nu, cc = c - jc * nu;
+                if (r < nYr) {
+                    const int t = r / ny, a = r - t * ny, t0 = jl(jc);
+                    if (t0 <= t) val = Stab[((t - t0) * ny + a) * nu + cc];
+                } else {
+                    val = exT[(jc * nx + (r - nYr)) * nu + cc];
+                }
             }
             Ed[idx] = val;
+        }
+        // terminal free response fx̂ = bx̂ + kx̂ x̂0 + vx̂ lastu0 (+ gx̂ d0 + jx̂ D̂0)  (transcription.jl:815-821; Step::build)
+        for (int i = l; i < nXr; i += SMALL_RL) {
+            const double* kx = m.kxT + (size_t)b * nx * nx;
+            double acc = m.bxv[(size_t)b * nx + i];
+            for (int k = 0; k < nx; ++k) acc += kx[i + nx * k] * x0[k];
+            for (int cc = 0; cc < nu; ++cc) acc += exT[i * nu + cc] * lu[cc];              // block j = 0 is vx̂ (j_0 = 0)
+            if (nd > 0) {
+                const double* Xd = m.Xdtab + (size_t)b * Hp * nx * nd;
+                const double* dd0 = io.d0 + (size_t)b * nd;
+                const double* Dh = io.Dhat0 + (size_t)b * d.nD;
+                for (int q = 0; q < nd; ++q) {
+                    acc += Xd[((Hp - 1) * nx + i) * nd + q] * dd0[q];
+                    for (int j = 1; j < Hp; ++j) acc += Xd[((Hp - j - 1) * nx + i) * nd + q] * Dh[(j - 1) * nd + q];
+                }
+            }
+            fxv[i] = acc;
         }
     }
     w.sync();
@@ -163,14 +195,20 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     mhe::sfor<KYM>([&](auto iq) {
         constexpr int q = decltype(iq)::v;
         const int r = l + SMALL_RL * q;
-        const bool has = HASY && r < nY;
+        const bool has = HASY && r < nR;
         yr[q] = has ? r : 0;
         double h0_ = 2.0 * BIG, h1_ = 2.0 * BIG, c0_ = 0.0, c1_ = 0.0;
-        if (has) {
+        if (has && r < nYr) {
             const size_t o = (size_t)b * nY + r;
             if (m.Y0min) h0_ = -m.Y0min[o] + Fv[r];
             if (m.Y0max) h1_ = m.Y0max[o] - Fv[r];
             if (d.neps) { c0_ = m.C_ymin ? m.C_ymin[o] : 1.0; c1_ = m.C_ymax ? m.C_ymax[o] : 1.0; }
+        } else if (has) {                  // terminal rows  -ex̂ z - c ϵ <= -x̂0min + fx̂,  ex̂ z - c ϵ <= x̂0max - fx̂
+            const int i = r - nYr;
+            const size_t o = (size_t)b * nx + i;
+            if (m.x0min) h0_ = -m.x0min[o] + fxv[i];
+            if (m.x0max) h1_ = m.x0max[o] - fxv[i];
+            if (d.neps) { c0_ = m.c_x0min ? m.c_x0min[o] : 1.0; c1_ = m.c_x0max ? m.c_x0max[o] : 1.0; }
         }
         if constexpr (HASY) {
             yk[(0 * KYM + q) * SMALL_RL] = h0_; yk[(1 * KYM + q) * SMALL_RL] = h1_;
@@ -198,7 +236,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             double se = 0.0;
             mhe::sfor<KYM>([&](auto iq) {
                 constexpr int q = decltype(iq)::v;
-                if (l + SMALL_RL * q < nY) wv[yr[q]] = whi[q] - wlo[q];
+                if (l + SMALL_RL * q < nR) wv[yr[q]] = whi[q] - wlo[q];
                 se += yc0(q) * wlo[q] + yc1(q) * whi[q];
             });
             w.sync();
@@ -206,12 +244,12 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             double acc4[4] = {0.0, 0.0, 0.0, 0.0};
             const double* Ec = Ed + (isvar ? l : 0);
             int r = 0;
-            for (; r + 4 <= nY; r += 4) {
+            for (; r + 4 <= nR; r += 4) {
                 const double e0_ = Ec[r * NX], e1_ = Ec[(r + 1) * NX], e2_ = Ec[(r + 2) * NX], e3_ = Ec[(r + 3) * NX];
                 const double v0_ = wv[r], v1_ = wv[r + 1], v2_ = wv[r + 2], v3_ = wv[r + 3];
                 acc4[0] = fma(e0_, v0_, acc4[0]); acc4[1] = fma(e1_, v1_, acc4[1]); acc4[2] = fma(e2_, v2_, acc4[2]); acc4[3] = fma(e3_, v3_, acc4[3]);
             }
-            for (; r < nY; ++r) acc4[0] = fma(Ec[r * NX], wv[r], acc4[0]);
+            for (; r < nR; ++r) acc4[0] = fma(Ec[r * NX], wv[r], acc4[0]);
             const double acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             const double set = d.neps ? w.rsum(se) : 0.0;
             w.sync();
@@ -374,7 +412,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             mhe::sfor<KYM>([&](auto iq) {
                 constexpr int q = decltype(iq)::v;
                 yd0[q] = rowd(yp0[q], ys0[q], yl0[q]); yd1[q] = rowd(yp1[q], ys1[q], yl1[q]);
-                if (l + SMALL_RL * q < nY) {
+                if (l + SMALL_RL * q < nR) {
                     dv[yr[q]] = yd0[q].Dt + yd1[q].Dt;
                     wv[yr[q]] = yd0[q].Dt * yc0(q) - yd1[q].Dt * yc1(q);
                 }
@@ -390,14 +428,14 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
                 mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = fma(tt, Er[c], Phi[c]); });
             };
             int r = 0;
-            for (; r + 2 <= nY; r += 2) {          // two rows in flight: the loads of both are issued before either update
+            for (; r + 2 <= nR; r += 2) {          // two rows in flight: the loads of both are issued before either update
                 Row Ea, Eb;
                 mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; Eb[c] = Ed[(r + 1) * NX + c]; });
                 const double ela = Ed[r * NX + lc], elb = Ed[(r + 1) * NX + lc], da = dv[r], db = dv[r + 1], wa = wv[r], wb = wv[r + 1];
                 rank1(r, ela, da, wa, Ea);
                 rank1(r + 1, elb, db, wb, Eb);
             }
-            for (; r < nY; ++r) {
+            for (; r < nR; ++r) {
                 Row Ea;
                 mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; });
                 rank1(r, Ed[r * NX + lc], dv[r], wv[r], Ea);

@@ -685,6 +685,13 @@ def small_kernel_cases(lib=None, B=6, with_y=False):
                  con=dict(umin=[-0.25, -0.3], umax=[0.25, 0.3], c_umin=[1.0, 0.5], c_umax=[0.5, 1.0], ymax=[0.1, 0.2, inf],
                           c_ymax=[1.0, 0.3, 1.0], ymin=[-inf, -0.3, -0.2], c_ymin=[1.0, 2.0, 0.0])),
             dict(cfg=synth.Config("ymin-nb", nx=3, nu=1, ny=1, Hp=16, Hc=[2, 2, 4, 8], Cwt=1e4), kw={}, con=dict(ymin=[-0.05], Δumax=[0.3])),
+            # terminal rows (x̂min / x̂max on x̂(k+Hp), setconstraint!, construct.jl:324-509): soft, next to a soft output bound;
+            # and hard terminal rows alone (nx̂ = 3 + 1 states, the output integrator unbounded)
+            dict(cfg=synth.Config("soft-terminal", nx=3, nu=2, ny=2, Hp=10, Hc=4, Cwt=1e4), kw={},
+                 con=dict(umin=[-1.0, -1.0], umax=[1.0, 1.0], ymax=[0.3, inf], x̂min=[-0.05, -0.05, -inf, -inf, -inf],
+                          x̂max=[0.05, inf, 0.08, inf, inf], c_x̂min=[1.0, 0.5, 1.0, 1.0, 1.0], c_x̂max=[2.0, 1.0, 1.0, 1.0, 1.0])),
+            dict(cfg=synth.Config("hard-terminal", nx=3, nu=2, ny=1, Hp=8, Hc=3, Cwt=np.inf), kw={},
+                 con=dict(umin=[-2.0, -2.0], umax=[2.0, 2.0], x̂min=[-0.1, -inf, -0.1, -inf], x̂max=[0.1, 0.1, inf, inf])),
         ]
     for case in cases:
         cfg, con = case["cfg"], case["con"]
@@ -696,7 +703,7 @@ def small_kernel_cases(lib=None, B=6, with_y=False):
         ors = []
         for i in range(B):
             m = cd.LinMPCOracle(bt["Ahat"][i], bt["Bhu"][i], bt["Chat"][i], **mk)
-            m.setconstraint(**{k.replace("Δ", "d"): v for k, v in con.items()})
+            m.setconstraint(**{k.replace("Δ", "d").replace("x̂", "xhat"): v for k, v in con.items()})
             ors.append(m)
         lu = bt["lastu0"].copy()
         mpc.lastu0 = lu.copy()
@@ -718,7 +725,10 @@ def small_kernel_cases(lib=None, B=6, with_y=False):
                     Y0 = m.Et @ z + m.F
                     lo = np.isfinite(m.Y0min) & (np.abs(Y0 - (m.Y0min - m.C_ymin * ze)) <= 1e-7)
                     hi = np.isfinite(m.Y0max) & (np.abs(Y0 - (m.Y0max + m.C_ymax * ze)) <= 1e-7)
-                    nact += int(lo.sum() + hi.sum()); epsmax = max(epsmax, ze)
+                    xe = m.ext @ z + m.fx
+                    lo_x = np.isfinite(m.x0min) & (np.abs(xe - (m.x0min - m.c_xmin * ze)) <= 1e-7)
+                    hi_x = np.isfinite(m.x0max) & (np.abs(xe - (m.x0max + m.c_xmax * ze)) <= 1e-7)
+                    nact += int(lo.sum() + hi.sum() + lo_x.sum() + hi_x.sum()); epsmax = max(epsmax, ze)
                 worst = max(worst, np.abs(mpc.Z[i, :nDU] - z[:nDU]).max() / max(1.0, np.abs(z[:nDU]).max()))
                 if mpc.neps:
                     worst = max(worst, abs(mpc.Z[i, -1] - z[-1]) / max(1.0, abs(z[-1])))

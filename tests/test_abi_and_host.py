@@ -364,11 +364,12 @@ def test_small_problem_kernel_on_cpu_emulator(emulib):
 def test_small_problem_kernel_with_output_bounds_on_cpu_emulator(emulib):
     """The small-problem kernel's variant with output-bound rows (HASY: setconstraint!(ymin, ymax, Ymax, c_ymin, ...),
     construct.jl:324-509) vs the oracle: soft band with an active ϵ, hard horizon-long bound with +-Inf holes, soft y and
-    soft u sharing the slack, ymin with move blocking -- every case on the small kernel, with rows on their bounds."""
+    soft u sharing the slack, ymin with move blocking, soft and hard terminal rows (x̂min / x̂max) -- every case on the small kernel,
+    with rows on their bounds."""
     from tests.parity_util import small_kernel_cases
     worst, kinds, yact = small_kernel_cases(lib=emulib, B=4, with_y=True)
     assert worst <= 1e-6, worst
-    assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
+    assert kinds == [mpcqp.api.KERNEL_SMALL] * 6
     assert all(n > 0 for n, _ in yact) and max(e for _, e in yact) > 1e-3, yact
 
 

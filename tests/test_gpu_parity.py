@@ -743,11 +743,12 @@ def test_small_problem_kernel_on_gpu(hiplib):
 
 def test_small_problem_kernel_with_output_bounds_on_gpu(hiplib):
     """Output-bound rows on the small-problem kernel (k_step_small_y: soft band with an active ϵ, hard horizon-long bound
-    with +-Inf holes, soft y + soft u, ymin with move blocking): every member vs the oracle, rows on their bounds."""
+    with +-Inf holes, soft y + soft u, ymin with move blocking, soft and hard terminal rows): every member vs the oracle, rows on
+    their bounds."""
     from tests.parity_util import small_kernel_cases
     worst, kinds, yact = small_kernel_cases(B=9, with_y=True)
     assert worst <= TOL, worst
-    assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
+    assert kinds == [mpcqp.api.KERNEL_SMALL] * 6
     assert all(n > 0 for n, _ in yact) and max(e for _, e in yact) > 1e-3, yact
 
 
