@@ -32,12 +32,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_SMALL_
     mhe::MheDevWave w{(int)threadIdx.x};
     step_small_body<mhe::MheDevWave, NX, 0>(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
 }
+// the same on a one-wave-per-SIMD register budget (no spills): for grids that leave most of the chip idle anyway -- up to one
+// wavefront per SIMD, i.e. B <= 4096 on 256 CUs, where nothing else would hide the scratch round trips of the spilled registers
+// (B = 1024: 0.116 -> 0.107 ms, B = 4096: 0.14 -> 0.12 ms; from B = 16384 on the two-wave kernel is 25 % faster)
+template <int NX>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8))) void k_step_small_w1(Dims d, Model m, StepIO io) {
+    mhe::MheDevWave w{(int)threadIdx.x};
+    step_small_body<mhe::MheDevWave, NX, 0>(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
+}
 // with output-bound rows: their slacks and multipliers (KYS rows of both sides per lane) want the registers of a
 // whole SIMD lane file, and the dense E in LDS bounds the occupancy anyway: one wave per SIMD
 template <int NX, int KYS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 8))) void k_step_small_y(Dims d, Model m, StepIO io) {
     mhe::MheDevWave w{(int)threadIdx.x};
     step_small_body<mhe::MheDevWave, NX, KYS>(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
+}
+
+// largest grid of the one-wave-per-SIMD variant: one wavefront per SIMD of the device
+static unsigned small_w1_grid() {
+    static const unsigned n = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return (unsigned)prop.multiProcessorCount * 4u;
+        return 1024u;
+    }();
+    return n;
 }
 
 hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
@@ -51,6 +71,8 @@ hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hi
             case 3: MHE_DISPATCH(NXv, hipLaunchKernelGGL((k_step_small_y<NX, 3>), dim3(grid), dim3(WAVE), lds, st, d, m, io)); break;
             default: MHE_DISPATCH(NXv, hipLaunchKernelGGL((k_step_small_y<NX, 4>), dim3(grid), dim3(WAVE), lds, st, d, m, io)); break;
         }
+    } else if (grid <= small_w1_grid()) {
+        MHE_DISPATCH(NXv, hipLaunchKernelGGL(k_step_small_w1<NX>, dim3(grid), dim3(WAVE), lds, st, d, m, io));
     } else {
         MHE_DISPATCH(NXv, hipLaunchKernelGGL(k_step_small<NX>, dim3(grid), dim3(WAVE), lds, st, d, m, io));
     }
