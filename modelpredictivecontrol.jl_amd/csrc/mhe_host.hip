@@ -232,7 +232,7 @@ int mpcqp_mhe_set_bounds(mpcqp_mhe h, const double* xmin, const double* xmax, co
             *dst[k] = nullptr;
         }
     }
-    d.cls = cls | (d.cls & mhe::CLS_S);
+    d.cls = cls | (d.cls & (mhe::CLS_S | mhe::CLS_C));     // (the softness set earlier stays: CLS_C says its arrays are window-long)
     return MPCQP_OK;
 }
 
@@ -270,7 +270,7 @@ int mpcqp_mhe_set_bounds_window(mpcqp_mhe h, const double* Xmin, const double* X
             *dst[k] = nullptr;
         }
     }
-    d.cls = cls | (d.cls & mhe::CLS_S) | mhe::CLS_L;
+    d.cls = cls | (d.cls & (mhe::CLS_S | mhe::CLS_C)) | mhe::CLS_L;
     return MPCQP_OK;
 }
 

@@ -609,11 +609,11 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
         io.prof = (double*)h->prof.p;
     }
 #endif
+    // (refusals first: nothing is recorded on the stream for a step that does not run)
+    if (uses_stage_kernel(h) && (ms_unsupported(h) || y0m || predict)) return MPCQP_ERR_UNSUPPORTED;
     HIPCHK(hipEventRecord(h->ev_s0, st));
     if (uses_stage_kernel(h)) {
         // the stage-structured kernel: model as equality constraints, Riccati recursion, H~ and E never formed
-        const int why = ms_unsupported(h);
-        if (why || y0m || predict) return MPCQP_ERR_UNSUPPORTED;
         MsIO ms{};
         int rc = dev_alloc(h, h->ms_X, (size_t)d.B * d.nxh * d.Hp * sizeof(double));
         if (!rc) rc = dev_alloc(h, h->ms_defect, (size_t)d.B * sizeof(double));
@@ -971,8 +971,9 @@ int mpcqp_prepare(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
     g_build_err.clear();
     if (uses_stage_kernel(h)) {
-        if (!ms_unsupported(h)) return MPCQP_KERNEL_MS;            // nothing to build: the stage-structured kernel is in the library
-        if (h->stage_only || h->stage_rows) return MPCQP_ERR_UNSUPPORTED;
+        // nothing to build: the stage-structured kernel is in the library.  A handle it cannot take is refused here exactly
+        // as its steps are (mpcqp_step*: MPCQP_ERR_UNSUPPORTED) -- the answer is what the steps WILL do
+        return ms_unsupported(h) ? MPCQP_ERR_UNSUPPORTED : MPCQP_KERNEL_MS;
     }
     int kind = prepare_step(h->d, h->m, &g_build_err);
     // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
@@ -1021,7 +1022,7 @@ int mpcqp_lds_bytes(mpcqp_handle h) {
 
 int mpcqp_kernel_kind(mpcqp_handle h) {
     if (!h) return MPCQP_ERR_NULL;
-    if (uses_stage_kernel(h) && !ms_unsupported(h)) return MPCQP_KERNEL_MS;
+    if (uses_stage_kernel(h)) return ms_unsupported(h) ? MPCQP_ERR_UNSUPPORTED : MPCQP_KERNEL_MS;
     return step_kernel_kind(h->d, h->m);
 }
 

@@ -4,6 +4,9 @@
 //   k_ms_step_g  the model and the work matrices of a stage in LDS, the horizon-long data in a per-wavefront scratch in
 //                HBM (L2-resident for the stage in flight); persistent grid of `nslots` wavefronts looping over the batch,
 //                so the scratch is nslots x big doubles whatever B -- any horizon, eight wavefronts per CU.
+#include <map>
+#include <mutex>
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include "mpcqp_bodies.h"
@@ -45,18 +48,29 @@ size_t ms_lds_bytes(const Dims& d, const Model& m) { return (size_t)make_ms_carv
 size_t ms_scratch_bytes(const Dims& d, const Model& m, int* nslots) {
     const MsCarve c = make_ms_carve(d, m);
     if (c.big_in_lds) { if (nslots) *nslots = 0; return 0; }
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     const size_t lds = (size_t)c.small * sizeof(double);
     // resident wavefronts per CU: what the runtime says for this kernel and this much LDS (registers, LDS allocation
     // granularity).  A persistent grid larger than that runs its surplus workgroups as a SECOND round (measured: 2048
-    // launched where 1792 fit cost 2x).
-    int per_cu = 0;
-    if (ensure_lds((const void*)k_ms_step_g, lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_step_g, WAVE, lds) != hipSuccess || per_cu < 1) {
-        per_cu = (int)((160 * 1024) / (lds ? lds : 1));
-        per_cu = per_cu > 8 ? 8 : per_cu < 1 ? 1 : per_cu;
+    // launched where 1792 fit cost 2x).  The answer depends on (device, LDS bytes) only: asked once, then remembered,
+    // so that a step does no runtime queries.
+    int dev = 0, cus = 256, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    {
+        static std::mutex mu;
+        static std::map<std::pair<int, size_t>, std::pair<int, int>> seen;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = seen.find({dev, lds});
+        if (it == seen.end()) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (ensure_lds((const void*)k_ms_step_g, lds) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_ms_step_g, WAVE, lds) != hipSuccess || per_cu < 1) {
+                per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+                per_cu = per_cu > 8 ? 8 : per_cu < 1 ? 1 : per_cu;
+            }
+            it = seen.emplace(std::make_pair(dev, lds), std::make_pair(cus, per_cu)).first;
+        }
+        cus = it->second.first; per_cu = it->second.second;
     }
     int n = cus * per_cu;
     if (n > d.B) n = d.B;

@@ -77,7 +77,17 @@ def ipm(H, q, G, h, z0=None, mu_tol=1e-14, res_tol=1e-10, maxit=200):
     def newton(s, lam, rd, rp, rc):
         # H dz + G'dl = -rd ; G dz + ds = -rp ; lam ds + s dl = -rc   (ds eliminated)
         K[idx, idx] = -s / lam
-        sol = np.linalg.solve(K, np.concatenate([-rd, -rp + rc / lam]))
+        rhs = np.concatenate([-rd, -rp + rc / lam])
+        try:
+            sol = np.linalg.solve(K, rhs)
+        except np.linalg.LinAlgError:
+            # s/lam underflows to ~1e-20 on more active rows than variables (a degenerate vertex reached with mu ~ 1e-9):
+            # the KKT matrix is then singular in float64 although the iterate is an optimum to 1e-9.  A dual
+            # regularisation of 1e-13 -- the same device as the kernels' delta -- makes the system solvable; it multiplies
+            # dlam, which vanishes at the optimum.  (Met by tests/parity_util.offset_tables_case, member 1: a terminal
+            # bound violated by 3.5 at the start, 12 iterations to mu = 1e-9, then LinAlgError.)
+            K[idx, idx] = -s / lam - 1e-13
+            sol = np.linalg.solve(K, rhs)
         dz, dl = sol[:n], sol[n:]
         ds = -rp - G @ dz
         return dz, ds, dl

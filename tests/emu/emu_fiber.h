@@ -87,6 +87,21 @@ private:
     int cur_ = 0, done_ = 0;
 };
 
+// The fibers run in the order 0..63 between barriers; which LANE a fiber plays is a permutation chosen by
+// MPCQP_EMU_LANE_ORDER (unset / "forward": identity, "reverse": 63 - i, "random": a fixed pseudo-random permutation), so
+// that a missing w.sync() where one lane reads what another wrote in the same section shows up in at least one order
+// (with the identity alone a read of a LOWER lane's fresh value always passed).
+inline void emu_lane_order(int* perm) {
+    for (int i = 0; i < 64; ++i) perm[i] = i;
+    if (const char* o = getenv("MPCQP_EMU_LANE_ORDER")) {
+        if (o[0] == 'r' && o[1] == 'e') { for (int i = 0; i < 64; ++i) perm[i] = 63 - i; }
+        else if (o[0] == 'r' && o[1] == 'a') {
+            unsigned x = 2463534242u;
+            for (int i = 63; i > 0; --i) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; const int j = (int)(x % (unsigned)(i + 1)); const int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+        }
+    }
+}
+
 // the fibers of this host thread (stacks are mapped once)
 inline LaneFibers& lane_fibers() { static thread_local LaneFibers f; return f; }
 

@@ -109,8 +109,10 @@ static void run_waves(int nwaves, size_t lds_doubles, F body) {
                 last = mx;
             }
         });
-    sh.bar.run([&](int lane) {
-        EmuWave w{lane, &sh};
+    int perm[64];
+    emu_lane_order(perm);
+    sh.bar.run([&](int fiber) {
+        EmuWave w{perm[fiber], &sh};
         for (int wv = 0; wv < nwaves; ++wv) {
             body(w, wv, smem.data());
             w.sync();

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: the CPU "wavefront" of the emulator -- one cooperative fiber per lane (emu_fiber.h), a barrier for
 // every wave-level operation.  Shared by emu_launch.cpp and emu_ms.cpp.
 #pragma once
+#include <cstdlib>
 #include <vector>
 
 #include "emu_fiber.h"
@@ -77,8 +78,10 @@ template <class F>
 inline void run_waves(int B, size_t lds_doubles, F body) {
     std::vector<double> smem(lds_doubles + 16, 0.0);
     EmuShared sh;
-    sh.bar.run([&](int lane) {
-        EmuWave w{lane, &sh};
+    int perm[64];
+    emu_lane_order(perm);
+    sh.bar.run([&](int fiber) {
+        EmuWave w{perm[fiber], &sh};
         for (int b = 0; b < B; ++b) {
             body(w, b, smem.data());
             w.sync();

@@ -333,7 +333,7 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, k
     def decide(key, value):                 # member 0 decides, the others follow
         return fam.setdefault(key, value)
 
-    def member(rg):
+    def member(rg, idx=0):
         lam = rg.uniform(0.3, 0.97, nx)
         Q, _ = np.linalg.qr(rg.standard_normal((nx, nx)))
         A = Q @ np.diag(lam) @ Q.T
@@ -341,6 +341,12 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, k
         Bd = rg.standard_normal((nx, nd)); Dd = 0.3 * rg.standard_normal((ny, nd))
         model = es.LinModelOracle(A, Bu, C, Bd, Dd).setop(uop=0.2 * rg.standard_normal(nu),
                                                           yop=rg.standard_normal(ny), dop=0.3 * rg.standard_normal(nd))
+        if seed % 2 == 0:
+            # a linearisation point that is NOT an equilibrium: f̂op ≠ x̂op, per member (the successive-linearisation use,
+            # docs/src/manual/nonlinmpc.md:501) -- B = [Ĉ S(t)](f̂op − x̂op) and bx̂ of init_predmat (transcription.jl:184-192)
+            # are then non-zero.  Drawn from a generator of its own: the other draws of the family stay what they were.
+            r2 = np.random.default_rng([777, seed, idx])
+            model.setop(xop=0.3 * r2.standard_normal(nx), fop=0.3 * r2.standard_normal(nx))
         kf = es.SteadyKalmanFilterOracle(model)
         soft = decide("soft", bool(rg.random() < 0.75))
         Mw, Nw = rg.uniform(0.5, 2.0, ny), rg.uniform(0.02, 0.3, nu)
@@ -374,7 +380,7 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, k
         orc.lastu0 = u_prev - model.uop
         return dict(model=model, kf=kf, orc=orc, kw=kw, con=con, x0=x0, u_prev=u_prev, rg=rg)
 
-    mem = [member(rng)] + [member(np.random.default_rng([1000 + seed, i])) for i in range(1, B)]
+    mem = [member(rng)] + [member(np.random.default_rng([1000 + seed, i]), i) for i in range(1, B)]
     st = lambda f: np.stack([f(m) for m in mem])
     nxh = mem[0]["kf"].nxh
     gpu = mpcqp.BatchLinMPC(st(lambda m: m["kf"].Ah), st(lambda m: m["kf"].Bhu), st(lambda m: m["kf"].Ch),
@@ -414,10 +420,59 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, k
                 stop = True               # with, and the two loops would part ways from here on
                 break
             uo = orc.moveinput(m["x0"], m["ry"], m["d"], Dhat=m["Dhat"])
-            m["x0"] = m["kf"].Ah @ m["x0"] + m["kf"].Bhu @ (uo - model.uop)
+            m["x0"] = m["kf"].Ah @ m["x0"] + m["kf"].Bhu @ (uo - model.uop) + m["kf"].fhop - m["kf"].xhop
         if stop:
             break
     return worst
+
+
+def offset_tables_case(lib=None, nx=3, nu=2, ny=2, Hp=7, Hc=3, B=3, seed=11):
+    """init_predmat with f̂op ≠ x̂op (transcription.jl:184-192: B = [Ĉ S(t)](f̂op − x̂op), bx̂ = S(Hp−1)(f̂op − x̂op)), one
+    offset per member: the B table read back through MPCQP_GET_BVEC, the free response F (execute.jl:248-255) through
+    MPCQP_GET_FVEC, and -- with a terminal bound, whose right-hand side carries bx̂ -- the optimum, each against the dense
+    restatement.  Returns (worst |B − B_oracle|, worst |F − F_oracle|, worst relative ΔU error, worst |B_oracle|)."""
+    from oracle import estim as es
+    mem = []
+    for i in range(B):
+        rg = np.random.default_rng([seed, i])
+        lam = rg.uniform(0.4, 0.95, nx)
+        Q, _ = np.linalg.qr(rg.standard_normal((nx, nx)))
+        A = Q @ np.diag(lam) @ Q.T
+        model = es.LinModelOracle(A, rg.standard_normal((nx, nu)) / np.sqrt(nx), rg.standard_normal((ny, nx)) / np.sqrt(nx),
+                                  np.zeros((nx, 0)), np.zeros((ny, 0)))
+        model.setop(uop=0.2 * rg.standard_normal(nu), yop=rg.standard_normal(ny),
+                    xop=0.5 * rg.standard_normal(nx), fop=0.5 * rg.standard_normal(nx))
+        kf = es.SteadyKalmanFilterOracle(model)
+        kw = dict(Hp=Hp, Hc=Hc, Mwt=rg.uniform(0.5, 2.0, ny), Nwt=rg.uniform(0.05, 0.3, nu), Lwt=np.zeros(nu), Cwt=1e4,
+                  uop=model.uop, yop=model.yop, dop=model.dop, xhop=kf.xhop, fhop=kf.fhop)
+        orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
+        xm = np.full(kf.nxh, np.inf); xm[0] = 0.3
+        con = dict(umin=model.uop - 0.8, umax=model.uop + 0.8, xhatmax=kf.xhop + xm)
+        orc.setconstraint(**con)
+        u_prev = model.uop + 0.1 * rg.standard_normal(nu)
+        orc.lastu0 = u_prev - model.uop
+        mem.append(dict(model=model, kf=kf, orc=orc, kw=kw, con=con, x0=0.5 * rg.standard_normal(kf.nxh), u_prev=u_prev,
+                        ry=model.yop + rg.standard_normal(ny)))
+    st = lambda f: np.stack([f(m) for m in mem])
+    gpu = mpcqp.BatchLinMPC(st(lambda m: m["kf"].Ah), st(lambda m: m["kf"].Bhu), st(lambda m: m["kf"].Ch), lib=lib, Hp=Hp, Hc=Hc,
+                            Mwt=st(lambda m: m["kw"]["Mwt"]), Nwt=st(lambda m: m["kw"]["Nwt"]), Lwt=st(lambda m: m["kw"]["Lwt"]),
+                            Cwt=1e4, uop=st(lambda m: m["model"].uop), yop=st(lambda m: m["model"].yop),
+                            xhop=st(lambda m: m["kf"].xhop), fhop=st(lambda m: m["kf"].fhop), keep_qp=True)
+    gpu.setconstraint(umin=st(lambda m: m["con"]["umin"]), umax=st(lambda m: m["con"]["umax"]),
+                      **{"x̂max": st(lambda m: m["con"]["xhatmax"])})
+    gpu.initstate(st(lambda m: m["u_prev"]))
+    gpu.moveinput(st(lambda m: m["x0"]), st(lambda m: m["ry"]))
+    Bv, F = gpu.hd.get(mpcqp.GET_BVEC), gpu.hd.get(mpcqp.GET_FVEC)
+    eB = eF = eZ = bmax = 0.0
+    for i, m in enumerate(mem):
+        orc, model = m["orc"], m["model"]
+        orc.initpred(m["x0"], orc.lastu0 + model.uop, m["ry"], None, None); orc.linconstraint()
+        z, sto, info = qp.solve_qp(*orc.qp_data(), orc.warmstart(), return_info=True)
+        assert sto == 0 and gpu.status[i] == 0, (i, sto, gpu.status)
+        eB = max(eB, np.abs(Bv[i] - orc.B).max()); bmax = max(bmax, np.abs(orc.B).max())
+        eF = max(eF, np.abs(F[i] - orc.F).max())
+        eZ = max(eZ, rel_err(gpu.Z[i:i + 1], z[None, :], orc.nDU).max())
+    return eB, eF, eZ, bmax
 
 
 def run_random_case2(seed, lib=None, B=2, small=False, kinds=None):

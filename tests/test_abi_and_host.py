@@ -268,6 +268,15 @@ def test_random_controller_families_on_cpu_emulator(seed, emulib):
     assert e is not None and e <= 1e-5
 
 
+def test_prediction_offset_table_with_fop_different_from_xop_on_cpu_emulator(emulib):
+    """f̂op ≠ x̂op (a linearisation point that is not an equilibrium): B and bx̂ of init_predmat (transcription.jl:184-192),
+    read back through MPCQP_GET_BVEC / _FVEC and through the optimum of a controller with a terminal bound."""
+    from tests.parity_util import offset_tables_case
+    eB, eF, eZ, bmax = offset_tables_case(lib=emulib)
+    assert bmax > 0.05                                  # the table is not trivially zero
+    assert eB <= 1e-12 * max(1.0, bmax) and eF <= 1e-11 and eZ <= 1e-6, (eB, eF, eZ)
+
+
 def test_fused_loop_equals_separate_steps_on_cpu_emulator(emulib):
     """mpcqp_loop_device: Kalman correction, moveinput! and Kalman prediction in one launch."""
     from tests.parity_util import fused_loop_vs_separate_steps

@@ -70,14 +70,18 @@ def test_transcriptions_agree_on_C3(hiplib):
     assert out["SingleShooting"][2] == api.KERNEL_AOT and out["MultipleShooting"][2] == api.KERNEL_MS
     st_ss, st_ms = out["SingleShooting"][3], out["MultipleShooting"][3]
     assert np.all(st_ss == 0) and np.all(st_ms != api.STATUS_ERROR)
-    # C3 is a heavily constrained workload (59 % of the input rows on a bound, multipliers of 1e5 on the soft rows): the
-    # stage-structured kernel (no active-set polish) leaves about one controller in a thousand at its iteration limit --
-    # flagged, like the reference's @warn branch -- and every solve it calls OPTIMAL agrees with the condensed kernel
+    # C3 is a heavily constrained workload (59 % of the input rows on a bound, multipliers of 1e5 on the soft rows).  The
+    # stage-structured kernel (interior point + its own active-set polish since round 4) may leave a controller at its
+    # iteration limit where the condensed kernel converges (3 of 8192 in the bench batch): such a solve is FLAGGED
+    # (status 1, the reference's @warn branch keeps the iterate, execute.jl:491-496) and is adjudicated here against the
+    # condensed optimum -- the kept iterate must still be that optimum to 1e-3; every solve called OPTIMAL agrees to TOL.
     ok = st_ms == 0
-    assert ok.mean() >= 0.99, ok.mean()
+    assert ok.mean() >= 0.995, ok.mean()
     nDU = cfg.nu * cfg.Hc
     assert rel_err(out["MultipleShooting"][0][ok], out["SingleShooting"][0][ok], nDU).max() <= TOL
     assert np.abs(out["MultipleShooting"][1][ok] - out["SingleShooting"][1][ok]).max() <= 1e-4
+    if not ok.all():
+        assert rel_err(out["MultipleShooting"][0][~ok], out["SingleShooting"][0][~ok], nDU).max() <= 1e-3
 
 
 def test_multiple_shooting_known_answers_run_on_the_ms_kernel(hiplib):

@@ -55,6 +55,19 @@ def test_condensation_tables_match_oracle(name, B, hiplib):
         assert np.abs(q[i] - m.qt).max() <= 1e-11 * max(1.0, np.abs(m.qt).max())
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 2, 7, 3), (12, 4, 4, 30, 10), (5, 3, 2, 12, 12)])
+def test_prediction_offset_table_with_fop_different_from_xop(shape, hiplib):
+    """f̂op ≠ x̂op, one offset per member (successive linearisation, docs/src/manual/nonlinmpc.md:501): B = [Ĉ S(t)](f̂op − x̂op)
+    and bx̂ of init_predmat (transcription.jl:184-192) -- MPCQP_GET_BVEC and the free response F directly, bx̂ through the
+    optimum of a controller with a terminal bound.  (3, ..) and (5, ..) take the LDS form of K1, (12, ..) = C3's sizes
+    (nx̂ = 16) the matrix-core form."""
+    from tests.parity_util import offset_tables_case
+    nx, nu, ny, Hp, Hc = shape
+    eB, eF, eZ, bmax = offset_tables_case(nx=nx, nu=nu, ny=ny, Hp=Hp, Hc=Hc, B=5)
+    assert bmax > 0.05
+    assert eB <= 1e-12 * max(1.0, bmax) and eF <= 1e-11 * max(1.0, bmax) and eZ <= TOL, (eB, eF, eZ)
+
+
 @pytest.mark.parametrize("name,B,seed", [("C2", 1024, 0), ("C3", 256, 0), ("C3", 256, 7)])
 def test_step_matches_oracle(name, B, seed, hiplib):
     """Full moveinput! (a11-a15) on BASELINE configs[1] (full size) and configs[2] (sampled)."""

@@ -220,6 +220,15 @@ def test_window_long_softness_on_emulator(emulib):
     assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
 
 
+def test_window_long_softness_survives_a_bound_reupload_on_emulator(emulib):
+    """BatchMHE.setmodel() re-uploads the bounds after C_x̂min ... were set: the window-long softness must stay in force
+    (mpcqp_mhe_set_bounds / _window keep CLS_C), same answers as without the call."""
+    eps = []
+    ex, ew, active = mhe_util.window_long_bounds(lib=emulib, B=2, nper=9, csoft=True, eps_seen=eps, noop_setmodel=True)
+    assert active > 0 and max(eps) > 1e-6, (active, eps)
+    assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
+
+
 def test_reference_setmodel_through_the_product_on_emulator(emulib):
     """setmodel!(::MovingHorizonEstimator, model), test/2_test_state_estim.jl:1668-1718, through BatchMHE.setmodel
     (mpcqp_mhe_set_model + mpcqp_mhe_shift_windows)."""
