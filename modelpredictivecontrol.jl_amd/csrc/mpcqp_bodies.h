@@ -29,9 +29,27 @@
 #if defined(MPCQP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define MPCQP_TIC() const long long tic_ = clock64()
 #define MPCQP_TOC(i) prof_[i] += (double)(clock64() - tic_)
+#define MPCQP_TICK(name) const long long name = clock64()
+#define MPCQP_TOCK(i, name) prof_[i] += (double)(clock64() - name)
+#elif defined(MPCQP_ISA_MARKERS) && defined(__HIP_DEVICE_COMPILE__)
+// Phase boundaries as comments in the device assembly (plus a scheduling barrier, so that no instruction crosses them):
+// scripts/isa_phase_table.py attributes every instruction of the interior-point loop to its phase and class.
+#define MPCQP_MARK_(txt) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MPCQP_MARK " txt ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPCQP_TIC() MPCQP_MARK_("tic")
+#define MPCQP_TOC(i) MPCQP_MARK_("toc " #i)
+#define MPCQP_TICK(name) MPCQP_MARK_("tic " #name)
+#define MPCQP_TOCK(i, name) MPCQP_MARK_("toc " #i)
+#define MPCQP_MTIC() MPCQP_MARK_("tic")
+#define MPCQP_MTOC(name) MPCQP_MARK_("toc " name)
 #else
 #define MPCQP_TIC() ((void)0)
 #define MPCQP_TOC(i) ((void)0)
+#define MPCQP_TICK(name) ((void)0)
+#define MPCQP_TOCK(i, name) ((void)0)
+#endif
+#ifndef MPCQP_MTIC
+#define MPCQP_MTIC() ((void)0)      // regions that only exist for the assembly markers (MPCQP_ISA_MARKERS)
+#define MPCQP_MTOC(name) ((void)0)
 #endif
 
 #ifndef MPCQP_POLISH_FACTS
@@ -55,6 +73,9 @@
 #endif
 #ifndef MPCQP_CHOL_INVD
 #define MPCQP_CHOL_INVD 0         // how 1/L_kk reaches lane k: 0 select, 1 LDS vector written by lane 0, 2 by every lane
+#endif
+#ifndef MPCQP_CHOL_RMW_BATCH
+#define MPCQP_CHOL_RMW_BATCH 1    // read-modify-writes of the in-panel update / the U rows: all reads first, then all writes
 #endif
 #ifndef MPCQP_SOLVE_DPP
 #define MPCQP_SOLVE_DPP 1         // triangular solves of the specialised kernels blocked by DPP rows (Step::solve_static)
@@ -195,9 +216,11 @@ struct StaticDims {
     int B, nd, nD, max_iter;
     double gap_tol, res_tol, dual_reg;
     uint32_t flags;
-    MPCQP_HD static constexpr int cnt(int p) {
+    MPCQP_HD static constexpr int eps_host() { return eps_host_group(GMASK, NEPS); }
+    MPCQP_HD static constexpr int len(int p) {
         return p == P_BOX ? nZ : p == P_U ? nDU : p == P_DU ? nDU : p == P_Y ? nY : p == P_X ? nxh : p == P_W ? nW : 0;
     }
+    MPCQP_HD static constexpr int cnt(int p) { return len(p) + ((p == P_Y && eps_host() >= 0) ? 1 : 0); }
     MPCQP_HD static constexpr int rowoff(int g) {
         int o = 0;
         for (int i = 0; i < g; ++i)
@@ -1379,12 +1402,13 @@ struct Step {
             case 2 * P_W + 1: p = m.C_wmax; def = 1.0; break;
             default: return 0.0;
         }
+        if ((g >> 1) == P_Y && k >= d.nY) return 1.0;      // the hosted row -eps <= 0 (eps_host_group)
         if (!p) return def;
         if ((g >> 1) == P_U) {       // one row per (block, channel): softness of the block's first step
             const int j = k / d.nu, cc = k - j * d.nu;
             return p[(size_t)b * d.nU + qp.jl(j) * d.nu + cc];
         }
-        return p[(size_t)b * d.cnt(g >> 1) + k];
+        return p[(size_t)b * d.len(g >> 1) + k];
     }
 
     // Multiplicity of a row in the barrier.  The U rows of one move-blocking interval are merged
@@ -1620,9 +1644,10 @@ struct Step {
         double hmax = 0.0, wacc = 0.0;
         for_rows([&](int g, int k, Row& r) {
             double bound = INFINITY;
-            const size_t o = (size_t)b * d.cnt(g >> 1) + k;
+            const size_t o = (size_t)b * d.len(g >> 1) + k;
+            const bool hosted = (g >> 1) == P_Y && k >= d.nY;      // the row -eps <= 0 riding in a Ŷ group: bound 0 in its host, absent in the other
             switch (g) {
-                case 0: bound = -zlo[k]; break;
+                case 0: bound = (k == d.nZ - 1 && d.neps && d.eps_host() >= 0) ? INFINITY : -zlo[k]; break;
                 case 1: bound = zhi[k]; break;
                 case 2 * P_U:
                 case 2 * P_U + 1: {
@@ -1648,8 +1673,8 @@ struct Step {
                 case 2 * P_DU + 1:
                     if (m.DUmax && m.C_dumax && m.C_dumax[o] != 0.0) bound = m.DUmax[o];
                     break;
-                case 2 * P_Y: if (m.Y0min) bound = -m.Y0min[o] + F[k]; break;
-                case 2 * P_Y + 1: if (m.Y0max) bound = m.Y0max[o] - F[k]; break;
+                case 2 * P_Y: if (hosted) bound = (g == d.eps_host()) ? 0.0 : INFINITY; else if (m.Y0min) bound = -m.Y0min[o] + F[k]; break;
+                case 2 * P_Y + 1: if (hosted) bound = (g == d.eps_host()) ? 0.0 : INFINITY; else if (m.Y0max) bound = m.Y0max[o] - F[k]; break;
                 case 2 * P_X: if (m.x0min) bound = -m.x0min[o] + fx[k]; break;
                 case 2 * P_X + 1: if (m.x0max) bound = m.x0max[o] - fx[k]; break;
                 case 2 * P_W: if (m.Wmin) bound = -m.Wmin[o] + Fw_at(k, io, x0, lu); break;
@@ -1705,7 +1730,7 @@ struct Step {
     // ---- primitives of G v: ucum (held cumulative sum), tY = E v, tX = ex̂ v ------------------
     MPCQP_HD void primitives(const double* v) {
         const int nu = d.nu;
-        const long long tic11_ = clock64_();
+        MPCQP_TICK(tic11_);
         if (qp.pair_on(P_U) || qp.pair_on(P_W)) {
             double* ucum = sm + c.ucum;
             if (d.nDU <= WAVE) {
@@ -1715,11 +1740,11 @@ struct Step {
                 block_scan(v, ucum, false);
             }
         }
-        prof_[11] += (double)(clock64_() - tic11_);
-        const long long tic12_ = clock64_();
+        MPCQP_TOCK(11, tic11_);
+        MPCQP_TICK(tic12_);
         if (!(MPCQP_ABLATE & 8))
         if (qp.pair_on(P_Y) || qp.pair_on(P_W)) qp.E_apply(v, sm + c.tA[P_Y]);
-        prof_[12] += (double)(clock64_() - tic12_);
+        MPCQP_TOCK(12, tic12_);
         if (qp.pair_on(P_X)) {
             double* tX = sm + c.tA[P_X];
             for (int i = w.lane; i < d.nxh; i += WAVE) {
@@ -1736,7 +1761,7 @@ struct Step {
             case P_BOX: return v[k];
             case P_U: return sm[c.ucum + k];
             case P_DU: return v[k];
-            case P_Y: return sm[c.tA[P_Y] + k];
+            case P_Y: return (d.eps_host() >= 0 && k >= d.nY) ? 0.0 : sm[c.tA[P_Y] + k];      // (hosted row -eps <= 0: its row of E is zero)
             case P_W: {
                 if constexpr (!has_w<DM>()) return 0.0;
                 else {
@@ -1774,7 +1799,7 @@ struct Step {
     MPCQP_HD void apply_Gt(Fn wv) {
         MPCQP_RELANE(6);
         MPCQP_TIC();
-        const long long tic_gt_ = clock64_();
+        MPCQP_TICK(tic_gt_);
         const int nu = d.nu;
         // per pair: tA[k] = w_max - w_min ; eps accumulates -(c_min w_min + c_max w_max)
         double eacc = 0.0;
@@ -1793,8 +1818,8 @@ struct Step {
                 useY = useU = true;
             }
         }
-        prof_[8] += (double)(clock64_() - tic_gt_);
-        const long long tic9_ = clock64_();
+        MPCQP_TOCK(8, tic_gt_);
+        MPCQP_TICK(tic9_);
         double sufU = 0.0;
         if (useU && d.nDU <= WAVE) sufU = qp.block_suffix(w.lane < d.nDU ? sm[c.tA[P_U] + w.lane] : 0.0);
         else if (useU) block_scan(sm + c.tA[P_U], sm + c.tA[P_U], true);       // (tA[P_U] is consumed here: in place)
@@ -1814,11 +1839,11 @@ struct Step {
             }
             gt[k] = acc;
         }
-        prof_[9] += (double)(clock64_() - tic9_);
-        const long long tic10_ = clock64_();
+        MPCQP_TOCK(9, tic9_);
+        MPCQP_TICK(tic10_);
         if (useY && !(MPCQP_ABLATE & 16)) qp.Et_apply_add(sm + c.tA[P_Y], gt);   // same lane owns gt[k]
         w.sync();
-        prof_[10] += (double)(clock64_() - tic10_);
+        MPCQP_TOCK(10, tic10_);
         MPCQP_TOC(1);
     }
 
@@ -1877,7 +1902,7 @@ struct Step {
             w.sync();      // the MFMA write-back uses its own entry->lane map
             MPCQP_TOC(4);
         }
-        const long long tic5_ = clock64_();
+        MPCQP_TICK(tic5_);
         // U rows: Pu' dU Pu has entry ((j,c),(j',c)) = sum_{jj >= max(j,j')} dU[jj,c]: lane (j,c)
         // forms its suffix sum once and adds it along its own row of the lower triangle
         if (qp.pair_on(P_U) && nDU <= WAVE && !(MPCQP_ABLATE & 64)) {
@@ -1890,11 +1915,24 @@ struct Step {
             double* const trash = sm + c.zero + 4;
             double* const row = Phi + pk(k, cc);
             if constexpr (DM::is_static) {
+#if MPCQP_CHOL_RMW_BATCH
+                // all reads, then all writes (entry by entry the trash slot's possible aliasing serialises Hc LDS round trips)
+                double* q_[DM::Hc];
+                double old_[DM::Hc];
+                MPCQP_UNROLL
+                for (int j2 = 0; j2 < DM::Hc; ++j2) {
+                    q_[j2] = (j2 <= j && w.lane < nDU) ? row + j2 * nu : trash;
+                    old_[j2] = *q_[j2];
+                }
+                MPCQP_UNROLL
+                for (int j2 = 0; j2 < DM::Hc; ++j2) *q_[j2] = old_[j2] + suf;
+#else
                 MPCQP_UNROLL
                 for (int j2 = 0; j2 < d.Hc; ++j2) {
                     double* const q_ = (j2 <= j && w.lane < nDU) ? row + j2 * nu : trash;
                     *q_ += suf;
                 }
+#endif
             } else {
                 for (int j2 = 0; j2 < d.Hc; ++j2) {
                     double* const q_ = (j2 <= j && w.lane < nDU) ? row + j2 * nu : trash;
@@ -1976,7 +2014,7 @@ struct Step {
             for (int k = w.lane; k < nDU; k += WAVE) Phi[pk(nZ - 1, k)] += st[k];
         }
         w.sync();
-        prof_[5] += (double)(clock64_() - tic5_);
+        MPCQP_TOCK(5, tic5_);
     }
 
     MPCQP_HD static long long clock64_() {
@@ -2078,6 +2116,33 @@ struct Step {
             x[T] = Phi[pk(row, 0) + K0 + lk];
         }
         double* const trash = sm + c.zero + 4;
+#if MPCQP_CHOL_RMW_BATCH
+        // Every entry to be updated is requested BEFORE the matrix-core instructions are issued and written after them:
+        // written as `*q -= acc[r]` entry by entry, the possible aliasing of the trash slot made each read-modify-write
+        // wait for the one before it (ds_read, s_waitcnt lgkmcnt(0), v_add, ds_write: 49 dependent LDS round trips per
+        // factorisation at C3, ~100 cycles each, on the critical path of the pivot chain).
+        double* q_[NT][4];
+        double old_[NT][4];
+        MPCQP_UNROLL
+        for (int T = P; T < NT; ++T) {
+            MPCQP_UNROLL
+            for (int r = Bk + 1; r < 4; ++r) {
+                if (16 * P + 4 * r >= n) continue;
+                const int row = 16 * T + li, col = 16 * P + 4 * r + lk;
+                q_[T][r] = (row < n && col <= row) ? Phi + pk(row, col) : trash;
+                old_[T][r] = *q_[T][r];
+            }
+        }
+        MPCQP_UNROLL
+        for (int T = P; T < NT; ++T) {
+            const v4d_ acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[P], x[T], v4d_{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            MPCQP_UNROLL
+            for (int r = Bk + 1; r < 4; ++r) {
+                if (16 * P + 4 * r >= n) continue;
+                *q_[T][r] = old_[T][r] - acc[r];
+            }
+        }
+#else
         MPCQP_UNROLL
         for (int T = P; T < NT; ++T) {
             const v4d_ acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[P], x[T], v4d_{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
@@ -2089,6 +2154,7 @@ struct Step {
                 *q_ -= acc[r];
             }
         }
+#endif
         w.sync();
     }
 
@@ -3073,6 +3139,7 @@ struct Step {
                 exact = true;
                 chol_broke = false;
             }
+            MPCQP_MTIC();
             if (exact) {
                 residuals(mu, rpn, rdn, ndd);      // also stages H̃ in Phi
                 exact = false;
@@ -3120,14 +3187,15 @@ struct Step {
             // factor 100 if it was not accepted (wrong active set: weakly active or degenerate rows).
             if (mu <= polmu_next && rpn <= MPCQP_POLISH_RP * nh && npolish < MPCQP_POLISH_BUDGET && !(d.flags & 16u)) {
                 polmu_next = 1e-2 * mu;
-                const long long tic14_ = clock64_();
+                MPCQP_TICK(tic14_);
                 const bool pol_ok = polish(npolish);
-                prof_[14] += (double)(clock64_() - tic14_);
+                MPCQP_TOCK(14, tic14_);
                 if (pol_ok) { polished = true; status = ST_OPTIMAL; break; }
                 exact = true;                      // Phi, rd, gt were used: start over from exact residuals
                 continue;
             }
 #endif
+            MPCQP_MTOC("looptop");
             if (!verified && !phi_direct()) load_H();
             add_GtDG([&](Row& r) {
                 return r.lam * row_wi_fresh(r);             // D~ = D / (1 + δ D)
@@ -3143,6 +3211,7 @@ struct Step {
                 newton([&](Row& r) { return fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)); });
                 double ppsum = 0.0;
                 tmax = pass ? 1e-300 : 1.0;       // 1 / (largest step that keeps s, lam >= 0), capped at 1 for the predictor
+                MPCQP_MTIC();
                 if (!(MPCQP_ABLATE & 32))
                 for_rows([&](int, int, Row& r) {
                     if (!fin(r)) return;
@@ -3158,6 +3227,7 @@ struct Step {
                     r.gd = pass ? dl : r.gd;
                     ppsum += ds * dl;
                 });
+                MPCQP_MTOC("rowstep");
                 if (pass == 0) {
                     const double aaff = rcp(w.maxv(tmax));
                     // mu after the affine step: sum (s + a ds)(lam + a dl) = sum s lam (1 - a) + a^2 sum ds dl,
@@ -3172,7 +3242,7 @@ struct Step {
             // neighbourhood min_i s_i lam_i >= 0.01 mu, otherwise 0.99.  (An unguarded 0.999 jams
             // about one instance in 20000; with the guard no instance of 65536 needs more
             // iterations than with 0.99 throughout and the mean drops by about 0.9.)
-            const long long tic13_ = clock64_();
+            MPCQP_TICK(tic13_);
             amin = rcp(w.maxv(tmax));
             const double ahi = fmin(1.0, 0.9999 * amin);
             double pmin = 1e300, psum = 0.0;
@@ -3207,7 +3277,7 @@ struct Step {
                 rd[k] *= (1.0 - alpha);
             }
             w.sync();
-            prof_[13] += (double)(clock64_() - tic13_);
+            MPCQP_TOCK(13, tic13_);
             ++it;
         }
         // never primal-feasible (or NaN) => the reference's error branch (execute.jl:484-489)

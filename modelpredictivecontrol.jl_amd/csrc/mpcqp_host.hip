@@ -129,7 +129,8 @@ const char* mpcqp_last_hip_error(void) { return g_hip_err.c_str(); }
 
 static void layout_rows(mpcqp_handle h) {
     Dims& d = h->d;
-    d.cnt_[P_BOX] = d.nZ; d.cnt_[P_U] = d.nDU; d.cnt_[P_DU] = d.nDU; d.cnt_[P_Y] = d.nY; d.cnt_[P_X] = d.nxh;
+    d.cnt_[P_BOX] = d.nZ; d.cnt_[P_U] = d.nDU; d.cnt_[P_DU] = d.nDU; d.cnt_[P_X] = d.nxh;
+    d.cnt_[P_Y] = d.nY + (d.eps_host() >= 0 ? 1 : 0);         // + the row -eps <= 0 when a Ŷ group hosts it (mpcqp_types.h)
     d.cnt_[P_W] = d.nW;
     int o = 0;
     for (int g = 0; g < NGROUP; ++g) {
@@ -503,7 +504,8 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
     m.C_umin = dev[8]; m.C_umax = dev[9]; m.C_dumin = dev[10]; m.C_dumax = dev[11];
     m.C_ymin = dev[12]; m.C_ymax = dev[13]; m.c_x0min = dev[14]; m.c_x0max = dev[15];
     uint32_t g = 0;
-    if (d.neps || m.DUmin) g |= 1u << 0;                 // box lower (ϵ >= 0, hard ΔUmin)
+    // box lower: hard ΔUmin rows, and the row ϵ >= 0 unless a Ŷ group exists (it then rides there: eps_host_group)
+    if (m.DUmin || (d.neps && !m.Y0min && !m.Y0max)) g |= 1u << 0;
     if (m.DUmax) g |= 1u << 1;                           // box upper
     if (m.U0min) g |= 1u << (2 * P_U);
     if (m.U0max) g |= 1u << (2 * P_U + 1);

@@ -55,7 +55,7 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 9        // 9: a blocked step (alpha < 1/2) no longer passes the last-step test; 8: MPCQP_FLAG_KEEP_ITERATE
+#define MPCQP_KERNEL_REV 10       // 10: the row eps >= 0 rides in a Ŷ group (eps_host_group); 9: a blocked step (alpha < 1/2) no longer passes the last-step test; 8: MPCQP_FLAG_KEEP_ITERATE
 
 namespace mpcqp {
 
@@ -63,6 +63,15 @@ enum { P_BOX = 0, P_U = 1, P_DU = 2, P_Y = 3, P_X = 4, P_W = 5, NPAIR = 6, NGROU
 
 constexpr int WAVE = 64;          // gfx950 wavefront
 constexpr double BIG = 1e300;     // |h| >= BIG  <=>  row absent (bound was +-Inf)
+
+// The row  -eps <= 0  (Z̃min[end] = 0, construct.jl:1216) is formally a box row, and the only one of its group when no hard
+// dUmin exists -- a whole row slot (64 lanes of per-row state and algebra in every pass of the interior-point iteration)
+// for ONE row.  It is the same inequality as an output-bound row with a zero row of E, softness 1 and bound 0:
+// 0'dU - 1 eps <= 0.  So when a Ŷ group exists the row rides there as its row k = nY (the group then has nY + 1 rows and
+// the box-lower group only exists for hard dUmin rows); eps_host_group says where.  -1: it stays in the box group.
+MPCQP_HD constexpr int eps_host_group(uint32_t gmask, int neps) {
+    return !neps ? -1 : ((gmask >> (2 * P_Y + 1)) & 1u) ? 2 * P_Y + 1 : ((gmask >> (2 * P_Y)) & 1u) ? 2 * P_Y : -1;
+}
 
 // Runtime dimensions (the generic kernels read these; the specialised kernels take the same
 // values as template constants, see StaticDims in mpcqp_bodies.h).
@@ -73,7 +82,7 @@ struct Dims {
     int npk;                 // pk_size(nZ): packed lower triangle, rows padded in groups of four
     uint32_t gmask;          // bit g set <=> row group g may hold finite rows (handle level)
     int rowoff_[NGROUP + 1]; // first row of group g in the per-problem row arrays (inactive: empty)
-    int cnt_[NPAIR];         // primitives per pair: nZ, nDU, nDU, nY, nxh, nW
+    int cnt_[NPAIR];         // rows per pair: nZ, nDU, nDU, nY (+ 1 with the eps row, eps_host_group), nxh, nW
     int default_nb;          // 1 iff nb = [1,..,1,Hp-Hc+1]
     int dense_w;             // 1 iff a dense M_Hp or L_Hp is set: the step runs on an on-demand variant with the dense products or on the runtime-dimension kernel
     int max_iter;
@@ -81,6 +90,9 @@ struct Dims {
     uint32_t flags;
     static constexpr bool is_static = false;
     MPCQP_HD int cnt(int p) const { return cnt_[p]; }
+    // length per problem of the caller's arrays of pair p (bounds, softness): cnt(p) without the hosted eps row
+    MPCQP_HD int len(int p) const { return p == P_Y ? nY : cnt_[p]; }
+    MPCQP_HD int eps_host() const { return eps_host_group(gmask, neps); }
     MPCQP_HD int rowoff(int g) const { return rowoff_[g]; }
     MPCQP_HD int nrows() const { return rowoff_[NGROUP]; }
 };

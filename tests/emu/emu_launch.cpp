@@ -16,7 +16,7 @@
     MPCQP_SPECIALIZATIONS(X)         \
     XNB(1, 1, 3, 6, 3, 1, 0x09Fu)    \
     XNB(1, 1, 3, 6, 3, 1, 0x39Fu)    \
-    XNB(1, 1, 3, 6, 3, 1, 0x08Du)
+    XNB(1, 1, 3, 6, 3, 1, 0x08Cu)
 
 #define MPCQP_EMU_FIBER_IMPL        // (the context switch of emu_fiber.h is assembled in this unit)
 #include "emu_wave.h"
