@@ -307,15 +307,9 @@ def main():
         active = {"controllers_with_an_active_row": float((act_u.any(axis=(1, 2)) | soft_on).mean()),
                   "input_rows_on_a_bound": float(act_u.mean()), "controllers_with_slack": float(soft_on.mean())}
         # HBM bytes per launch: counters need rocprofv3 around the process (separate --pmc passes), so this is NOT a
-        # measurement of this run but the figure of the committed passes over the same command (scripts/profile_round.sh);
+        # measurement of this run but the figure of the committed passes over the same command (scripts/profile_all.sh);
         # traffic_source says which
-        traffic, traffic_source = None, None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_k_step.json")))
-            if tr["config"] == args.config and tr["batch"] == B:
-                traffic, traffic_source = tr["hbm_bytes_per_launch"], tr.get("source")
-        except Exception:
-            pass
+        traffic, traffic_source = (committed_traffic("k_step_s_C3", B) if args.config == "C3" else (None, None))
         out = {
             "metric": "QP solves/sec (moveinput!)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -359,6 +353,21 @@ def main():
         dist.destroy_process_group()
 
 
+def committed_traffic(kernel, units):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json, written by
+    scripts/pmc_summary_all.py from scripts/profile_all.sh: FETCH_SIZE + WRITE_SIZE of the kernel's last launch in separate
+    --pmc passes over THIS bench command) -- counters need rocprofv3 around the process, so the figure is not measured by
+    this run; None when the committed passes were taken at another batch size."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        k = tr[kernel]
+        if k["units_per_launch"] == units:
+            return k["hbm_bytes_per_launch"], tr.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
 def secondary(args, local):
     """BASELINE configs[1] (C2: nx=2 nu=2 Hp=20 Hc=5, batch 1024 -- the reference's own CPU-runnable case -- and batch
     65536), a C3-style problem with nZ~ = 106 (nu = ny = 3, Hp = 40, Hc = 35, batch 8192) and configs[4] (C5: linear MovingHorizonEstimator, He=20, batch 65536) on this GPU: value, kernel time and
@@ -383,13 +392,17 @@ def secondary(args, local):
         flops, _, _ = algorithmic_flops(cfg, float(iters.mean()), rows_u, rows_y)
         kms = float(np.mean(kern_ms))
         ach = flops * B / (kms * 1e-3) / 1e12
+        pk = {("C2", 1024): "k_step_small_w1_12", ("C2", 65536): "k_step_small_12", ("12,3,3,40,35", 8192): "k_step_s_nZ106",
+              ("4,2,2,20,5", 65536): "k_step_small_y_12"}[(name, B)]
+        tr_, trs_ = committed_traffic(pk, B)
         recs.append({"workload": cfg.name, "batch": B, "metric": "QP solves/sec (moveinput!)", "value": B * args.steps / elapsed,
                      "unit": "solves/s", "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kms,
                      "ipm_mean_iters": float(iters.mean()), "optimal_fraction": float((status == 0).mean()),
                      "kernel": {0: "runtime-dimension", 1: "ahead-of-time specialisation", 2: "on-demand specialisation",
                                 3: "small-problem kernel (four controllers per wavefront)"}[sh.kernel],
                      "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / FP64_PEAK_TFLOPS, "flops_per_solve": flops}})
+                                  "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr_, "traffic_source": trs_, "profile": pk,
+                                  "flops_per_solve": flops}})
         del sh
         torch.cuda.empty_cache()
     # the MultipleShooting transcription on its stage-structured kernel (Riccati recursion inside the
@@ -411,7 +424,9 @@ def secondary(args, local):
                      "kernel_ms": kms, "ipm_mean_iters": float(iters.mean()), "optimal_fraction": float((status == 0).mean()),
                      "kernel": "k_ms_step_g (stage-structured MultipleShooting kernel, HBM scratch)",
                      "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / FP64_PEAK_TFLOPS, "flops_per_solve": flops}})
+                                  "frac": ach / FP64_PEAK_TFLOPS, "traffic": committed_traffic("k_ms_step_g", B)[0],
+                                  "traffic_source": committed_traffic("k_ms_step_g", B)[1], "profile": "k_ms_step_g",
+                                  "flops_per_solve": flops}})
         del sh
         torch.cuda.empty_cache()
     a5 = copy.copy(args)
@@ -421,7 +436,8 @@ def secondary(args, local):
                  "value": r5["value"], "unit": r5["unit"], "ms_per_step": r5["ms_per_step"],
                  "kernel_ms": r5["roofline"]["kernel_ms"], "ipm_mean_iters": r5["config"]["ipm_mean_iters"],
                  "optimal_fraction": r5["config"]["optimal_fraction"], "kernel": "k_mhe_step (+ 2 k_mhe_cov per period)",
-                 "roofline": {k: r5["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flops_per_solve")},
+                 "roofline": {k: r5["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_period",
+                                                           "traffic_over_algorithmic", "flops_per_solve")},
                  "cpu_baseline": r5.get("cpu_baseline")})
     # the soft variant of the estimator kernel (bounds relaxed by the slack: k_mhe_step<12, 15>), VERDICT r3 item 4
     a5s = copy.copy(args)
@@ -431,7 +447,8 @@ def secondary(args, local):
                  "value": r5s["value"], "unit": r5s["unit"], "ms_per_step": r5s["ms_per_step"],
                  "kernel_ms": r5s["roofline"]["kernel_ms"], "ipm_mean_iters": r5s["config"]["ipm_mean_iters"],
                  "optimal_fraction": r5s["config"]["optimal_fraction"], "kernel": "k_mhe_step, soft variant (+ 2 k_mhe_cov per period)",
-                 "roofline": {k: r5s["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "flops_per_solve")}})
+                 "roofline": {k: r5s["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_period",
+                                                            "traffic_over_algorithmic", "flops_per_solve")}})
     return recs
 
 

@@ -121,11 +121,14 @@ def measure(args, rank, world, local, dist, cpu=True):
     kms = float(np.mean(sh.kern_ms))
     achieved = flops * B / (kms * 1e-3) / 1e12
     Zt = sh.h.get(pm.GET_ZTILDE)
-    traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/
+    # HBM bytes per launch from the PMC passes committed under profiles/ (traffic.json: scripts/profile_all.sh +
+    # pmc_summary_all.py, the steady-state launch of each variant) and the algorithmic bytes of one period next to them
+    traffic, algo = None, None
     try:
-        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_k_mhe_step.json")))
-        if tr["config"] == args.config and tr["batch"] == B:
-            traffic = tr["hbm_bytes_per_launch"]
+        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
+        k = tr["k_mhe_step_12_soft" if args.config == "C5S" else "k_mhe_step_12_hard"]
+        if k["units_per_launch"] == B and cfg.nxh == 12:
+            traffic, algo = k["hbm_bytes_per_launch"], k.get("algorithmic_bytes_per_unit")
     except Exception:
         pass
     out = {
@@ -147,6 +150,8 @@ def measure(args, rank, world, local, dist, cpu=True):
         "roofline": {"bound": "mfma", "kernel": "k_mhe_step", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "kernel_ms": kms,
                      "hbm_measured_GBps": (traffic / (kms * 1e-3) / 1e9) if traffic else None,
+                     "algorithmic_bytes_per_period": algo,
+                     "traffic_over_algorithmic": (traffic / B / algo) if (traffic and algo) else None,
                      "flops_per_solve": flops,
                      "note": "FP64 vector peak (v_fma_f64; the kernel's blocks are 12 x 12, below the 16 x 16 x 4 MFMA "
                              "tile, and run on v_fma_f64 + DPP row broadcasts); flops = setup + I W_iter, block "

@@ -77,6 +77,9 @@
 #ifndef MPCQP_CHOL_RMW_BATCH
 #define MPCQP_CHOL_RMW_BATCH 1    // read-modify-writes of the in-panel update / the U rows: all reads first, then all writes
 #endif
+#ifndef MPCQP_CHOL_DIAG
+#define MPCQP_CHOL_DIAG 1         // chol_static: pivot guard by a floor, 1/L_kk from the diagonal slot after the last column
+#endif
 #ifndef MPCQP_SOLVE_DPP
 #define MPCQP_SOLVE_DPP 1         // triangular solves of the specialised kernels blocked by DPP rows (Step::solve_static)
 #endif
@@ -2219,6 +2222,21 @@ struct Step {
         MPCQP_UNROLL
         for (int cc = 0; cc < NC; ++cc) gt[K0 + cc] = d_[cc];        // every lane, same value, same address
 #endif
+#elif MPCQP_CHOL_DIAG
+        // The pivot guard is a floor (v_max with the lane's threshold: one instruction on the pivot chain instead of a
+        // compare and two selects after it) and L_kk = v_k / sqrt(v_k) stays in the diagonal slot: cholesky() turns it
+        // into 1/L_kk -- and tells a floored pivot by L_kk^2 <= thr -- once, after the last column (one LDS read, one
+        // reciprocal, one store per lane instead of a three-instruction select per column).  A factor with a floored
+        // pivot is finite garbage: Step::run discards it (larger dual regularisation, no step taken).
+        MPCQP_UNROLL
+        for (int cc = 0; cc < CB; ++cc) {
+            const int k = K0 + cc;                       // k <= 63; a column k >= n only sees zeros
+            const double idl = rsqrt_(fmx(v[cc], thr));  // (only lane k's value is used)
+            const double idb = w.bcast(idl, k);
+            lk[cc] = v[cc] * idb;
+            MPCQP_UNROLL
+            for (int c2 = cc + 1; c2 < CB; ++c2) v[c2] -= lk[cc] * w.bcast(lk[cc], K0 + c2);
+        }
 #else
         MPCQP_UNROLL
         for (int cc = 0; cc < CB; ++cc) {
@@ -2233,7 +2251,7 @@ struct Step {
 #endif
         if (mine) {
             MPCQP_UNROLL
-            for (int cc = 0; cc < CB; ++cc) lk[cc] = (i > K0 + cc) ? lk[cc] : 0.0;
+            for (int cc = 0; cc < CB; ++cc) lk[cc] = (MPCQP_CHOL_DIAG && !MPCQP_CHOL_REDUNDANT ? i >= K0 + cc : i > K0 + cc) ? lk[cc] : 0.0;
             store4(Phi + rowi + K0, lk);
         }
         w.sync();
@@ -2278,6 +2296,18 @@ struct Step {
 #if MPCQP_CHOL_REDUNDANT && MPCQP_CHOL_INVD != 0
             myinvd = act ? gt[i] : 0.0;           // (gt is free during a factorisation)
             w.sync();
+#endif
+#if MPCQP_CHOL_DIAG && !MPCQP_CHOL_REDUNDANT
+            {
+                // L_ii from the diagonal slot -> 1/L_ii in the lane's register, zero in the slot (what the sweeps expect)
+                const double Ld = act ? Phi[rowi + i] : 1.0;
+                if (act) Phi[rowi + i] = 0.0;
+                chol_broke = w.any(act && !(Ld * Ld > thr));         // a floored (or NaN) pivot
+                myinvd = act ? rcp(Ld) : 0.0;
+                w.sync();
+                MPCQP_TOC(6);
+                return;
+            }
 #endif
             myinvd = fmx(myinvd, 1e-32);
             chol_broke = w.any(act && myinvd <= 1e-32);
@@ -3036,15 +3066,17 @@ struct Step {
     }
 
     // (H + G'D~G) dz = -rd + G'(w rc/s - D~ rp); then gd = G dz.  rc(Row&) given by functor.
-    template <class Fn>
-    MPCQP_HD void newton(Fn rc) {
+    // rowfn(Row&) runs on every finite row right after its gd = (G dz)[row] is known -- the row step of the caller in the
+    // same pass over the rows as G dz (one traversal of the row slots less per Newton solve).
+    template <class Fn, class RowFn>
+    MPCQP_HD void newton(Fn rc, RowFn rowfn) {
         apply_Gt([&](Row& r) {
             return row_wi_cached(r) * (rc(r) - r.lam * r.rp);
         });
         for (int k = w.lane; k < d.nZ; k += WAVE) gt[k] -= rd[k];
         w.sync();
         if (!(MPCQP_ABLATE & 4)) solve_into_dz();
-        apply_G(dz, [&](Row& r, double g) { r.gd = g; });
+        apply_G(dz, [&](Row& r, double g) { r.gd = g; rowfn(r); });
     }
 
     MPCQP_HD int run(const StepIO& io, int& iters_out) {
@@ -3201,6 +3233,18 @@ struct Step {
                 return r.lam * row_wi_fresh(r);             // D~ = D / (1 + δ D)
             });
             if (!(MPCQP_ABLATE & 2)) cholesky();
+#if MPCQP_CHOL_DIAG && !MPCQP_FIXED_ITERS && defined(__HIP_DEVICE_COMPILE__)
+            // (chol_static's floored pivots leave a finite but meaningless factor: no step is taken with it -- the loop top
+            //  raises the dual regularisation and re-evaluates the residuals; with the regularisation at its cap the solve
+            //  has failed.  The runtime-dimension factorisation freezes the coordinate instead and goes on as before.)
+            if constexpr (one_row_per_lane<DM>()) {
+                if (chol_broke) {
+                    if (delta < 1e-8) continue;
+                    status = ST_ERROR;
+                    break;
+                }
+            }
+#endif
             // Two Newton solves with the same factor, one pass of the loop each (one copy of the
             // code): pass 0 the predictor, rc = s lam; pass 1 the corrector,
             // rc = s lam + ds_aff dl_aff - sigma mu (sigma = (mu_aff/mu)^3 from the predictor).
@@ -3208,13 +3252,11 @@ struct Step {
             MPCQP_NOUNROLL
             for (int pass = 0; pass < 2; ++pass) {
                 const double cpp = pass ? 1.0 : 0.0;
-                newton([&](Row& r) { return fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)); });
                 double ppsum = 0.0;
                 tmax = pass ? 1e-300 : 1.0;       // 1 / (largest step that keeps s, lam >= 0), capped at 1 for the predictor
-                MPCQP_MTIC();
-                if (!(MPCQP_ABLATE & 32))
-                for_rows([&](int, int, Row& r) {
-                    if (!fin(r)) return;
+                newton([&](Row& r) { return fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)); },
+                [&](Row& r) {
+                    if (MPCQP_ABLATE & 32) return;
                     double ds, dl;
                     row_step(r, fma(cpp, r.pp, fma(r.s, r.lam, -r.wt * smu)), ds, dl);
                     // step to the boundary as 1 / max(-ds/s, -dl/lam): no compare, no select; raw reciprocals
@@ -3227,7 +3269,6 @@ struct Step {
                     r.gd = pass ? dl : r.gd;
                     ppsum += ds * dl;
                 });
-                MPCQP_MTOC("rowstep");
                 if (pass == 0) {
                     const double aaff = rcp(w.maxv(tmax));
                     // mu after the affine step: sum (s + a ds)(lam + a dl) = sum s lam (1 - a) + a^2 sum ds dl,

@@ -83,16 +83,18 @@ spans = sorted((a, b, nm) for a, (nm, b) in names.items())
 for a, b, nm in spans:                       # outer spans first (sorted by start), inner overwrite -- except inside polish
     for i in range(a, b):
         region[i] = nm
-# main loop: the smallest loop that contains a Cholesky span outside the polish and the step-rule span
-chol = [a for a, b, nm in spans if nm == "6"]
+# main loop: the smallest loop that holds the loop-top span (convergence test, exact residual evaluation and the
+# inlined polish all sit inside it) and a step-rule span; the phases of a TYPICAL iteration (no exact re-evaluation, no
+# polish) are the spans laid out between the end of the loop-top span and the back edge
+lt = [(a, b) for a, b, nm in spans if nm == "looptop"]
 upd = [a for a, b, nm in spans if nm == "13"]
-# (the polish, with its own factorisation, is laid out after the loop's back edge: the smallest such loop is the polish-free path)
-etde = [a for a, b, nm in spans if nm == "4"]
-cands = [(b - a, a, b) for a, b in loops if any(a <= c <= b for c in chol) and any(a <= u <= b for u in upd) and any(a <= e <= b for e in etde)]
+cands = [(b - a, a, b) for a, b in loops if any(a <= x and y <= b + 8 for x, y in lt) and any(a <= u <= b for u in upd)]
 _, L0, L1 = min(cands)
+LT0, LT1 = [(a, b) for a, b in lt if L0 <= a <= L1][0]
+L0 = LT1
 inner = {}
 for a, b in loops:                      # several back edges to one header are one loop
-    if L0 <= a and b <= L1 and a != L0:
+    if L0 <= a and b <= L1:
         inner[a] = max(inner.get(a, 0), b)
 inner = sorted(inner.items())
 weight = [1.0] * len(insts)
@@ -122,7 +124,7 @@ for i in range(L0, L1 + 1):
     if k == "nop":
         nopstates[r] += weight[i] * (int(s.split()[1]) + 1)
 cols = ["fma64", "f64", "trans", "dpp64", "int", "sel", "mov", "lane", "dpp32", "mfma", "lds", "vmem", "salu", "br", "wait", "nop"]
-print(f"interior-point loop: instructions {L0}..{L1} of the kernel ({L1 - L0 + 1} static); dynamic count per iteration, one pass through the polish-free path")
+print(f"interior-point loop, typical iteration (no exact residual re-evaluation, no polish): instructions {L0}..{L1} of the kernel ({L1 - L0 + 1} static); dynamic count per iteration")
 print("%-38s" % "phase" + "".join("%7s" % c for c in cols) + "%8s%8s" % ("VALU", "nopst"))
 valu_c = ["fma64", "f64", "trans", "dpp64", "int", "sel", "mov", "lane", "dpp32"]
 tot = collections.Counter()

@@ -114,3 +114,5 @@ for pat, short, what, units, algo in KERNELS:
           f"HBM B/unit {d['hbm_traffic_bytes_per_unit']:10.0f}  issue {d['wave_issue_fraction']:.2f} wait {d['wave_wait_fraction']:.2f} bank-conflict {d['lds_bank_conflict_fraction']:.2f}")
 traffic["source"] = f"{os.path.basename(dst.rstrip('/'))}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) of the last launch of each kernel, separate passes, raw"
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+if os.path.basename(os.path.dirname(os.path.abspath(dst))) == "profiles":        # the copy bench.py / bench_mhe.py read
+    json.dump(traffic, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "traffic.json"), "w"), indent=1)
