@@ -405,6 +405,38 @@ def secondary(args, local):
                                   "flops_per_solve": flops}})
         del sh
         torch.cuda.empty_cache()
+    # Several SMALL handles at once: C2 at the reference's batch of 1024 occupies 256 of the 1024 SIMDs
+    # for one launch latency.  mpcqp_step_device takes the caller's stream, so independent handles overlap when each is
+    # stepped on a stream of its own -- no new entry point: four C2 handles (different controllers) on four streams, one
+    # round = one step of each, against the same four steps issued on ONE stream.
+    try:
+        cfg = synth.get_config("C2")
+        shs = [Shard(cfg, i * 1024, 1024, args.seed, local) for i in range(4)]
+        res = {}
+        for mode in ("one stream", "four streams"):
+            for i, sh in enumerate(shs):
+                sh.stream = torch.cuda.Stream(device=sh.dev) if (mode == "four streams") else torch.cuda.current_stream()
+            for _ in range(max(1, args.warmup)):
+                for sh in shs:
+                    sh.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rounds = max(20, 4 * args.steps)
+            for _ in range(rounds):
+                for sh in shs:
+                    sh.step()
+            torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / rounds
+        ok = all(bool((sh.t_st.cpu().numpy() == 0).all()) for sh in shs)
+        recs.append({"workload": cfg.name + ", four handles of 1024 controllers stepped together", "batch": 4096,
+                     "metric": "QP solves/sec (moveinput!)", "value": 4096 / res["four streams"], "unit": "solves/s",
+                     "ms_per_round_four_streams": res["four streams"] * 1e3, "ms_per_round_one_stream": res["one stream"] * 1e3,
+                     "value_one_stream": 4096 / res["one stream"], "optimal_fraction": 1.0 if ok else 0.0,
+                     "kernel": "small-problem kernel, one launch per handle, one HIP stream per handle (wall time incl. launch overhead)"})
+        del shs
+        torch.cuda.empty_cache()
+    except Exception as e:       # (a diagnostic record: never fails the bench line)
+        recs.append({"workload": "C2, four handles stepped together", "error": repr(e)})
     # the MultipleShooting transcription on its stage-structured kernel (Riccati recursion inside the
     # interior-point iteration; horizon-long data in a per-wavefront HBM scratch): a long-horizon shape, Hp = Hc = 50.
     # Flops: per iteration and stage three ns x ns x ns products of the Joseph-form recursion (6 ns^3) and five vector

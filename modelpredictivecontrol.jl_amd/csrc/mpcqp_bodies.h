@@ -80,6 +80,9 @@
 #ifndef MPCQP_CHOL_DIAG
 #define MPCQP_CHOL_DIAG 1         // chol_static: pivot guard by a floor, 1/L_kk from the diagonal slot after the last column
 #endif
+#ifndef MPCQP_FOLD_H
+#define MPCQP_FOLD_H 1            // diagonal weights: the Newton matrix and H~ z are assembled without the packed H~ (Step::fold_H)
+#endif
 #ifndef MPCQP_SOLVE_DPP
 #define MPCQP_SOLVE_DPP 1         // triangular solves of the specialised kernels blocked by DPP rows (Step::solve_static)
 #endif
@@ -91,6 +94,9 @@
 #endif
 #ifndef MPCQP_EAPPLY44_HCMAX
 #define MPCQP_EAPPLY44_HCMAX 10   // longer control horizons take the general form of E v (the row-load form spills there)
+#endif
+#ifndef MPCQP_EAPPLY44_UNROLL
+#define MPCQP_EAPPLY44_UNROLL 2   // block columns per group of loads in flight of the row-load form of E v (nu = ny = 4)
 #endif
 #ifndef MPCQP_EV_UNROLL
 #define MPCQP_EV_UNROLL 4         // block columns / steps per unrolled pass of the general E v and E'w forms
@@ -506,7 +512,7 @@ struct Qp {
                 const double* Sa = S + t0 * sp + a0 * rs;        // block (t - j) at S_[-j * sp]
                 const double* Sb = S + t1 * sp + a1 * rs;
                 double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
-                _Pragma("unroll 2")
+                MPCQP_PRAGMA(unroll MPCQP_EAPPLY44_UNROLL)
                 for (int j = 0; j < DM::Hc; ++j) {
                     double vv[4], sa[4], sb[4];
                     load4q(v + j * 4, vv);
@@ -516,7 +522,7 @@ struct Qp {
                     y0 = fma(sb[0], vv[0], y0); y1 = fma(sb[1], vv[1], y1);
                     x0 = fma(sa[2], vv[2], x0); x1 = fma(sa[3], vv[3], x1);
                     y0 = fma(sb[2], vv[2], y0); y1 = fma(sb[3], vv[3], y1);
-                    if (j % 2 == 1) MPCQP_SCHED_FENCE();     // bounds the loads in flight (registers)
+                    if (j % MPCQP_EAPPLY44_UNROLL == MPCQP_EAPPLY44_UNROLL - 1) MPCQP_SCHED_FENCE();     // bounds the loads in flight (registers)
                 }
                 if (ok0) out[r0] = x0 + x1;
                 if (ok1) out[r1] = y0 + y1;
@@ -701,9 +707,12 @@ struct Qp {
             etde_passes<(I0 == 0 ? 2 : I0 + 1), NT>(f);
         }
     }
+    // ow: P is OVERWRITTEN with (Hg ? H̃ : 0) + scale * E'DE on the whole stored triangle (Hg == nullptr: the weights of H̃
+    // ride in dd, Step::fold_H)
     __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb,
-                                                 const double* Hg = nullptr) {
+                                                 const double* Hg = nullptr, bool ow = false) {
         MPCQP_RELANE(2);
+        ow = ow || Hg != nullptr;
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp, RS = DM::rs;
         constexpr int NT = (NDU + 15) / 16, NK = (NYR + 3) / 4;
         const int li = w.lane & 15, lk = w.lane >> 4;
@@ -838,8 +847,8 @@ struct Qp {
                     else { kload(kk, cur); kcomp(cur, true, true); }
                 }
             }
-            if (Hg) {
-                // plain stores of H̃ + scale acc on the stored triangle
+            if (ow) {
+                // plain stores of H̃ + scale acc (or scale acc alone) on the stored triangle
                 MPCQP_UNROLL
                 for (int I = I0; I <= I1; ++I) {
                     MPCQP_UNROLL
@@ -847,7 +856,7 @@ struct Qp {
                         MPCQP_UNROLL
                         for (int reg = 0; reg < 4; ++reg)
                             if (entry_ok(I, J, reg))
-                                P[entry_idx(I, J, reg)] = fma(scale, acc[I - I0][J][reg], hreg[I - I0][J][reg]);
+                                P[entry_idx(I, J, reg)] = Hg ? fma(scale, acc[I - I0][J][reg], hreg[I - I0][J][reg]) : scale * acc[I - I0][J][reg];
                     }
                 }
                 return;
@@ -874,7 +883,12 @@ struct Qp {
         };
         etde_passes<0, NT>(pass);
         if constexpr (DM::neps != 0) {
-            if (Hg) {
+            if (ow && !Hg) {             // (same as below with H̃'s ϵ row: zero off the diagonal; the caller adds 2 C to the diagonal)
+                if constexpr (IE >= NT) {
+                    for (int k = w.lane; k < NDU; k += WAVE) P[pk(NDU, k)] = 0.0;
+                }
+                if (w.lane == 0) P[pk(NDU, NDU)] = 0.0;
+            } else if (Hg) {
                 // nDU a multiple of 16: the ϵ row (index nDU) starts a tile row of its own that no pass covers -- in
                 // the overwrite mode nothing else initialises it (the caller adds E'tb to it: eps_t0 stays -1), and the
                 // row would keep the previous factor's entries: a wrong Newton matrix, twice the iterations and
@@ -893,9 +907,9 @@ struct Qp {
     // and the matrix-core path runs, the ϵ row P[pk(nDU, i')] += sum_r tb[r] E[r,i'] is added for the
     // rows of the steps t >= the returned value; the caller adds the rest (Et_apply_add; -1: all of it).
     MPCQP_HD_ETDE int EtDE_add(const double* dd, double* P, double scale = 1.0, const double* tb = nullptr,
-                          const double* Hg = nullptr) {
+                          const double* Hg = nullptr, bool ow = false) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (DM::is_static) return EtDE_add_mfma(dd, P, scale, tb, Hg);
+        if constexpr (DM::is_static) return EtDE_add_mfma(dd, P, scale, tb, Hg, ow);
 #endif
         // Strips of four: the packed layout (pk) stores row i as (i/4 + 1) aligned chunks of four
         // columns, chunk s of the whole triangle at P[4s..4s+3].  A lane takes a strip (i, ip0..ip0+3):
@@ -1377,6 +1391,15 @@ struct Step {
     double prof_[16] = {0};   // phase cycle counters (profiling builds)
     double myinvd = 0.0;      // 1/L[lane][lane] of the current factor
     bool chol_broke = false;  // the last factorisation met a pivot below its threshold (wave-uniform)
+    // H̃ = 2(E'M E + N + Pu'L Pu) (+) 2C (construct.jl:837-845) with DIAGONAL weights never has to be read by a step: its
+    // terms have the structure of G'D G -- 2 M_r joins the factor of the Ŷ row r in E'(D + 2M)E, 2 sum_{t in block} L_t the
+    // factor of the block's U row, 2 N_k (2 C for the slack) the diagonal -- and H̃ z is two structured products with the
+    // Σ table already in LDS.  fold_H: this handle takes that route (no packed H̃ from global memory in the iteration: 24
+    // loads per lane and factorisation with a drained vmcnt in front of the matrix-core loop, and the strided re-read
+    // of the 861 entries for every H̃ z of the polish).  Block / dense weight matrices keep the packed H̃.
+    bool fold_H = false;
+    bool h_Lnz = false;       // some L weight of this controller is non-zero
+    double h2n_ = 0.0, h2l_ = 0.0;      // one row per lane: lane k's 2 N_k (2 C on the slack's lane) and 2 sum_{t in block(k)} L_t
 
     MPCQP_HD Step(Qp<W, DM>& qp_)
         : qp(qp_), w(qp_.w), d(qp_.d), m(qp_.m), b(qp_.b), sm(qp_.sm), c(qp_.c),
@@ -1850,6 +1873,60 @@ struct Step {
         MPCQP_TOC(1);
     }
 
+    // 2 N_k (k < nDU), 2 C (slack); 2 sum over the steps of block(k) of L[t, c(k)]
+    MPCQP_HD double H2N(int k) const {
+        if (one_row_per_lane<DM>()) return h2n_;            // (callers pass their own lane's k)
+        return k < d.nDU ? 2.0 * m.Ndiag[(size_t)b * d.nDU + k] : (d.neps ? 2.0 * m.Cwt[b] : 0.0);
+    }
+    MPCQP_HD double H2N_load(int k) const {
+        return k < d.nDU ? 2.0 * m.Ndiag[(size_t)b * d.nDU + k] : ((d.neps && k == d.nZ - 1) ? 2.0 * m.Cwt[b] : 0.0);
+    }
+    MPCQP_HD double H2L_load(int k) const {
+        if (k >= d.nDU) return 0.0;
+        const int j = k / d.nu, cc = k - j * d.nu;
+        const int t1 = (j + 1 < d.Hc) ? qp.jl(j + 1) : d.Hp;
+        double acc = 0.0;
+        for (int t = qp.jl(j); t < t1; ++t) acc += m.Ldiag[(size_t)b * d.nU + t * d.nu + cc];
+        return 2.0 * acc;
+    }
+    MPCQP_HD double H2L(int k) const { return one_row_per_lane<DM>() ? h2l_ : H2L_load(k); }
+    MPCQP_HD void init_fold_H() {
+        double lmx = 0.0;
+        for (int k = w.lane; k < d.nDU; k += WAVE) lmx = fmax(lmx, fabs(H2L_load(k)));
+        h_Lnz = w.maxv(lmx) > 0.0;
+        if (one_row_per_lane<DM>()) { h2n_ = H2N_load(w.lane); h2l_ = H2L_load(w.lane); }
+        fold_H = MPCQP_FOLD_H && !m.Mblk && !m.Mfull && !m.Ndense && !m.Ldense && qp.pair_on(P_Y) && d.nDU <= WAVE &&
+                 (qp.pair_on(P_U) || !h_Lnz);
+        if (fold_H) {           // pads of the packed layout hold zero from here on (load_H used to bring them)
+            for (int i = w.lane; i < d.npk; i += WAVE) Phi[i] = 0.0;
+            w.sync();
+        }
+    }
+
+    // rd <- H̃ z by structured products (fold_H): 2 E'(M (E z)) + 2 N z + 2 Pu'(L (Pu z)), 2 C z_eps.  `Ez_ready`: tA[P_Y]
+    // holds E z already (apply_G(z) just ran).  tA[P_Y] is used as scratch.
+    MPCQP_HD void Hz_structured(bool Ez_ready) {
+        MPCQP_TIC();
+        double* tY = sm + c.tA[P_Y];
+        if (!Ez_ready) { qp.E_apply(z, tY); w.sync(); }
+        const double* Md = m.Mdiag + (size_t)b * d.nY;
+        for (int r = w.lane; r < d.nY; r += WAVE) tY[r] *= Md[r];
+        for (int k = w.lane; k < d.nZ; k += WAVE) rd[k] = 0.0;
+        w.sync();
+        qp.Et_apply_add(tY, rd, 2.0);                       // (lane k owns rd[k])
+        double suf = 0.0;
+        if (h_Lnz && d.nDU <= WAVE) {
+            const double pre = qp.block_prefix(w.lane < d.nDU ? z[w.lane] : 0.0);
+            suf = qp.block_suffix(w.lane < d.nDU ? H2L(w.lane) * pre : 0.0);
+        }
+        for (int k = w.lane; k < d.nZ; k += WAVE) {
+            const double hn = one_row_per_lane<DM>() ? h2n_ : H2N_load(k);
+            rd[k] = (k < d.nDU ? rd[k] + suf : 0.0) + hn * z[k];
+        }
+        w.sync();
+        MPCQP_TOC(2);
+    }
+
     // ---- Phi <- H̃ (global -> LDS) ------------------------------------------------------------
     MPCQP_HD void load_H() {
         MPCQP_RELANE(11);
@@ -1861,6 +1938,14 @@ struct Step {
     // true: add_GtDG() builds Phi = H̃ + G'DG itself, H̃ read from global memory by the matrix-core pass of the Ŷ rows
     // (EtDE_add_mfma with Hg); false: Phi must hold H̃ when add_GtDG() is called (load_H)
     MPCQP_HD bool phi_direct() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return fold_H || (DM::is_static && qp.pair_on(P_Y));
+#else
+        return fold_H;
+#endif
+    }
+    // the matrix-core pass of E'DE writes the whole stored triangle (instead of adding to it)
+    MPCQP_HD bool etde_overwrites() const {
 #if defined(__HIP_DEVICE_COMPILE__)
         return DM::is_static && qp.pair_on(P_Y);
 #else
@@ -1879,7 +1964,12 @@ struct Step {
             double dmin = 0.0, dmax = 0.0, cmin = 0.0, cmax = 0.0;
             if (r0 && fin(*r0)) { dmin = dd(*r0); cmin = r0->cs; }
             if (r1 && fin(*r1)) { dmax = dd(*r1); cmax = r1->cs; }
-            sm[c.tA[p] + k] = dmin + dmax;
+            double hw = 0.0;        // H̃'s own term of this primitive (fold_H)
+            if (fold_H) {
+                if (p == P_Y) hw = k < d.nY ? 2.0 * m.Mdiag[(size_t)b * d.nY + k] : 0.0;
+                else if (p == P_U) hw = H2L(k);
+            }
+            sm[c.tA[p] + k] = dmin + dmax + hw;
             if (p != P_BOX) {
                 sm[c.tB[p] + k] = cmin * dmin - cmax * dmax;
                 ee += cmin * cmin * dmin + cmax * cmax * dmax;
@@ -1887,6 +1977,10 @@ struct Step {
         });
         ee = w.sum(ee);
         w.sync();
+        if (fold_H && !etde_overwrites()) {      // (scalar E'DE adds in place: start from zero instead of from H̃)
+            for (int i = w.lane; i < d.npk; i += WAVE) Phi[i] = 0.0;
+            w.sync();
+        }
         bool epsY = qp.pair_on(P_Y), epsU = qp.pair_on(P_U);     // who feeds the ϵ row below
         if constexpr (has_w<DM>()) {
             if (qp.pair_on(P_W) && d.neps) {      // ϵ row of the custom rows: E_w' tB_W through Y and U
@@ -1901,7 +1995,7 @@ struct Step {
             MPCQP_TIC();
             if (!(MPCQP_ABLATE & 1))
             eps_t0 = qp.EtDE_add(sm + c.tA[P_Y], Phi, 1.0, d.neps ? sm + c.tB[P_Y] : nullptr,
-                                 phi_direct() ? m.Hpk + (size_t)b * d.npk : nullptr);
+                                 (phi_direct() && !fold_H) ? m.Hpk + (size_t)b * d.npk : nullptr, fold_H && etde_overwrites());
             w.sync();      // the MFMA write-back uses its own entry->lane map
             MPCQP_TOC(4);
         }
@@ -1990,6 +2084,7 @@ struct Step {
             if (qp.pair_on(P_BOX)) acc += sm[c.tA[P_BOX] + k];
             if (k < nDU && qp.pair_on(P_DU)) acc += sm[c.tA[P_DU] + k];
             if (k == nZ - 1 && d.neps) acc += ee;
+            if (fold_H) acc += one_row_per_lane<DM>() ? h2n_ : H2N_load(k);
             Phi[pk(k, k)] += acc;
         }
         // ϵ row: Phi[eps, k] += sum_pairs L_P' tB     (staged in dz, which is free here)
@@ -2854,14 +2949,19 @@ struct Step {
         for (int k = w.lane; k < n; k += WAVE) {
             // H̃ z with the packed lower triangle: row k up to the diagonal is contiguous,
             // the rest of the (symmetric) row comes from column k of the rows below
+            // (Hp_ == nullptr: rd holds H̃ z already, Hz_structured)
             double h0 = 0.0, h1 = 0.0;
-            const double* Hk = Hp_ + pk(k, 0);
-            int j = 0;
-            MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
-            for (; j + 1 <= k; j += 2) { h0 += Hk[j] * z[j]; h1 += Hk[j + 1] * z[j + 1]; }
-            if (j <= k) h0 += Hk[j] * z[j];
-            MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
-            for (int jj = k + 1; jj < n; ++jj) h1 += Hp_[pk(jj, k)] * z[jj];
+            if (Hp_) {
+                const double* Hk = Hp_ + pk(k, 0);
+                int j = 0;
+                MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
+                for (; j + 1 <= k; j += 2) { h0 += Hk[j] * z[j]; h1 += Hk[j + 1] * z[j + 1]; }
+                if (j <= k) h0 += Hk[j] * z[j];
+                MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
+                for (int jj = k + 1; jj < n; ++jj) h1 += Hp_[pk(jj, k)] * z[jj];
+            } else {
+                h0 = rd[k];
+            }
             const double hz = h0 + h1;
             const double r = hz + q[k] + gt[k];
             rd[k] = r;
@@ -2885,6 +2985,12 @@ struct Step {
         });
         mu = w.sum(musum) / wsum;
         rpn = w.maxv(rpmax);
+        if (fold_H) {
+            Hz_structured(true);            // (E z is still in the scratch of apply_G)
+            apply_Gt([&](Row& r) { return r.lam; });
+            dual_residual(nullptr, rdn, nd_);
+            return;
+        }
         apply_Gt([&](Row& r) { return r.lam; });
         MPCQP_TIC();
         load_H();
@@ -2957,9 +3063,12 @@ struct Step {
                 rpa_prev = rpa;
                 // r_A above the floor: the step needs G_A'l^; at the floor: the test needs G_A'l
                 const bool last = rpa <= 1e-13 * nh && !retry;
+                if (fold_H) Hz_structured(false);
                 apply_Gt([&](Row& r) { return last ? r.pp : r.rp * fma(rho, r.gd, r.pp); });
                 double rdn2, ndd2;
-                {
+                if (fold_H) {
+                    dual_residual(nullptr, rdn2, ndd2);
+                } else {
                     MPCQP_TIC();
                     dual_residual(m.Hpk + (size_t)b * d.npk, rdn2, ndd2);
                     MPCQP_TOC(2);
@@ -3093,6 +3202,7 @@ struct Step {
             z[k] = v;
         }
         w.sync();
+        if (mact != 0) init_fold_H();
         if (mact == 0) {
             // no finite row at all: Z̃ = -H̃^{-1} q̃ (what ExplicitMPC computes, explicitmpc.jl:216)
             load_H();
