@@ -87,7 +87,7 @@
 #define MPCQP_SOLVE_DPP 1         // triangular solves of the specialised kernels blocked by DPP rows (Step::solve_static)
 #endif
 #ifndef MPCQP_POLISH_MU
-#define MPCQP_POLISH_MU 1e-6      // complementarity gap at which the first polish attempt is made (then every factor 100)
+#define MPCQP_POLISH_MU 1e-7      // complementarity gap at which the first polish attempt is made (then every factor 100); C3, round 5: 1e-4 15.6 ms, 1e-5 15.25, 1e-6 15.05, 1e-7 14.9, 1e-8 14.9, never 15.55 (profiles/r5e)
 #endif
 #ifndef MPCQP_POLISH_RP
 #define MPCQP_POLISH_RP 1e-6      // ... and the relative primal residual it needs

@@ -529,11 +529,11 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
 // the handle is routed to the stage-structured kernel: asked for (MultipleShooting), or the condensed kernels cannot take it
 static bool uses_stage_kernel(mpcqp_handle h) { return h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only || h->stage_rows; }
 
-// 0 when the MultipleShooting kernel takes this handle; else the reason (bit mask): 1 dense / block weights, 2 custom
+// 0 when the MultipleShooting kernel takes this handle; else the reason (bit mask): 1 dense weight matrices, 2 custom
 // linear constraints, 4 the stage data does not fit the 160 KB of LDS, 8 flags of the condensed kernels only
 static int ms_unsupported(mpcqp_handle h) {
     int why = 0;
-    if (h->m.Mblk || h->m.Mfull || h->m.Ndense || h->m.Ldense) why |= 1;
+    if (h->m.Mfull || h->m.Ndense || h->m.Ldense) why |= 1;          // (a block-diagonal M_Hp, e.g. a terminal cost, is taken since round 5)
     if (h->d.nw > 0) why |= 2;
     if (ms_lds_bytes(h->d, h->m) > 160 * 1024) why |= 4;
     if (h->d.flags & (MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL)) why |= 8;

@@ -195,6 +195,9 @@ struct MsStep {
     double prof_[8] = {0};          // -DMPCQP_MS_PROFILE: cycles per phase (residuals, stage data, factor, psi sweep, newton, update, polish, run)
     int mact = 0;
 
+    // block-diagonal M_Hp (terminal costs, construct.jl:45-93; mpcqp_set_output_weight_blocks): [Hp][ny][ny] symmetric blocks
+    // of this controller, or null (diagonal Mdiag)
+    MPCQP_HD const double* Mblk_() const { return m.Mblk ? m.Mblk + (size_t)b * d.Hp * d.ny * d.ny : nullptr; }
     MPCQP_HD MsStep(W& w_, const Dims& d_, const Model& m_, const StepIO& io_, int b_, double* sm_, double* big_)
         : w(w_), bg(big_), d(d_), m(m_), io(io_), b(b_), sm(sm_), c(make_ms_carve(d_, m_)), nx(d_.nxh), nu(d_.nu), ny(d_.ny), nd(d_.nd),
           ns(d_.nxh + d_.nu), Hp(d_.Hp), Hc(d_.Hc), nDU(d_.nDU), nY(d_.nY), nXt(d_.nxh * d_.Hp), nVt(d_.nu * d_.Hp),
@@ -387,7 +390,14 @@ struct MsStep {
             for (int a = 0; a < ny; ++a) {
                 const int r = t * ny + a;
                 double ty = rowv(MS_YMAX, r) - rowv(MS_YMIN, r);
-                if (with_cost) ty += 2.0 * m.Mdiag[(size_t)b * nY + r] * (bg[c.CX + r] - bg[c.ry + r]);
+                if (with_cost) {
+                    if (const double* Mb = Mblk_()) {
+                        for (int a2 = 0; a2 < ny; ++a2)
+                            ty += 2.0 * Mb[((size_t)t * ny + a2) * ny + a] * (bg[c.CX + t * ny + a2] - bg[c.ry + t * ny + a2]);
+                    } else {
+                        ty += 2.0 * m.Mdiag[(size_t)b * nY + r] * (bg[c.CX + r] - bg[c.ry + r]);
+                    }
+                }
                 acc += Cm[a + ny * k] * ty;
             }
             if (t == Hp - 1) acc += rowv(MS_XMAX, k) - rowv(MS_XMIN, k);
@@ -496,8 +506,15 @@ struct MsStep {
         for (int idx = w.lane; idx < ns * ns; idx += WAVE) {
             const int i = idx / ns, j = idx - i * ns;
             double acc = 0.0;
-            if (i < nx && j < nx) {           // C^' diag(QY_t) C^  (+ terminal rows on the last stage)
+            if (i < nx && j < nx) {           // C^' (diag(QY_t) [+ 2 M_t, block weights]) C^  (+ terminal rows on the last stage)
                 for (int a = 0; a < ny; ++a) acc += Cm[a + ny * i] * bg[c.QY + t * ny + a] * Cm[a + ny * j];
+                if (const double* Mb = Mblk_()) {
+                    for (int a = 0; a < ny; ++a) {
+                        double ms = 0.0;
+                        for (int a2 = 0; a2 < ny; ++a2) ms += Mb[((size_t)t * ny + a2) * ny + a] * Cm[a2 + ny * j];
+                        acc += 2.0 * Cm[a + ny * i] * ms;
+                    }
+                }
                 if (t == Hp - 1 && i == j) acc += xterm(i);
             } else if (i == j) {
                 acc = bg[c.QV + t * nu + (i - nx)];
@@ -810,10 +827,29 @@ struct MsStep {
             copy(sv1, gX + t * nx, nx); copy(sv1 + nx, gV + t * nu, nu);               // g_{t+1}
             copy(sv2, bg + c.QV + t * nu, nu); copy(sv2 + nu, bg + c.QY + t * ny, ny);  // stage Hessian diagonals
             w.sync_lds();
-            for (int a = w.lane; a < ny; a += WAVE) {
-                double acc = 0.0;
-                for (int k = 0; k < nx; ++k) acc += Cm[a + ny * k] * sv0[k];
-                ul[a] = acc * sv2[nu + a];
+            if (const double* Mb = Mblk_()) {        // (2 M_t + diag) (C^ dx): C^ dx first, then the block product
+                for (int a = w.lane; a < ny; a += WAVE) {
+                    double acc = 0.0;
+                    for (int k = 0; k < nx; ++k) acc += Cm[a + ny * k] * sv0[k];
+                    ul[a] = acc;
+                }
+                w.sync_lds();
+                double nv[4];                            // rows a = lane + 64 q (ny <= 256)
+                int nq = 0;
+                for (int a = w.lane; a < ny; a += WAVE, ++nq) {
+                    double acc = ul[a] * sv2[nu + a];
+                    for (int a2 = 0; a2 < ny; ++a2) acc += 2.0 * Mb[((size_t)t * ny + a2) * ny + a] * ul[a2];
+                    nv[nq] = acc;
+                }
+                w.sync_lds();
+                nq = 0;
+                for (int a = w.lane; a < ny; a += WAVE, ++nq) ul[a] = nv[nq];
+            } else {
+                for (int a = w.lane; a < ny; a += WAVE) {
+                    double acc = 0.0;
+                    for (int k = 0; k < nx; ++k) acc += Cm[a + ny * k] * sv0[k];
+                    ul[a] = acc * sv2[nu + a];
+                }
             }
             w.sync_lds();
             for (int i = w.lane; i < ns; i += WAVE) {
@@ -1055,7 +1091,7 @@ struct MsStep {
         auto dt_ = [&](int g, int k) { return on(g) ? rgd[c.rowoff[g] + k] : 0.0; };
         auto cs_ = [&](int g, int k) { return on(g) ? rcs[c.rowoff[g] + k] : 0.0; };
         for (int r = w.lane; r < nY; r += WAVE) {
-            bg[c.QY + r] = 2.0 * m.Mdiag[(size_t)b * nY + r] + dt_(MS_YMIN, r) + dt_(MS_YMAX, r);
+            bg[c.QY + r] = (m.Mblk ? 0.0 : 2.0 * m.Mdiag[(size_t)b * nY + r]) + dt_(MS_YMIN, r) + dt_(MS_YMAX, r);   // (block weights: add_Q, sweep)
             bg[c.CD + r] = cs_(MS_YMIN, r) * dt_(MS_YMIN, r) - cs_(MS_YMAX, r) * dt_(MS_YMAX, r);      // tB of the output rows
         }
         for (int r = w.lane; r < nVt; r += WAVE) {

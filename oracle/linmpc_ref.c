@@ -146,7 +146,7 @@ void linmpc_ref_destroy(void* p) {
  *     (H + rho G_A'G_A) dz = -(H z + q + G_A'lam) - rho G_A'(G_A z - h_A),   lam += rho (G_A (z + dz) - h_A),
  * with exactly evaluated residuals each round; the point is accepted when it satisfies the KKT
  * conditions of the inequality-constrained QP (multipliers >= 0 on A, inactive rows feasible). */
-static double POL_MU = 1e-6, POL_RHO = 1e10, POL_RD = 1e-14, POL_RP = 1e-13, POL_LAM = 1e-12, POL_SL = 1e-11;
+static double POL_MU = 1e-7, POL_RHO = 1e10, POL_RD = 1e-14, POL_RP = 1e-13, POL_LAM = 1e-12, POL_SL = 1e-11;
 static int POL_ROUNDS = 8;
 static double TERM_PFAC = 10.0, TERM_PSTALL = 1e-9;   /* primal residual target (x res_tol) and stall ceiling (x nh) */
 void linmpc_ref_term_params(double pfac, double pstall) { TERM_PFAC = pfac; TERM_PSTALL = pstall; }

@@ -52,6 +52,16 @@ def test_multiple_shooting_beats_condensation_on_a_harder_unstable_plant(hiplib)
     assert r["err"].max() <= TOL, r["err"]
 
 
+def test_terminal_cost_is_lqr_on_the_multiple_shooting_kernel_on_gpu(hiplib):
+    """T6 (test/3_test_predictive_control.jl:498-527: M_Hp = blkdiag(I, I, P_DARE), Hp = Hc = 3 => the closed loop is the LQR's,
+    atol 1e-5 there) with transcription = MultipleShooting on the stage-structured kernel (block weights, round 5)."""
+    from tests.parity_util import run_lqr_terminal_cost
+    kinds = []
+    X_mpc, X_lqr = run_lqr_terminal_cost(B=64, transcription="MultipleShooting", kinds=kinds)
+    assert kinds == [api.KERNEL_MS]
+    assert np.abs(X_mpc - X_lqr).max() <= 1e-8
+
+
 def test_transcriptions_agree_on_C3(hiplib):
     """BASELINE configs[2] shapes, 512 controllers: the MultipleShooting kernel and the condensed (SingleShooting)
     specialisation return the same ΔU, ϵ and Ŷ."""

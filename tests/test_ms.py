@@ -112,14 +112,48 @@ def test_multiple_shooting_kernel_on_an_unstable_plant_on_the_emulator(emulib):
     assert r["defect"].max() <= 1e-12
 
 
-def test_multiple_shooting_fallback_is_announced(emulib):
-    """A MultipleShooting controller the stage-structured kernel does not take (here: a block-diagonal M_Hp) keeps the
-    SingleShooting kernels -- same optimal ΔU -- and says so."""
+def test_terminal_cost_is_lqr_on_the_multiple_shooting_kernel(emulib):
+    """T6 (test/3_test_predictive_control.jl:498-527) with transcription = MultipleShooting: the block-diagonal
+    M_Hp = blkdiag(I, I, P_DARE) runs on the stage-structured kernel (block weights in the stage cost, round 5) and the closed
+    loop is the LQR's."""
+    from tests.parity_util import run_lqr_terminal_cost
+    kinds = []
+    X_mpc, X_lqr = run_lqr_terminal_cost(lib=emulib, B=2, transcription="MultipleShooting", kinds=kinds)
+    assert kinds == [api.KERNEL_MS]
+    assert np.abs(X_mpc - X_lqr).max() <= 1e-8
+
+
+def test_block_weights_on_the_multiple_shooting_kernel_match_the_oracle(emulib):
+    """A block-diagonal M_Hp with off-diagonal entries inside every block, input bounds active: the stage-structured kernel
+    against the dense oracle."""
     rng = np.random.default_rng(5)
     Ah, Bhu, Ch = _plant(rng, 3, 2, 2)
     rep = lambda M: np.repeat(np.asarray(M, float)[None], 2, 0)
     Hp = 6
     M = np.kron(np.eye(Hp), np.array([[2.0, 0.3], [0.3, 1.0]]))
+    M[-2:, -2:] = [[5.0, -1.0], [-1.0, 3.0]]
+    kw = dict(Hp=Hp, Hc=2, M_Hp=M, Nwt=[0.1, 0.1])
+    mpc = mpcqp.BatchLinMPC(rep(Ah), rep(Bhu), rep(Ch), transcription="MultipleShooting", lib=emulib, **kw)
+    mpc.setconstraint(umin=[-0.3, -0.3], umax=[0.3, 0.3])
+    x0, ry = rng.standard_normal(5), 2.0 * rng.standard_normal(2)
+    mpc.moveinput(rep(x0), ry)
+    assert mpc.kernel == api.KERNEL_MS and np.all(mpc.status == 0)
+    o = cd.LinMPCOracle(Ah, Bhu, Ch, **kw)
+    o.setconstraint(umin=[-0.3, -0.3], umax=[0.3, 0.3])
+    o.moveinput(x0, ry)
+    assert np.abs(o.Zt[:o.nDU]).max() > 0.05
+    assert np.abs(mpc.Z[0, :o.nDU] - o.Zt[:o.nDU]).max() <= 1e-7
+
+
+def test_multiple_shooting_fallback_is_announced(emulib):
+    """A MultipleShooting controller the stage-structured kernel does not take (here: an M_Hp that couples different prediction
+    steps) keeps the SingleShooting kernels -- same optimal ΔU -- and says so."""
+    rng = np.random.default_rng(5)
+    Ah, Bhu, Ch = _plant(rng, 3, 2, 2)
+    rep = lambda M: np.repeat(np.asarray(M, float)[None], 2, 0)
+    Hp = 6
+    M = np.kron(np.eye(Hp), np.array([[2.0, 0.3], [0.3, 1.0]]))
+    M[0, 3] = M[3, 0] = 0.2                         # couples steps 1 and 2: a dense M_Hp
     kw = dict(Hp=Hp, Hc=2, M_Hp=M, Nwt=[0.1, 0.1])
     mpc = mpcqp.BatchLinMPC(rep(Ah), rep(Bhu), rep(Ch), transcription="MultipleShooting", lib=emulib, **kw)
     x0, ry = rng.standard_normal(5), rng.standard_normal(2)
