@@ -1088,7 +1088,14 @@ struct Solver {
                 const int i = meas_of(s);
                 const double cx = op.mv(Cm, xs);
                 if (i >= 0 && live && r < nym) a.Vhat[(size_t)b * He * nym + i * nym + r] = Sld(sm.E + i) - cx;
-                if (s < N) xs = bad ? op.mv(A, xs) + Sld(sm.G + s) : Sld(sm.X + s + 1);
+                if (s < N) {
+                    // (the row product in EVERY group, failed or not: `bad` is per estimator, and a cross-lane operation under a
+                    //  per-group condition makes the groups of one wavefront disagree on the sequence of cross-lane operations --
+                    //  harmless for the row-local DPP broadcast of the device, fatal for the emulator's barriers: the "stack
+                    //  smashing" of ADVICE r4 was this line, reached when one estimator of a wavefront failed and another did not)
+                    const double ax = op.mv(A, xs) + Sld(sm.G + s);
+                    xs = bad ? ax : Sld(sm.X + s + 1);
+                }
             }
         }
         if (live) {

@@ -21,6 +21,7 @@ namespace mhe {
 struct EmuShared {
     LaneFibers& bar = lane_fibers();
     double xd[2][WAVE];
+    unsigned cn[2][WAVE];                // index of the cross-lane operation every lane is in
     unsigned long calls[WAVE] = {};      // cross-lane operations of every lane (MPCQP_EMU_WATCHDOG)
 };
 
@@ -33,10 +34,21 @@ struct EmuWave {
     unsigned n = 0;
     void sync() { sh->bar.arrive_and_wait(); }
     double* xchg(double v) {
+        sh->cn[n & 1][lane] = n;
         double* buf = sh->xd[n++ & 1];
         buf[lane] = v;
         ++sh->calls[lane];
         sh->bar.arrive_and_wait();
+        // every lane must be in the SAME cross-lane operation (a product under a per-estimator condition once was not:
+        // mhe_bodies.h write_outputs): a divergent call site aborts here with a message instead of corrupting
+        // a fiber stack somewhere later
+        for (int i = 0; i < WAVE; ++i)
+            if (sh->cn[(n - 1) & 1][i] != n - 1) {
+                fprintf(stderr, "[emu] lanes disagree on the sequence of cross-lane operations: lane %d in operation %u, lane %d in %u\n",
+                        lane, n - 1, i, sh->cn[(n - 1) & 1][i]);
+                fflush(stderr);
+                abort();
+            }
         return buf;
     }
     template <int C>

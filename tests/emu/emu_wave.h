@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: the CPU "wavefront" of the emulator -- one cooperative fiber per lane (emu_fiber.h), a barrier for
 // every wave-level operation.  Shared by emu_launch.cpp and emu_ms.cpp.
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -16,60 +17,77 @@ struct EmuShared {
     LaneFibers& bar = lane_fibers();
     double xd[WAVE];
     int xi[WAVE];
+    unsigned tg[2][WAVE], cn[2][WAVE];     // kind and index of the wave-level operation every lane is in (EmuWave::enter)
 };
 
 struct EmuWave {
     int lane;
     EmuShared* sh;
-    void sync() { sh->bar.arrive_and_wait(); }
+    unsigned n = 0;
+    // Every wave-level operation must be reached by ALL lanes in the same order (on the GPU a lane that skips one reads a
+    // stale DPP / readlane value; here the barriers would pair up operations that do not belong together and the test
+    // would fail somewhere else, or crash: ADVICE r4).  Each lane posts (kind, index) of the operation it enters and,
+    // past the operation's barrier, checks that every lane posted the same -- a divergent call site aborts with a message.
+    void enter(unsigned kind) { ++n; sh->tg[n & 1][lane] = kind; sh->cn[n & 1][lane] = n; }
+    void check(const char* what) const {
+        for (int i = 0; i < WAVE; ++i)
+            if (sh->tg[n & 1][i] != sh->tg[n & 1][lane] || sh->cn[n & 1][i] != n) {
+                fprintf(stderr, "[emu] lanes disagree on the sequence of wave-level operations: lane %d in %s (operation %u, kind %u), "
+                        "lane %d in operation %u of kind %u\n", lane, what, n, sh->tg[n & 1][lane], i, sh->cn[n & 1][i], sh->tg[n & 1][i]);
+                fflush(stderr);
+                abort();
+            }
+    }
+    void bar() { sh->bar.arrive_and_wait(); }
+    void sync() { enter(0); bar(); check("sync"); }
     void sync_lds() { sync(); }
     double sum(double v) {
-        sh->xd[lane] = v; sync();
+        enter(1); sh->xd[lane] = v; bar(); check("sum");
         double s = 0.0;
         for (int i = 0; i < WAVE; ++i) s += sh->xd[i];
-        sync();
+        bar();
         return s;
     }
     double quad_sum(double v) {
-        sh->xd[lane] = v; sync();
+        enter(2); sh->xd[lane] = v; bar(); check("quad_sum");
         const int q = lane & ~3;
         double s = sh->xd[q] + sh->xd[q + 1] + sh->xd[q + 2] + sh->xd[q + 3];
-        sync();
+        bar();
         return s;
     }
     double minv(double v) {
-        sh->xd[lane] = v; sync();
+        enter(3); sh->xd[lane] = v; bar(); check("minv");
         double s = sh->xd[0];
         for (int i = 1; i < WAVE; ++i) s = fmin(s, sh->xd[i]);
-        sync();
+        bar();
         return s;
     }
     double maxv(double v) {
-        sh->xd[lane] = v; sync();
+        enter(4); sh->xd[lane] = v; bar(); check("maxv");
         double s = sh->xd[0];
         for (int i = 1; i < WAVE; ++i) s = fmax(s, sh->xd[i]);
-        sync();
+        bar();
         return s;
     }
     int isum(int v) {
-        sh->xi[lane] = v; sync();
+        enter(5); sh->xi[lane] = v; bar(); check("isum");
         int s = 0;
         for (int i = 0; i < WAVE; ++i) s += sh->xi[i];
-        sync();
+        bar();
         return s;
     }
     bool any(bool p) { return isum(p ? 1 : 0) != 0; }
     void relane() {}
     double fetch(double v, int src) {
-        sh->xd[lane] = v; sync();
+        enter(6); sh->xd[lane] = v; bar(); check("fetch");
         double s = sh->xd[src & (WAVE - 1)];
-        sync();
+        bar();
         return s;
     }
     double bcast(double v, int src) {
-        sh->xd[lane] = v; sync();
+        enter(7); sh->xd[lane] = v; bar(); check("bcast");
         double s = sh->xd[src];
-        sync();
+        bar();
         return s;
     }
 };

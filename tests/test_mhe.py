@@ -229,6 +229,35 @@ def test_window_long_softness_survives_a_bound_reupload_on_emulator(emulib):
     assert ex <= 2e-6 and ew <= 2e-6, (ex, ew)
 
 
+def test_a_failed_estimator_next_to_solved_ones_in_one_wavefront_on_emulator(emulib):
+    """One estimator of a wavefront fails (bounds its data cannot meet: status 2, finite open-loop estimate) while its
+    neighbours are solved, and getinfo asks for V̂: the V̂ roll-out of write_outputs once ran a cross-lane product under the
+    per-estimator `failed` condition -- the groups of the wavefront then disagreed on the sequence of cross-lane operations
+    (the emulator's "stack smashing" of ADVICE r4).  Same scenario as tests/test_gpu_mhe.py::test_infeasible_estimator_fails_alone."""
+    cfg = synth.MheConfig("inf", nx=2, nu=2, nym=2, nd=1, He=3, xabs=0.8, wabs=0.3)
+    B = 6
+    bt = synth.make_mhe_batch(cfg, B, seed=2)
+    Y, U, D = synth.make_mhe_data(cfg, bt, 4)
+    bm = mhe_util.make_product(cfg, bt, lib=emulib)
+    ors = mhe_util.make_oracles(cfg, bt, range(B))
+    failed = np.zeros(B, bool)
+    for k in range(4):
+        xg = bm.preparestate(Y[k], D[k])
+        info = bm.getinfo()
+        assert np.all(np.isfinite(info["V̂"])) and np.all(np.isfinite(xg))
+        for b, e in enumerate(ors):
+            xo = e.preparestate(Y[k][b], D[k][b])
+            if e.status != 0:
+                assert bm.status[b] == 2
+                failed[b] = True
+            elif not failed[b]:
+                assert bm.status[b] == 0 and np.abs(xg[b] - xo).max() <= 2e-6 * max(1.0, np.abs(xo).max())
+        bm.updatestate(U[k], Y[k], D[k])
+        for b, e in enumerate(ors):
+            e.updatestate(U[k][b], Y[k][b], D[k][b])
+    assert failed.any() and not failed.all()
+
+
 def test_reference_setmodel_through_the_product_on_emulator(emulib):
     """setmodel!(::MovingHorizonEstimator, model), test/2_test_state_estim.jl:1668-1718, through BatchMHE.setmodel
     (mpcqp_mhe_set_model + mpcqp_mhe_shift_windows)."""
