@@ -83,6 +83,9 @@
 #ifndef MPCQP_FOLD_H
 #define MPCQP_FOLD_H 1            // diagonal weights: the Newton matrix and H~ z are assembled without the packed H~ (Step::fold_H)
 #endif
+#ifndef MPCQP_CHOL_LDL
+#define MPCQP_CHOL_LDL 1          // chol_static / solve_static: Phi = M D M' with unit-triangular M (stored negated), no square roots, no per-solve scaling
+#endif
 #ifndef MPCQP_SOLVE_DPP
 #define MPCQP_SOLVE_DPP 1         // triangular solves of the specialised kernels blocked by DPP rows (Step::solve_static)
 #endif
@@ -1389,7 +1392,8 @@ struct Step {
     double nh;          // 1 + max |h|
     double delta;
     double prof_[16] = {0};   // phase cycle counters (profiling builds)
-    double myinvd = 0.0;      // 1/L[lane][lane] of the current factor
+    double myinvd = 0.0;      // 1/L[lane][lane] of the current factor (LDL' form: 1/d[lane])
+    double myd_ = 0.0;        // LDL' form: the lane's pivot d[lane] while the factorisation runs
     bool chol_broke = false;  // the last factorisation met a pivot below its threshold (wave-uniform)
     // H̃ = 2(E'M E + N + Pu'L Pu) (+) 2C (construct.jl:837-845) with DIAGONAL weights never has to be read by a step: its
     // terms have the structure of G'D G -- 2 M_r joins the factor of the Ŷ row r in E'(D + 2M)E, 2 sum_{t in block} L_t the
@@ -2169,10 +2173,13 @@ struct Step {
             MPCQP_PRAGMA(unroll MPCQP_PANEL_UNROLL)
             for (int kk = 0; kk < 4 * P; ++kk) {
                 const double bb = X[P][4 * kk];
-                acc[P] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb, bb, acc[P], 0, 0, 0);
+                // (one row per lane, M D M' form: one operand carries d of its column, the d vector sits in gt; the
+                //  several-rows-per-lane factorisation that shares this function is LL')
+                const double bs = (MPCQP_CHOL_LDL && !MPCQP_CHOL_REDUNDANT && one_row_per_lane<DM>()) ? bb * gt[4 * kk + lk] : bb;
+                acc[P] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb, bs, acc[P], 0, 0, 0);
                 MPCQP_UNROLL
                 for (int I = P + 1; I < NT; ++I)
-                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[I][4 * kk], bb, acc[I], 0, 0, 0);
+                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[I][4 * kk], bs, acc[I], 0, 0, 0);
             }
             double* const trash = sm + c.zero + 4;        // unconditional write-back, see EtDE_add_mfma
             MPCQP_UNROLL
@@ -2213,6 +2220,7 @@ struct Step {
             const int row = 16 * T + li < n ? 16 * T + li : n - 1;
             x[T] = Phi[pk(row, 0) + K0 + lk];
         }
+        const double xPs = (MPCQP_CHOL_LDL && !MPCQP_CHOL_REDUNDANT && one_row_per_lane<DM>()) ? x[P] * gt[K0 + lk] : x[P];   // (M D M': d of the block's columns, written by chol_static)
         double* const trash = sm + c.zero + 4;
 #if MPCQP_CHOL_RMW_BATCH
         // Every entry to be updated is requested BEFORE the matrix-core instructions are issued and written after them:
@@ -2233,7 +2241,7 @@ struct Step {
         }
         MPCQP_UNROLL
         for (int T = P; T < NT; ++T) {
-            const v4d_ acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[P], x[T], v4d_{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            const v4d_ acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xPs, x[T], v4d_{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
             MPCQP_UNROLL
             for (int r = Bk + 1; r < 4; ++r) {
                 if (16 * P + 4 * r >= n) continue;
@@ -2243,7 +2251,7 @@ struct Step {
 #else
         MPCQP_UNROLL
         for (int T = P; T < NT; ++T) {
-            const v4d_ acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[P], x[T], v4d_{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            const v4d_ acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xPs, x[T], v4d_{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
             MPCQP_UNROLL
             for (int r = Bk + 1; r < 4; ++r) {
                 if (16 * P + 4 * r >= n) continue;
@@ -2317,6 +2325,26 @@ struct Step {
         MPCQP_UNROLL
         for (int cc = 0; cc < NC; ++cc) gt[K0 + cc] = d_[cc];        // every lane, same value, same address
 #endif
+#elif MPCQP_CHOL_LDL
+        // Phi = M D M' with unit lower-triangular M, stored NEGATED (m_ik = -a_ik / d_k: the substitution chains of
+        // solve_static add), no square root: the pivot chain is v_rcp_f64 + two multiply-adds per column (LL': floor,
+        // v_rsq_f64 + three), and -- the point -- the sweeps of solve_static use the stored entries as they are: no scaling of
+        // the factor by 1/L_ii in every solve (176 multiplications per interior-point iteration).  A column's 1/d_k is known
+        // when its entries are stored, which is what a row scaling of L never is.  No guard on the chain: a pivot <= thr
+        // (or NaN) is told from d afterwards and the factor discarded (Step::run).
+        constexpr int NCL = (n - K0 < CB) ? n - K0 : CB;             // columns of this block that exist
+        MPCQP_UNROLL
+        for (int cc = 0; cc < CB; ++cc) {
+            if (cc < NCL) {
+                const int k = K0 + cc;
+                const double nidb = -w.bcast(rcp(v[cc]), k);          // -1/d_k (every lane takes the reciprocal of its own entry, lane k's is used)
+                lk[cc] = v[cc] * nidb;                               // m_ik
+                MPCQP_UNROLL
+                for (int c2 = cc + 1; c2 < NCL; ++c2) v[c2] = fma(v[cc], w.bcast(lk[cc], K0 + c2), v[c2]);   // a_i,c2 -= a_ik a_c2,k / d_k
+            } else {
+                lk[cc] = 0.0;
+            }
+        }
 #elif MPCQP_CHOL_DIAG
         // The pivot guard is a floor (v_max with the lane's threshold: one instruction on the pivot chain instead of a
         // compare and two selects after it) and L_kk = v_k / sqrt(v_k) stays in the diagonal slot: cholesky() turns it
@@ -2345,8 +2373,19 @@ struct Step {
         }
 #endif
         if (mine) {
+#if MPCQP_CHOL_LDL && !MPCQP_CHOL_REDUNDANT
+            // lane K0 + a still holds its pivot in v[a] (a column's entry is not touched after its own step); the lanes
+            // beyond the block pick up a meaningless value here and the right one in their own block, the last one
+            // they take part in.  gt doubles as the d vector the matrix-core updates scale one operand with.
+            const double t0 = (i & 1) ? v[1] : v[0], t1 = (i & 1) ? v[3] : v[2];
+            myd_ = (i & 2) ? t1 : t0;
+            gt[i] = myd_;
+            MPCQP_UNROLL
+            for (int cc = 0; cc < CB; ++cc) lk[cc] = (i > K0 + cc) ? lk[cc] : 0.0;
+#else
             MPCQP_UNROLL
             for (int cc = 0; cc < CB; ++cc) lk[cc] = (MPCQP_CHOL_DIAG && !MPCQP_CHOL_REDUNDANT ? i >= K0 + cc : i > K0 + cc) ? lk[cc] : 0.0;
+#endif
             store4(Phi + rowi + K0, lk);
         }
         w.sync();
@@ -2392,7 +2431,15 @@ struct Step {
             myinvd = act ? gt[i] : 0.0;           // (gt is free during a factorisation)
             w.sync();
 #endif
-#if MPCQP_CHOL_DIAG && !MPCQP_CHOL_REDUNDANT
+#if MPCQP_CHOL_LDL && !MPCQP_CHOL_REDUNDANT
+            {
+                chol_broke = w.any(act && !(myd_ > thr));            // a pivot at or below its threshold, or NaN
+                myinvd = act ? rcp(myd_) : 0.0;
+                w.sync();
+                MPCQP_TOC(6);
+                return;
+            }
+#elif MPCQP_CHOL_DIAG && !MPCQP_CHOL_REDUNDANT
             {
                 // L_ii from the diagonal slot -> 1/L_ii in the lane's register, zero in the slot (what the sweeps expect)
                 const double Ld = act ? Phi[rowi + i] : 1.0;
@@ -2499,7 +2546,10 @@ struct Step {
         MPCQP_UNROLL
         for (int u = 0; u < NC; ++u) {
             const int k0 = K0 + 4 * u;
-            const double* p = Phi + pk(k0, 0) + (i < k0 + 4 ? i : 0);
+            // (M D M' form with enough zero blocks in front of the Sigma table: entries used as stored, the lanes beyond the
+            //  chunk's rows read zeros there -- at every offset e (k0 + 4) of the strided reads)
+            const double* p = solve_zero_region() ? ((i < k0 + 4 && i < n) ? Phi + pk(k0, 0) + i : sm + c.S)
+                                                  : Phi + pk(k0, 0) + (i < k0 + 4 ? i : 0);
             MPCQP_UNROLL
             for (int e = 0; e < 4; ++e) cb[u][e] = (k0 + e < n) ? p[e * (k0 + 4)] : 0.0;
         }
@@ -2520,10 +2570,12 @@ struct Step {
             for (int u = 0; u < NC; ++u) rows_sw<0xf & ~((2 << T) - 1)>(u, (u & 1) ? a1 : a0, y, cf[u]);
             r += a0 + a1;
             MPCQP_SCHED_FENCE();
-            MPCQP_UNROLL
-            for (int u = 0; u < 4; ++u) {
+            if constexpr (!solve_unscaled()) {
                 MPCQP_UNROLL
-                for (int e = 0; e < 4; ++e) nx[u][e] *= nm;
+                for (int u = 0; u < 4; ++u) {
+                    MPCQP_UNROLL
+                    for (int e = 0; e < 4; ++e) nx[u][e] *= nm;
+                }
             }
             solve_fwd_tile<T + 1>(r, nx, rowi, act, nm);
         } else {
@@ -2538,11 +2590,13 @@ struct Step {
         double nx[4][4];
         if constexpr (T > 0) solve_bwd_load<T - 1>(nx);
         MPCQP_SCHED_FENCE();
-        MPCQP_UNROLL
-        for (int u = 0; u < NC; ++u) {
-            const double sc = (act && i < K0 + 4 * u + 4) ? nm : 0.0;
+        if constexpr (!solve_zero_region()) {
             MPCQP_UNROLL
-            for (int e = 0; e < 4; ++e) cb[u][e] *= sc;
+            for (int u = 0; u < NC; ++u) {
+                const double sc = (act && i < K0 + 4 * u + 4) ? (solve_unscaled() ? 1.0 : nm) : 0.0;
+                MPCQP_UNROLL
+                for (int e = 0; e < 4; ++e) cb[u][e] *= sc;
+            }
         }
         MPCQP_UNROLL
         for (int u = NC - 1; u >= 0; --u) chain_sw<1 << T, true>(u, r, cb[u]);
@@ -2574,19 +2628,28 @@ struct Step {
             default: W::template fmabc4<12, ROWS>(a, x, cc[0], cc[1], cc[2], cc[3]); break;
         }
     }
+    // the factor is M D M' with the negated unit-triangular M stored (chol_static, MPCQP_CHOL_LDL): the sweeps use its entries
+    // as they are.  Needs zeros at the strided offsets of solve_bwd_load, i.e. enough zero blocks in front of the Sigma table.
+    static constexpr bool solve_unscaled() { return MPCQP_CHOL_LDL && !MPCQP_CHOL_REDUNDANT; }
+    // ... and the lanes beyond a chunk's rows of the backward sweep read zeros from the zero blocks in front of the Sigma
+    // table (enough of them for the strided offsets e (k0 + 4)); otherwise their entries are multiplied by zero
+    static constexpr bool solve_zero_region() { return solve_unscaled() && DM::zpad * DM::sp >= 3 * (DM::nZ + 3) + 4; }
     __device__ __forceinline__ void solve_static() {
         constexpr int n = DM::nZ;
         const int i = w.lane;
         const bool act = i < n;
         const int rowi = pk(act ? i : 0, 0);
         const double nm = act ? -myinvd : 0.0;
-        double r = (act ? gt[i] : 0.0) * myinvd;            // L y = r in the variable scaled by 1/L_ii
+        double r = act ? gt[i] : 0.0;
+        if constexpr (!(MPCQP_CHOL_LDL && !MPCQP_CHOL_REDUNDANT)) r *= myinvd;      // LL': L y = r in the variable scaled by 1/L_ii
         double cf[4][4];
         solve_fwd_load<0>(cf, rowi, act);
-        MPCQP_UNROLL
-        for (int u = 0; u < 4; ++u) {
+        if constexpr (!solve_unscaled()) {
             MPCQP_UNROLL
-            for (int e = 0; e < 4; ++e) cf[u][e] *= nm;
+            for (int u = 0; u < 4; ++u) {
+                MPCQP_UNROLL
+                for (int e = 0; e < 4; ++e) cf[u][e] *= nm;
+            }
         }
         solve_fwd_tile<0>(r, cf, rowi, act, nm);            // (runs on into the backward sweep)
         if (act) dz[i] = r;
@@ -3343,7 +3406,7 @@ struct Step {
                 return r.lam * row_wi_fresh(r);             // D~ = D / (1 + δ D)
             });
             if (!(MPCQP_ABLATE & 2)) cholesky();
-#if MPCQP_CHOL_DIAG && !MPCQP_FIXED_ITERS && defined(__HIP_DEVICE_COMPILE__)
+#if (MPCQP_CHOL_DIAG || MPCQP_CHOL_LDL) && !MPCQP_FIXED_ITERS && defined(__HIP_DEVICE_COMPILE__)
             // (chol_static's floored pivots leave a finite but meaningless factor: no step is taken with it -- the loop top
             //  raises the dual regularisation and re-evaluates the residuals; with the regularisation at its cap the solve
             //  has failed.  The runtime-dimension factorisation freezes the coordinate instead and goes on as before.)
