@@ -306,8 +306,12 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
  *                      revision AND the identity of the compiler binary that built them.
  *   mpcqp_kernel_kind  the kind a step would run on right now; never compiles.
  *   mpcqp_row_groups   the handle's pattern of constraint groups (bit g: group g may hold finite rows;
- *                      0 box lower [eps >= 0, hard dUmin], 1 box upper, 2 Umin, 3 Umax, 4 soft dUmin,
- *                      5 soft dUmax, 6 Ymin, 7 Ymax, 8 xhat-min, 9 xhat-max, 10 Wmin, 11 Wmax).
+ *                      0 box lower [hard dUmin; also the row eps >= 0 when no output-bound group exists -- with
+ *                      one, that row rides there as an extra row with a zero row of E, softness 1, bound 0 (kernel
+ *                      revision 10: a whole row slot less in the step kernel)], 1 box upper, 2 Umin, 3 Umax,
+ *                      4 soft dUmin, 5 soft dUmax, 6 Ymin, 7 Ymax, 8 xhat-min, 9 xhat-max, 10 Wmin, 11 Wmax).
+ *                      Use the value a handle of the same constraint pattern reports, e.g. BASELINE config 3 (hard
+ *                      umin / umax, soft ymax): 0x8c.
  *   mpcqp_prebuild     compile-only (no GPU, no handle): for build pipelines; dims->batch is ignored.  Returns the
  *                      MPCQP_KERNEL_* kind of the shape (>= 0) or a negative error code.  The package ships a manifest
  *                      of shapes (spec_manifest.txt: `nu ny nxhat Hp Hc neps row_groups`) that its build and
