@@ -42,6 +42,9 @@
 #ifndef MPCQP_MHE_EXACT_PIVOT
 #define MPCQP_MHE_EXACT_PIVOT 0
 #endif
+#ifndef MPCQP_MHE_GJ_DEFER
+#define MPCQP_MHE_GJ_DEFER 1     // Gauss-Jordan inverse with the row scalings deferred to the end (Ops::gj)
+#endif
 #ifndef MPCQP_MHE_BMID_LDS
 #define MPCQP_MHE_BMID_LDS 1     // middle diagonal block of the Hessian in LDS (18 KB per wave) or read from the constant block (12 KB)
 #endif
@@ -104,6 +107,15 @@ struct Ops {
             C[c] = acc;
         });
     }
+    MPCQP_HD void mmt_sub(const Row& X, const Row& Y, Row& C) const {   // C -= X Y', accumulated in place
+        sfor<NX>([&](auto ic) {
+            constexpr int c = decltype(ic)::v;
+            sfor<NX / 4>([&](auto ij) {
+                constexpr int k = 4 * decltype(ij)::v;
+                w.template fmsbc4<c, c, c, c>(C[c], Y[k], Y[k + 1], Y[k + 2], Y[k + 3], X[k], X[k + 1], X[k + 2], X[k + 3]);
+            });
+        });
+    }
     MPCQP_HD void mmt_acc(const Row& X, const Row& Y, Row& C, double sign) const {   // C += sign X Y'
         sfor<NX>([&](auto ic) {
             constexpr int c = decltype(ic)::v;
@@ -117,8 +129,38 @@ struct Ops {
     }
     // in-place inverse of a symmetric positive definite matrix (Gauss-Jordan, no pivoting: the pivots
     // are those of the LDL' factorisation).  Returns false (for the whole group) on a bad pivot.
+    // MPCQP_MHE_GJ_DEFER: the pivot row is NOT divided by its pivot when it is eliminated with -- a row scaling commutes
+    // with the later eliminations (they see d_k times the scaled row and form d_k times its update) -- so the step is one
+    // in-place multiply-add per entry (the pivot lane with factor 0) instead of a multiply and a multiply-add, and every
+    // lane scales its row by its own 1/d once at the end: NX^2 + NX instead of 2 NX^2 FP64 instructions per inverse.
     MPCQP_HD bool gj(Row& a, int r) const {
         bool ok = true;
+#if MPCQP_MHE_GJ_DEFER
+        double mypinv = 0.0;
+        sfor<NX>([&](auto ik) {
+            constexpr int k = decltype(ik)::v;
+            const double dk = w.template rowbc_after_asm<k>(a[k]);
+            ok = ok && (dk > 1e-280) && (dk < 1e280);
+#if MPCQP_MHE_EXACT_PIVOT
+            const double pinv = 1.0 / dk;
+#else
+            const double pinv = recip(dk);
+#endif
+            // one = 1 on the pivot lane, 0 elsewhere (a select of the high word only); the three lane-dependent values follow
+            // by arithmetic: g = x - one x (exactly 0 on the pivot lane), the lane's own 1/d, the new column k
+            const double one = (r == k) ? 1.0 : 0.0;
+            const double x = -a[k] * pinv;                   // other rows: a[c] - a[k] a_k[c] / dk
+            const double g = fma(-one, x, x);
+            mypinv = fma(one, pinv, mypinv);
+            // (column k is computed too and then replaced: the four-element groups stay uniform)
+            sfor<NX / 4>([&](auto ij) {
+                constexpr int c = 4 * decltype(ij)::v;
+                w.template gjacc4<k>(a[c], a[c + 1], a[c + 2], a[c + 3], g);
+            });
+            a[k] = g + one;
+        });
+        sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; a[c] *= mypinv; });
+#else
         sfor<NX>([&](auto ik) {
             constexpr int k = decltype(ik)::v;
             const double dk = w.template rowbc<k>(a[k]);
@@ -140,6 +182,7 @@ struct Ops {
             });
             a[k] = g;
         });
+#endif
         return ok;
     }
     MPCQP_HD static void ld(const double* p, int stride, Row& M) {
@@ -829,7 +872,7 @@ struct Solver {
                             if (s > 0) {
                                 op.mm(Oprev, Si, U);
                                 MPCQP_SCHED_FENCE();
-                                op.mmt_acc(U, Oprev, Bs, -1.0);
+                                op.mmt_sub(U, Oprev, Bs);
                                 MPCQP_SCHED_FENCE();
                             }
                             ok = op.gj(Bs, r) && ok;

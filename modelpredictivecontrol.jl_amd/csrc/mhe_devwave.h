@@ -80,6 +80,40 @@ struct MheDevWave : DevWave {
             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(m), "v"(g), "n"(K));
         a0 = t0; a1 = t1; a2 = t2; a3 = t3;
     }
+    // acc -= sum_i (x_i of lane L_i of this lane's row) * y_i (the negation is the source modifier of the multiply-add)
+    template <int L0, int L1, int L2, int L3>
+    __device__ __forceinline__ void fmsbc4(double& acc, double x0, double x1, double x2, double x3, double y0, double y1,
+                                           double y2, double y3) const {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %1, -%5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, -%6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %3, -%7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %4, -%8 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc)
+            : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
+    }
+    // rowbc with the two wait states a DPP read needs after a VALU write of its source INSIDE a preceding asm block (which
+    // the compiler's hazard recogniser does not see)
+    template <int C>
+    __device__ __forceinline__ double rowbc_after_asm(double v) const {
+        double r;
+        asm("s_nop 1\n\t"
+            "v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+            : "=v"(r) : "v"(v), "n"(C));
+        return r;
+    }
+    // Gauss-Jordan elimination step on four elements, in place: a_i <- a_i + g (a_i of lane K); the pivot lane passes g = 0
+    // and keeps its row (Ops::gj scales the rows once, after the last pivot)
+    template <int K>
+    __device__ __forceinline__ void gjacc4(double& a0, double& a1, double& a2, double& a3, double g) const {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+            : "v"(g), "n"(K));
+    }
     template <class Op>
     static __device__ __forceinline__ double rowred(double v, Op op) {
         v = op(v, dpp<0xB1>(v));     // quad_perm [1,0,3,2]

@@ -81,6 +81,18 @@ struct EmuWave {
         const double b0 = rowbc<K>(a0), b1 = rowbc<K>(a1), b2 = rowbc<K>(a2), b3 = rowbc<K>(a3);
         a0 = fma(b0, g, a0 * m); a1 = fma(b1, g, a1 * m); a2 = fma(b2, g, a2 * m); a3 = fma(b3, g, a3 * m);
     }
+    template <int L0, int L1, int L2, int L3>
+    void fmsbc4(double& acc, double x0, double x1, double x2, double x3, double y0, double y1, double y2, double y3) {
+        acc = fma(rowbc<L0>(x0), -y0, acc); acc = fma(rowbc<L1>(x1), -y1, acc);
+        acc = fma(rowbc<L2>(x2), -y2, acc); acc = fma(rowbc<L3>(x3), -y3, acc);
+    }
+    template <int C>
+    double rowbc_after_asm(double v) { return rowbc<C>(v); }
+    template <int K>
+    void gjacc4(double& a0, double& a1, double& a2, double& a3, double g) {
+        const double b0 = rowbc<K>(a0), b1 = rowbc<K>(a1), b2 = rowbc<K>(a2), b3 = rowbc<K>(a3);
+        a0 = fma(b0, g, a0); a1 = fma(b1, g, a1); a2 = fma(b2, g, a2); a3 = fma(b3, g, a3);
+    }
     template <class Op>
     double rowred(double v, Op op) {
         const double* buf = xchg(v);
