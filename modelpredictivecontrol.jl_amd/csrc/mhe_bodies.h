@@ -139,7 +139,7 @@ struct Ops {
         double mypinv = 0.0;
         sfor<NX>([&](auto ik) {
             constexpr int k = decltype(ik)::v;
-            const double dk = w.template rowbc_after_asm<k>(a[k]);
+            const double dk = w.template rowbc<k>(a[k]);      // (gjacc4 ends with the wait states a DPP read of its results needs)
             ok = ok && (dk > 1e-280) && (dk < 1e280);
 #if MPCQP_MHE_EXACT_PIVOT
             const double pinv = 1.0 / dk;

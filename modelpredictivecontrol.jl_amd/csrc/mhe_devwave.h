@@ -92,25 +92,19 @@ struct MheDevWave : DevWave {
             : "+v"(acc)
             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y0), "v"(y1), "v"(y2), "v"(y3), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
     }
-    // rowbc with the two wait states a DPP read needs after a VALU write of its source INSIDE a preceding asm block (which
-    // the compiler's hazard recogniser does not see)
-    template <int C>
-    __device__ __forceinline__ double rowbc_after_asm(double v) const {
-        double r;
-        asm("s_nop 1\n\t"
-            "v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-            : "=v"(r) : "v"(v), "n"(C));
-        return r;
-    }
     // Gauss-Jordan elimination step on four elements, in place: a_i <- a_i + g (a_i of lane K); the pivot lane passes g = 0
-    // and keeps its row (Ops::gj scales the rows once, after the last pivot)
+    // and keeps its row (Ops::gj scales the rows once, after the last pivot).  The trailing s_nop: the next DPP read of a result
+    // may be the compiler's (rowbc of the next pivot), and its hazard recogniser does not see the writes inside the block.
+    // (A pivot broadcast written as asm -- s_nop + v_mov_b64_dpp without bound_ctrl -- made k_step_small_y<8,2> fault on the
+    //  GPU, round 5; the builtin form does not.)
     template <int K>
     __device__ __forceinline__ void gjacc4(double& a0, double& a1, double& a2, double& a3, double g) const {
         asm("s_nop 1\n\t"
             "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+            "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1"
             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
             : "v"(g), "n"(K));
     }

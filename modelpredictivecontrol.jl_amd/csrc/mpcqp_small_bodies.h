@@ -13,7 +13,7 @@
 // HASY, up to 64 dense rows -- Y (hard or soft output bounds, any horizon-long pattern with +-Inf holes: setconstraint!(ymin,
 // ymax, Ymin, Ymax, c_ymin, ...), construct.jl:324-509) and the terminal rows (x̂min, x̂max, c_x̂min, c_x̂max on x̂(k+Hp): the
 // rows ex̂ z of transcription.jl:815-821 appended to the same dense block), diagonal weights, no custom rows.  Dual-regularised Mehrotra
-// predictor-corrector as everywhere else, without the active-set polish.
+// predictor-corrector and active-set polish as everywhere else (one polish attempt per wavefront, see there).
 //
 // Y rows (HASY): row r = (step t, output a) of  -E z - c0 ϵ <= -Y0min + F,  E z - c1 ϵ <= Y0max - F  belongs to lane r % 16
 // of its controller, slot r / 16 (up to four slots per lane: s, λ of both sides in registers).  The dense E (nY x NX,
@@ -24,6 +24,19 @@
 
 #include "mhe_bodies.h"
 #include "mpcqp_types.h"
+
+#ifndef MPCQP_SMALL_POLISH
+#define MPCQP_SMALL_POLISH 1      // active-set polish of the interior-point iterate, one attempt per wavefront (step_small_body)
+#endif
+#ifndef MPCQP_SMALL_POLISH_Y
+#define MPCQP_SMALL_POLISH_Y 0     // ... of the variant with dense rows: measured slower (C2 shapes with soft ymax, 65536: 4.55 -> 5.09 ms although 12.4 -> 10.7 iterations: a round costs two passes over the dense rows in LDS)
+#endif
+#ifndef MPCQP_POLISH_MU
+#define MPCQP_POLISH_MU 1e-7
+#endif
+#ifndef MPCQP_POLISH_RP
+#define MPCQP_POLISH_RP 1e-6
+#endif
 
 namespace mpcqp {
 
@@ -320,8 +333,9 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         }
     }
     const double delta = d.dual_reg;
-    int st = 1, it = 0;
+    int st = 1, it = 0, npol = 0, waited = 0;
     bool done = false;
+    double polmu_next = MPCQP_POLISH_MU, polished = 0.0;
     double laststep = 1e300, rdn_prev = 1e300, rpn_prev = 1e300, lastscale = 1.0, rpn = 0.0;
     double mu_seen = 0.0, rd_seen = 0.0;      // what the convergence test saw last (audit record)
     // one reciprocal per row, wi = 1/(s + δλ): D̃ = λ wi, w/s = wi (mhe::row_rhs)
@@ -331,6 +345,74 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         r.wi = mhe::recip(fma(delta, lv, sv));
         r.Dt = has ? lv * r.wi : 0.0;
         return r;
+    };
+    // Φ = H̃ + Gᵀ D G for row factors D of this lane's rows (the interior-point iterations: D̃ = λ / (s + δλ); the polish: ρ on its
+    // active rows)
+    const double meps = iseps ? 1.0 : 0.0;
+    auto build_phi = [&](double D0, double D1, double D2, double D3, const double (&yD0)[KYM], const double (&yD1)[KYM], Row& Phi) {
+        // P̃u' (D̃2 + D̃3) P̃u without forming the product: entry (l, c) of two variables of the same input channel is the
+        // sum of D̃ over the intervals from the later of the two on, i.e. the suffix sum `suf` of the later one -- the
+        // lane's own for the columns up to its own, the column's lane's (row broadcast) for the later columns.
+        // (GU = 1 on the columns c <= l of the lane's channel, GUt = 1 on the columns c >= l: both include c = l.)
+        const double suf = op.mv(GUt, D2 + D3);
+        // (Φ[l][c] = H̃ + GU[c] suf(l) + GUt[c] suf(c): the second product takes its left factor from lane c -- the row
+        //  broadcast is the multiply-add's own DPP modifier; both count the diagonal, taken out again with the box rows' D̃)
+        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = fma(GU[c], suf, H[c]); });
+        mhe::sfor<NX / 4>([&](auto ij) {
+            constexpr int c = 4 * decltype(ij)::v;
+            w.template rank1bc4<c, c + 1, c + 2, c + 3>(Phi[c], Phi[c + 1], Phi[c + 2], Phi[c + 3], suf, GUt[c], GUt[c + 1], GUt[c + 2], GUt[c + 3]);
+        });
+        O::add_diag(Phi, l, D0 + D1 - (isdu ? suf : 0.0));
+        // ϵ row and column of a group of soft rows: the row (lane ϵ) takes the column vector `col` of the ΔU lanes across the
+        // row -- zero on the other lanes by construction --, every ΔU lane its own entry into column ϵ, lane ϵ the diagonal
+        auto eps_border = [&](double col, double dee) {
+            mhe::sfor<NX / 4>([&](auto ij) {
+                constexpr int c = 4 * decltype(ij)::v;
+                w.template rank1bc4<c, c + 1, c + 2, c + 3>(Phi[c], Phi[c + 1], Phi[c + 2], Phi[c + 3], col, meps, meps, meps, meps);
+            });
+            const double xe = iseps ? dee : (isdu ? col : 0.0);
+            mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += (c == e) ? xe : 0.0; });
+        };
+        if (d.neps) {      // ϵ column / row: Φ[k][ϵ] = sum_j P̃u[j][k] (D̃2 cs0 - D̃3 cs1)_j,  Φ[ϵ][ϵ] += sum_j D̃2 cs0² + D̃3 cs1²
+            const double col = op.mv(GUt, D2 * cs0 - D3 * cs1);
+            const double dee = w.rsum(D2 * cs0 * cs0 + D3 * cs1 * cs1);
+            eps_border(col, dee);
+        }
+        if constexpr (HASY) {      // + Ey' (D̃lo + D̃hi) Ey, the ϵ column Ey'(D̃lo c0 - D̃hi c1) and Φ[ϵ][ϵ] += sum D̃lo c0² + D̃hi c1²
+            double dee = 0.0;
+            mhe::sfor<KYM>([&](auto iq) {
+                constexpr int q = decltype(iq)::v;
+                if (l + SMALL_RL * q < nR) {
+                    dv[yr[q]] = yD0[q] + yD1[q];
+                    wv[yr[q]] = yD0[q] * yc0(q) - yD1[q] * yc1(q);
+                }
+                dee += yD0[q] * yc0(q) * yc0(q) + yD1[q] * yc1(q) * yc1(q);
+            });
+            w.sync();
+            double col = 0.0;
+            const int lc = isvar ? l : 0;
+            auto rank1 = [&](int r, double el, double dr, double wr, const Row& Er) {
+                el = isdu ? el : 0.0;
+                const double tt = el * dr;
+                col = fma(el, wr, col);
+                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = fma(tt, Er[c], Phi[c]); });
+            };
+            int r = 0;
+            for (; r + 2 <= nR; r += 2) {          // two rows in flight: the loads of both are issued before either update
+                Row Ea, Eb;
+                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; Eb[c] = Ed[(r + 1) * NX + c]; });
+                const double ela = Ed[r * NX + lc], elb = Ed[(r + 1) * NX + lc], da = dv[r], db = dv[r + 1], wa = wv[r], wb = wv[r + 1];
+                rank1(r, ela, da, wa, Ea);
+                rank1(r + 1, elb, db, wb, Eb);
+            }
+            for (; r < nR; ++r) {
+                Row Ea;
+                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; });
+                rank1(r, Ed[r * NX + lc], dv[r], wv[r], Ea);
+            }
+            if (d.neps) eps_border(col, w.rsum(dee));
+            w.sync();
+        }
     };
     for (int pass = 0; pass < d.max_iter; ++pass) {
         // ---- residuals
@@ -374,75 +456,112 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
                 laststep <= 1e-6) { st = 0; done = true; }
         }
         if (!w.any(!done)) break;
+#if MPCQP_SMALL_POLISH
+        // ---- active-set polish (Step::polish of mpcqp_bodies.h, oracle/linmpc_ref.c): once the gap is below MPCQP_POLISH_MU the rows
+        // with λ > s are taken as the active set A and the equality-constrained QP on A is solved by Newton steps on its
+        // augmented Lagrangian (ρ = 1e10, exact residuals every round); the point is accepted with the KKT conditions of the
+        // inequality QP.  The four controllers of a wavefront share the instruction stream: an attempt is made when every
+        // unfinished one is ready for it (a ready controller iterates on for at most two more passes while it waits), so a
+        // wavefront pays for one attempt, not four.
+        {
+            const bool want = (MPCQP_SMALL_POLISH_Y || !HASY) && !done && !norows && !(d.flags & 16u) && mu <= polmu_next && rpn <= MPCQP_POLISH_RP * nh && npol < 4;
+            waited = want ? waited + 1 : 0;
+            if (w.any(want) && (!w.any(!done && !want) || w.any(want && waited >= 3))) {
+                constexpr double rho = 1e10;
+                const bool A0 = want && p0 && l0 > s0, A1 = want && p1 && l1 > s1, A2 = want && p2 && l2 > s2, A3 = want && p3 && l3 > s3;
+                bool yA0[KYM], yA1[KYM];
+                double lp0 = A0 ? l0 : 0.0, lp1 = A1 ? l1 : 0.0, lp2 = A2 ? l2 : 0.0, lp3 = A3 ? l3 : 0.0;
+                double ylp0[KYM], ylp1[KYM], yr0[KYM], yr1[KYM];
+                mhe::sfor<KYM>([&](auto iq) {
+                    constexpr int q = decltype(iq)::v;
+                    yA0[q] = HASY && want && yp0[q] && yl0[q] > ys0[q]; yA1[q] = HASY && want && yp1[q] && yl1[q] > ys1[q];
+                    ylp0[q] = yA0[q] ? yl0[q] : 0.0; ylp1[q] = yA1[q] ? yl1[q] : 0.0;
+                    yr0[q] = yA0[q] ? rho : 0.0; yr1[q] = yA1[q] ? rho : 0.0;
+                });
+                Row Pp;
+                build_phi(A0 ? rho : 0.0, A1 ? rho : 0.0, A2 ? rho : 0.0, A3 ? rho : 0.0, yr0, yr1, Pp);
+                const bool run = op.gj(Pp, l) && want;
+                double zp = z, pg2 = 0.0, pg3 = 0.0, pgy[KYM], pze = 0.0, rpa_prev = 1e300;
+                mhe::sfor<KYM>([&](auto iq) { pgy[decltype(iq)::v] = 0.0; });
+                bool okp = false, gaveup = false;
+                for (int round = 0; round <= 8; ++round) {
+                    gmul(zp, pg2, pg3);
+                    if constexpr (HASY) { ymul(zp, pgy); pze = epsof(zp); }
+                    const double ra0 = A0 ? -zp - h0 : 0.0, ra1 = A1 ? zp - h1 : 0.0, ra2 = A2 ? pg2 - h2 : 0.0, ra3 = A3 ? pg3 - h3 : 0.0;
+                    double yra0[KYM], yra1[KYM], yram = 0.0;
+                    mhe::sfor<KYM>([&](auto iq) {
+                        constexpr int q = decltype(iq)::v;
+                        yra0[q] = yA0[q] ? -pgy[q] - yc0(q) * pze - yh0(q) : 0.0;
+                        yra1[q] = yA1[q] ? pgy[q] - yc1(q) * pze - yh1(q) : 0.0;
+                        yram = fmax(yram, fmax(fabs(yra0[q]), fabs(yra1[q])));
+                    });
+                    const double rpan = w.rmax(fmax(fmax(fmax(fabs(ra0), fabs(ra1)), fmax(fabs(ra2), fabs(ra3))), yram));
+                    const double hzp = op.mv(H, zp);
+                    const double glp = (lp1 - lp0) + gtmul(lp2, lp3) + ytmul(ylp0, ylp1);
+                    const double gtv = isvar ? hzp + qv + glp : 0.0;
+                    const double rdn2 = w.rmax(fabs(gtv));
+                    const double ndd2 = w.rmax(isvar ? fmax(fabs(qv), fmax(fabs(hzp), fabs(glp))) : 0.0);
+                    if (run && !okp && !gaveup && rpan <= 1e-13 * nh && rdn2 <= 1e-14 * (1.0 + ndd2)) okp = true;
+                    // (a round that no longer contracts the residual of the active rows: dependent active rows, wrong set)
+                    if (round >= 2 && !(rpan < 0.25 * rpa_prev) && rpan > 1e-13 * nh) gaveup = true;
+                    rpa_prev = rpan;
+                    const bool go = run && !okp && !gaveup;
+                    if (round == 8 || !w.any(go)) break;
+                    const double c0 = rho * ra0, c1 = rho * ra1, c2 = rho * ra2, c3 = rho * ra3;
+                    double yc0v[KYM], yc1v[KYM];
+                    mhe::sfor<KYM>([&](auto iq) { constexpr int q = decltype(iq)::v; yc0v[q] = rho * yra0[q]; yc1v[q] = rho * yra1[q]; });
+                    const double gtc = gtmul(c2, c3) + ytmul(yc0v, yc1v);       // (every lane takes part in the mat-vecs)
+                    const double rhs = isvar ? -gtv - ((c1 - c0) + gtc) : 0.0;
+                    const double dzp = op.mv(Pp, rhs);
+                    double gd2, gd3, gdy[KYM], dze = 0.0;
+                    gmul(dzp, gd2, gd3);
+                    mhe::sfor<KYM>([&](auto iq) { gdy[decltype(iq)::v] = 0.0; });
+                    if constexpr (HASY) { ymul(dzp, gdy); dze = epsof(dzp); }
+                    if (go) {
+                        zp += dzp;
+                        if (A0) lp0 += rho * (ra0 - dzp);
+                        if (A1) lp1 += rho * (ra1 + dzp);
+                        if (A2) lp2 += rho * (ra2 + gd2);
+                        if (A3) lp3 += rho * (ra3 + gd3);
+                        mhe::sfor<KYM>([&](auto iq) {
+                            constexpr int q = decltype(iq)::v;
+                            if (yA0[q]) ylp0[q] += rho * (yra0[q] - gdy[q] - yc0(q) * dze);
+                            if (yA1[q]) ylp1[q] += rho * (yra1[q] + gdy[q] - yc1(q) * dze);
+                        });
+                    }
+                }
+                // KKT conditions of the inequality QP: multipliers >= 0 on A, the other rows feasible (G zp of the last round)
+                {
+                    double lm = fmax(fmax(fabs(lp0), fabs(lp1)), fmax(fabs(lp2), fabs(lp3)));
+                    mhe::sfor<KYM>([&](auto iq) { constexpr int q = decltype(iq)::v; lm = fmax(lm, fmax(fabs(ylp0[q]), fabs(ylp1[q]))); });
+                    const double ltol = -1e-12 * (1.0 + w.rmax(lm)), stol = -1e-11 * nh;
+                    bool bad = (A0 && lp0 < ltol) || (A1 && lp1 < ltol) || (A2 && lp2 < ltol) || (A3 && lp3 < ltol);
+                    bad = bad || (p0 && !A0 && h0 + zp < stol) || (p1 && !A1 && h1 - zp < stol) || (p2 && !A2 && h2 - pg2 < stol) || (p3 && !A3 && h3 - pg3 < stol);
+                    mhe::sfor<KYM>([&](auto iq) {
+                        constexpr int q = decltype(iq)::v;
+                        bad = bad || (yA0[q] && ylp0[q] < ltol) || (yA1[q] && ylp1[q] < ltol);
+                        bad = bad || (yp0[q] && !yA0[q] && yh0(q) + pgy[q] + yc0(q) * pze < stol) || (yp1[q] && !yA1[q] && yh1(q) - pgy[q] + yc1(q) * pze < stol);
+                    });
+                    const bool anybad = w.rmax(bad ? 1.0 : 0.0) > 0.0;
+                    okp = okp && !anybad;
+                }
+                if (want) { ++npol; polmu_next = 1e-2 * mu; waited = 0; }
+                if (okp) { z = zp; st = 0; done = true; it = pass + npol; polished = 1.0; }
+                if (!w.any(!done)) break;
+            }
+        }
+#endif
         // ---- Φ = H̃ + Gᵀ D̃ G, Φ⁻¹
         const RowD d0 = rowd(p0, s0, l0), d1 = rowd(p1, s1, l1), d2 = rowd(p2, s2, l2), d3 = rowd(p3, s3, l3);
         Row Phi;
-        // P̃u' (D̃2 + D̃3) P̃u without forming the product: entry (l, c) of two variables of the same input channel is the
-        // sum of D̃ over the intervals from the later of the two on, i.e. the suffix sum `suf` of the later one -- the
-        // lane's own for the columns up to its own, the column's lane's (row broadcast) for the later columns.
-        // (GU = 1 on the columns c <= l of the lane's channel, GUt = 1 on the columns c >= l: both include c = l.)
-        const double suf = op.mv(GUt, d2.Dt + d3.Dt);
-        // (Φ[l][c] = H̃ + GU[c] suf(l) + GUt[c] suf(c): the second product takes its left factor from lane c -- the row
-        //  broadcast is the multiply-add's own DPP modifier; both count the diagonal, taken out again with the box rows' D̃)
-        mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = fma(GU[c], suf, H[c]); });
-        mhe::sfor<NX / 4>([&](auto ij) {
-            constexpr int c = 4 * decltype(ij)::v;
-            w.template rank1bc4<c, c + 1, c + 2, c + 3>(Phi[c], Phi[c + 1], Phi[c + 2], Phi[c + 3], suf, GUt[c], GUt[c + 1], GUt[c + 2], GUt[c + 3]);
-        });
-        O::add_diag(Phi, l, d0.Dt + d1.Dt - (isdu ? suf : 0.0));
-        // ϵ row and column of a group of soft rows: the row (lane ϵ) takes the column vector `col` of the ΔU lanes across the
-        // row -- zero on the other lanes by construction --, every ΔU lane its own entry into column ϵ, lane ϵ the diagonal
-        const double meps = iseps ? 1.0 : 0.0;
-        auto eps_border = [&](double col, double dee) {
-            mhe::sfor<NX / 4>([&](auto ij) {
-                constexpr int c = 4 * decltype(ij)::v;
-                w.template rank1bc4<c, c + 1, c + 2, c + 3>(Phi[c], Phi[c + 1], Phi[c + 2], Phi[c + 3], col, meps, meps, meps, meps);
-            });
-            const double xe = iseps ? dee : (isdu ? col : 0.0);
-            mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] += (c == e) ? xe : 0.0; });
-        };
-        if (d.neps) {      // ϵ column / row: Φ[k][ϵ] = sum_j P̃u[j][k] (D̃2 cs0 - D̃3 cs1)_j,  Φ[ϵ][ϵ] += sum_j D̃2 cs0² + D̃3 cs1²
-            const double col = op.mv(GUt, d2.Dt * cs0 - d3.Dt * cs1);
-            const double dee = w.rsum(d2.Dt * cs0 * cs0 + d3.Dt * cs1 * cs1);
-            eps_border(col, dee);
-        }
         RowD yd0[KYM], yd1[KYM];
-        if constexpr (HASY) {      // + Ey' (D̃lo + D̃hi) Ey, the ϵ column Ey'(D̃lo c0 - D̃hi c1) and Φ[ϵ][ϵ] += sum D̃lo c0² + D̃hi c1²
-            double dee = 0.0;
-            mhe::sfor<KYM>([&](auto iq) {
-                constexpr int q = decltype(iq)::v;
-                yd0[q] = rowd(yp0[q], ys0[q], yl0[q]); yd1[q] = rowd(yp1[q], ys1[q], yl1[q]);
-                if (l + SMALL_RL * q < nR) {
-                    dv[yr[q]] = yd0[q].Dt + yd1[q].Dt;
-                    wv[yr[q]] = yd0[q].Dt * yc0(q) - yd1[q].Dt * yc1(q);
-                }
-                dee += yd0[q].Dt * yc0(q) * yc0(q) + yd1[q].Dt * yc1(q) * yc1(q);
-            });
-            w.sync();
-            double col = 0.0;
-            const int lc = isvar ? l : 0;
-            auto rank1 = [&](int r, double el, double dr, double wr, const Row& Er) {
-                el = isdu ? el : 0.0;
-                const double tt = el * dr;
-                col = fma(el, wr, col);
-                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Phi[c] = fma(tt, Er[c], Phi[c]); });
-            };
-            int r = 0;
-            for (; r + 2 <= nR; r += 2) {          // two rows in flight: the loads of both are issued before either update
-                Row Ea, Eb;
-                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; Eb[c] = Ed[(r + 1) * NX + c]; });
-                const double ela = Ed[r * NX + lc], elb = Ed[(r + 1) * NX + lc], da = dv[r], db = dv[r + 1], wa = wv[r], wb = wv[r + 1];
-                rank1(r, ela, da, wa, Ea);
-                rank1(r + 1, elb, db, wb, Eb);
-            }
-            for (; r < nR; ++r) {
-                Row Ea;
-                mhe::sfor<NX>([&](auto ic) { constexpr int c = decltype(ic)::v; Ea[c] = Ed[r * NX + c]; });
-                rank1(r, Ed[r * NX + lc], dv[r], wv[r], Ea);
-            }
-            if (d.neps) eps_border(col, w.rsum(dee));
-            w.sync();
-        }
+        double ydt0[KYM], ydt1[KYM];
+        mhe::sfor<KYM>([&](auto iq) {
+            constexpr int q = decltype(iq)::v;
+            yd0[q] = rowd(HASY && yp0[q], ys0[q], yl0[q]); yd1[q] = rowd(HASY && yp1[q], ys1[q], yl1[q]);
+            ydt0[q] = yd0[q].Dt; ydt1[q] = yd1[q].Dt;
+        });
+        build_phi(d0.Dt, d1.Dt, d2.Dt, d3.Dt, ydt0, ydt1, Phi);
         const bool ok = op.gj(Phi, l);
         if (!done && !ok) { st = 2; done = true; }
         // ---- predictor, corrector
@@ -572,7 +691,7 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
             if (io.iters) io.iters[b] = it;                          // factorisations (0: closed form, no finite row)
             if (io.audit) {
                 double* au = io.audit + (size_t)b * 4;
-                au[0] = mu_seen; au[1] = rd_seen; au[2] = rpn / nh; au[3] = 0.0;     // (no polish in this kernel)
+                au[0] = mu_seen; au[1] = rd_seen; au[2] = rpn / nh; au[3] = polished;
             }
         }
     }

@@ -86,8 +86,6 @@ struct EmuWave {
         acc = fma(rowbc<L0>(x0), -y0, acc); acc = fma(rowbc<L1>(x1), -y1, acc);
         acc = fma(rowbc<L2>(x2), -y2, acc); acc = fma(rowbc<L3>(x3), -y3, acc);
     }
-    template <int C>
-    double rowbc_after_asm(double v) { return rowbc<C>(v); }
     template <int K>
     void gjacc4(double& a0, double& a1, double& a2, double& a3, double g) {
         const double b0 = rowbc<K>(a0), b1 = rowbc<K>(a1), b2 = rowbc<K>(a2), b3 = rowbc<K>(a3);
