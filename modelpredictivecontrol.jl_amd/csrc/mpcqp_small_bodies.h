@@ -26,7 +26,13 @@
 #include "mpcqp_types.h"
 
 #ifndef MPCQP_SMALL_POLISH
-#define MPCQP_SMALL_POLISH 1      // active-set polish of the interior-point iterate, one attempt per wavefront (step_small_body)
+#define MPCQP_SMALL_POLISH 1      // active-set polish of the interior-point iterate, one attempt per wavefront (step_small_body<.., POL = true>):
+                                  // C2, 65536 controllers: 13.7 -> 9.9 factorisations, 1.09 -> 0.98 ms.  Not in the one-wave-per-SIMD variant: a launch of
+                                  // <= 4096 controllers lasts as long as its slowest wavefront, and that one pays for failed attempts on top of its
+                                  // interior-point passes (1024 controllers: 0.088 ms without, 0.109 ms with polish)
+#endif
+#ifndef MPCQP_SMALL_POLISH_WAIT
+#define MPCQP_SMALL_POLISH_WAIT 0  // passes a ready controller waits for the others of its wavefront before the attempt is made without them (0: for ever)
 #endif
 #ifndef MPCQP_SMALL_POLISH_Y
 #define MPCQP_SMALL_POLISH_Y 0     // ... of the variant with dense rows: measured slower (C2 shapes with soft ymax, 65536: 4.55 -> 5.09 ms although 12.4 -> 10.7 iterations: a round costs two passes over the dense rows in LDS)
@@ -56,7 +62,9 @@ MPCQP_HD inline size_t small_group_doubles(const Dims& d, bool hasy) {
 MPCQP_HD inline size_t small_lds_doubles(const Dims& d, bool hasy = false) { return (size_t)SMALL_GPW * small_group_doubles(d, hasy); }
 
 // KYS: Y-row slots per lane (0: the variant without output-bound rows; 2, 3, 4: nY <= 16 KYS)
-template <class W, int NX, int KYS = 0>
+// POL: with the active-set polish (the throughput variant k_step_small; the grids of at most one wavefront per SIMD and the dense-row
+// variant run without it, see MPCQP_SMALL_POLISH)
+template <class W, int NX, int KYS = 0, bool POL = false>
 MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO& io, int wg, double* smem) {
     constexpr bool HASY = KYS > 0;
     using O = mhe::Ops<W, NX>;
@@ -93,8 +101,17 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         const bool rconst = d.flags & 1u;
         for (int r = l; r < nY; r += SMALL_RL) {
             const int t = r / ny, a = r - t * ny;
+            // (loads in batches of four, requested before the first of them is used: a dependent chain of single loads costs
+            //  one memory latency each -- the set-up was 20 of the 90 us of a C2 step at 1024 controllers)
             double acc = Bv[r];
-            for (int k = 0; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
+            {
+                int k = 0;
+                for (; k + 4 <= nx; k += 4) {
+                    const double k0 = K[(size_t)k * nY + r], k1 = K[(size_t)(k + 1) * nY + r], k2 = K[(size_t)(k + 2) * nY + r], k3 = K[(size_t)(k + 3) * nY + r];
+                    acc += k0 * x0[k]; acc += k1 * x0[k + 1]; acc += k2 * x0[k + 2]; acc += k3 * x0[k + 3];
+                }
+                for (; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
+            }
             for (int cc = 0; cc < nu; ++cc) acc += Stab[(t * ny + a) * nu + cc] * lu[cc];
             if (nd > 0) {
                 const double* Gd = m.Gdtab + (size_t)b * Hp * ny * nd;
@@ -153,12 +170,33 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
     if (isdu) {
         const int t0 = jl(jme);
         double acc = 0.0;
-        for (int t = t0; t < Hp; ++t)
-            for (int a = 0; a < ny; ++a) acc += Stab[((t - t0) * ny + a) * nu + cme] * cyv[t * ny + a];
-        const double* Ld = m.Ldiag + (size_t)b * d.nU;
-        for (int t = t0; t < Hp; ++t) {
-            const double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cme] : 0.0;
-            acc += Ld[t * nu + cme] * (lu[cme] - ru);
+        {
+            // rows (t, a), t >= t0, are the contiguous range i = (t - t0) ny + a of the table column and of cy
+            const int n = (Hp - t0) * ny;
+            const double* Sp = Stab + cme;
+            const double* cp = cyv + t0 * ny;
+            double a1_ = 0.0, a2_ = 0.0, a3_ = 0.0;
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                const double v0 = Sp[i * nu], v1 = Sp[(i + 1) * nu], v2 = Sp[(i + 2) * nu], v3 = Sp[(i + 3) * nu];
+                const double v4 = Sp[(i + 4) * nu], v5 = Sp[(i + 5) * nu], v6 = Sp[(i + 6) * nu], v7 = Sp[(i + 7) * nu];
+                acc = fma(v0, cp[i], acc); a1_ = fma(v1, cp[i + 1], a1_); a2_ = fma(v2, cp[i + 2], a2_); a3_ = fma(v3, cp[i + 3], a3_);
+                acc = fma(v4, cp[i + 4], acc); a1_ = fma(v5, cp[i + 5], a1_); a2_ = fma(v6, cp[i + 6], a2_); a3_ = fma(v7, cp[i + 7], a3_);
+            }
+            for (; i < n; ++i) acc = fma(Sp[i * nu], cp[i], acc);
+            acc += (a1_ + a2_) + a3_;
+        }
+        const double* Ld = m.Ldiag + (size_t)b * d.nU + cme;
+        const double* Rup = io.Ru ? io.Ru + (size_t)b * d.nU + cme : nullptr;
+        {
+            int t = t0;
+            for (; t + 4 <= Hp; t += 4) {
+                const double e0 = Ld[t * nu], e1 = Ld[(t + 1) * nu], e2 = Ld[(t + 2) * nu], e3 = Ld[(t + 3) * nu];
+                double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+                if (Rup) { r0 = Rup[t * nu]; r1 = Rup[(t + 1) * nu]; r2 = Rup[(t + 2) * nu]; r3 = Rup[(t + 3) * nu]; }
+                acc += e0 * (lu[cme] - r0); acc += e1 * (lu[cme] - r1); acc += e2 * (lu[cme] - r2); acc += e3 * (lu[cme] - r3);
+            }
+            for (; t < Hp; ++t) acc += Ld[t * nu] * (lu[cme] - (Rup ? Rup[t * nu] : 0.0));
         }
         qv = 2.0 * acc;
     }
@@ -280,13 +318,25 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         const int t0 = jl(jme), t1 = (jme + 1 < Hc) ? jl(jme + 1) : Hp;
         wt = (double)(t1 - t0);                   // multiplicity of the merged row (barrier weight)
         if (m.U0min) {
+            const double* p = m.U0min + (size_t)b * d.nU + cme;
             double v = -INFINITY;
-            for (int t = t0; t < t1; ++t) v = fmax(v, m.U0min[(size_t)b * d.nU + t * nu + cme]);
+            int t = t0;
+            for (; t + 4 <= t1; t += 4) {
+                const double v0 = p[t * nu], v1 = p[(t + 1) * nu], v2 = p[(t + 2) * nu], v3 = p[(t + 3) * nu];
+                v = fmax(fmax(v, v0), fmax(fmax(v1, v2), v3));
+            }
+            for (; t < t1; ++t) v = fmax(v, p[t * nu]);
             h2 = -v + lu[cme];
         }
         if (m.U0max) {
+            const double* p = m.U0max + (size_t)b * d.nU + cme;
             double v = INFINITY;
-            for (int t = t0; t < t1; ++t) v = fmin(v, m.U0max[(size_t)b * d.nU + t * nu + cme]);
+            int t = t0;
+            for (; t + 4 <= t1; t += 4) {
+                const double v0 = p[t * nu], v1 = p[(t + 1) * nu], v2 = p[(t + 2) * nu], v3 = p[(t + 3) * nu];
+                v = fmin(fmin(v, v0), fmin(fmin(v1, v2), v3));
+            }
+            for (; t < t1; ++t) v = fmin(v, p[t * nu]);
             h3 = v - lu[cme];
         }
     } else if (iseps) {
@@ -461,12 +511,11 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
         // with λ > s are taken as the active set A and the equality-constrained QP on A is solved by Newton steps on its
         // augmented Lagrangian (ρ = 1e10, exact residuals every round); the point is accepted with the KKT conditions of the
         // inequality QP.  The four controllers of a wavefront share the instruction stream: an attempt is made when every
-        // unfinished one is ready for it (a ready controller iterates on for at most two more passes while it waits), so a
-        // wavefront pays for one attempt, not four.
+        // unfinished one is ready for it (a ready controller iterates on while it waits: measured on C2, an attempt costs two
+        // passes, so a wavefront should pay for one attempt, not for one per controller).
         {
-            const bool want = (MPCQP_SMALL_POLISH_Y || !HASY) && !done && !norows && !(d.flags & 16u) && mu <= polmu_next && rpn <= MPCQP_POLISH_RP * nh && npol < 4;
-            waited = want ? waited + 1 : 0;
-            if (w.any(want) && (!w.any(!done && !want) || w.any(want && waited >= 3))) {
+            const bool want = POL && (MPCQP_SMALL_POLISH_Y || !HASY) && !done && !norows && !(d.flags & 16u) && mu <= polmu_next && rpn <= MPCQP_POLISH_RP * nh && npol < 4;
+            if (w.any(want) && (!w.any(!done && !want) || (MPCQP_SMALL_POLISH_WAIT > 0 && w.any(want && ++waited >= MPCQP_SMALL_POLISH_WAIT)))) {
                 constexpr double rho = 1e10;
                 const bool A0 = want && p0 && l0 > s0, A1 = want && p1 && l1 > s1, A2 = want && p2 && l2 > s2, A3 = want && p3 && l3 > s3;
                 bool yA0[KYM], yA1[KYM];
@@ -506,6 +555,9 @@ MPCQP_HD void step_small_body(W& w, const Dims& d, const Model& m, const StepIO&
                     if (round >= 2 && !(rpan < 0.25 * rpa_prev) && rpan > 1e-13 * nh) gaveup = true;
                     rpa_prev = rpan;
                     const bool go = run && !okp && !gaveup;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(MPCQP_DEBUG_POLISH)
+                    if (l == 0) printf("  small polish wg %d g %d pass %d round %d want %d run %d rpan %.3e rdn2 %.3e (tol %.1e) okp %d gaveup %d\n", wg, g, pass, round, (int)want, (int)run, rpan, rdn2, 1e-14 * (1.0 + ndd2), (int)okp, (int)gaveup);
+#endif
                     if (round == 8 || !w.any(go)) break;
                     const double c0 = rho * ra0, c1 = rho * ra1, c2 = rho * ra2, c3 = rho * ra3;
                     double yc0v[KYM], yc1v[KYM];

@@ -30,7 +30,7 @@ namespace mhe {
 template <int NX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_SMALL_WAVES, 8))) void k_step_small(Dims d, Model m, StepIO io) {
     mhe::MheDevWave w{(int)threadIdx.x};
-    step_small_body<mhe::MheDevWave, NX, 0>(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
+    step_small_body<mhe::MheDevWave, NX, 0, true>(w, d, m, io, (int)blockIdx.x, mpcqp_smem);
 }
 // the same on a one-wave-per-SIMD register budget (no spills): for grids that leave most of the chip idle anyway -- up to one
 // wavefront per SIMD, i.e. B <= 4096 on 256 CUs, where nothing else would hide the scratch round trips of the spilled registers

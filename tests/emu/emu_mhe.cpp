@@ -177,7 +177,14 @@ hipError_t launch_step_small(const Dims& d, const Model& m, const StepIO& io, hi
             default: MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d, true), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 4>(w, d, m, io, wv, sm); })); break;
         }
     } else {
-        MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 0>(w, d, m, io, wv, sm); }));
+        // the product runs the variant with the active-set polish on grids beyond one wavefront per SIMD; here: unless
+        // MPCQP_EMU_SMALL_POLISH=0 (the tests run both)
+        const char* e = getenv("MPCQP_EMU_SMALL_POLISH");
+        if (e && e[0] == '0') {
+            MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 0>(w, d, m, io, wv, sm); }));
+        } else {
+            MHE_DISPATCH(NXv, run_waves(grid, small_lds_doubles(d), [&](EmuWave& w, int wv, double* sm) { step_small_body<EmuWave, NX, 0, true>(w, d, m, io, wv, sm); }));
+        }
     }
     return hipSuccess;
 }

@@ -362,12 +362,37 @@ def test_dense_weight_matrices_on_cpu_emulator(emulib, which):
 
 
 @pytest.mark.slow
-def test_small_problem_kernel_on_cpu_emulator(emulib):
-    """csrc/mpcqp_small_bodies.h (four controllers per wavefront for nZ̃ <= 16) vs the oracle."""
+@pytest.mark.parametrize("polish", ["1", "0"])
+def test_small_problem_kernel_on_cpu_emulator(emulib, polish, monkeypatch):
+    """csrc/mpcqp_small_bodies.h (four controllers per wavefront for nZ̃ <= 16) vs the oracle: the variant with the active-set
+    polish (the product's kernel for grids beyond one wavefront per SIMD) and the one without (small grids)."""
     from tests.parity_util import small_kernel_cases
+    monkeypatch.setenv("MPCQP_EMU_SMALL_POLISH", polish)
     worst, kinds = small_kernel_cases(lib=emulib, B=4)          # one wavefront per case
     assert worst <= 1e-6, worst
     assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
+
+
+def test_small_problem_kernel_polish_ends_most_solves_on_cpu_emulator(emulib, monkeypatch):
+    """The polish of the small-problem kernel on C2 instances: it must end the solves (audit record: polished) about four
+    factorisations earlier than the interior-point iteration alone, at the same optimum as the oracle's C port."""
+    from mpcqp import synth
+    from oracle import cport
+    from tests.parity_util import make_controller
+    cfg = synth.C2
+    bt = synth.make_batch(cfg, 32, seed=0)
+    Zc, _, stc, _ = cport.from_synth(cfg, bt).step(bt["xhat0"], bt["lastu0"], bt["ry"])
+    its = {}
+    for polish in ("1", "0"):
+        monkeypatch.setenv("MPCQP_EMU_SMALL_POLISH", polish)
+        mpc = make_controller(cfg, bt, lib=emulib, cold_start=True)
+        mpc.lastu0 = bt["lastu0"].copy()
+        mpc.moveinput(bt["xhat0"], bt["ry"])
+        assert mpc.kernel == mpcqp.api.KERNEL_SMALL and np.all(mpc.status == 0) and np.all(stc == 0)
+        nDU = cfg.nu * cfg.Hc
+        assert np.max(np.abs(mpc.Z[:, :nDU] - Zc[:, :nDU])) <= 1e-9
+        its[polish] = mpc.iters.mean()
+    assert its["1"] <= its["0"] - 2.0, its
 
 
 def test_small_problem_kernel_with_output_bounds_on_cpu_emulator(emulib):
