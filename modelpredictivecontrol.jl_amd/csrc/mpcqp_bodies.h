@@ -379,13 +379,27 @@ struct Qp {
     MPCQP_HD int jl(int j) const { return d.default_nb ? j : jlt[j]; }
     MPCQP_HD int blk(int t) const { return d.default_nb ? (t < d.Hc - 1 ? t : d.Hc - 1) : blkt[t]; }
 
+    // dst(i, g[i]) for i < n, eight loads of a lane in flight: `for (i = lane; i < n; i += WAVE) dst(i, g[i])` compiles to one
+    // conditional block per trip -- load, wait, store, one memory latency each (the set-up of a C3 step was 50 us of its 460,
+    // round 5).  The loads here are unconditional (index clamped to 0: n >= 1) and all requested before the first is used.
+    template <class Fn>
+    MPCQP_HD void stage(const double* g, int n, Fn dst) {
+        constexpr int NB = 8;
+        for (int i0 = 0; i0 < n; i0 += NB * WAVE) {
+            double v[NB];
+            MPCQP_UNROLL
+            for (int q_ = 0; q_ < NB; ++q_) { const int i = i0 + w.lane + WAVE * q_; v[q_] = g[i < n ? i : 0]; }
+            MPCQP_UNROLL
+            for (int q_ = 0; q_ < NB; ++q_) { const int i = i0 + w.lane + WAVE * q_; if (i < n) dst(i, v[q_]); }
+        }
+    }
+
     MPCQP_HD void load_tables() {
         const int nb_ = d.ny * d.nu, ns = d.Hp * nb_;
-        const double* g = m.Stab + (size_t)b * ns;
-        for (int i = w.lane; i < ns; i += WAVE) {
+        stage(m.Stab + (size_t)b * ns, ns, [&](int i, double v) {
             const int blk_ = i / nb_, e = i - blk_ * nb_, a = e / d.nu;
-            S[blk_ * sp + a * rs + (e - a * d.nu)] = g[i];
-        }
+            S[blk_ * sp + a * rs + (e - a * d.nu)] = v;
+        });
         for (int i = w.lane; i < zpad_S(d) * sp; i += WAVE) sm[c.S + i] = 0.0;
         if (!d.default_nb) {
             for (int i = w.lane; i <= d.Hc; i += WAVE) jlt[i] = m.jl[i];
@@ -393,8 +407,7 @@ struct Qp {
         }
         if (pair_on(P_X) && m.exT) {      // (K2 of a specialisation with terminal rows runs before they are built)
             const int ne = d.Hc * d.nxh * d.nu;
-            const double* e = m.exT + (size_t)b * ne;
-            for (int i = w.lane; i < ne; i += WAVE) sm[c.exT + i] = e[i];
+            stage(m.exT + (size_t)b * ne, ne, [&](int i, double v) { sm[c.exT + i] = v; });
         }
         if constexpr (has_w<DM>()) {
             if (pair_on(P_W)) {
@@ -1566,8 +1579,18 @@ struct Step {
         for (int r = w.lane; r < nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
             double acc = Bv[r];
-            MPCQP_UNROLL4
-            for (int k = 0; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
+            {
+                // (the row's entries of K in batches of eight loads: see QP::stage)
+                int k = 0;
+                for (; k + 8 <= nx; k += 8) {
+                    double kv[8];
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 8; ++u) kv[u] = K[(size_t)(k + u) * nY + r];
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 8; ++u) acc += kv[u] * x0[k + u];
+                }
+                for (; k < nx; ++k) acc += K[(size_t)k * nY + r] * x0[k];
+            }
             const double* Sb = qp.S + t * qp.sp + a * qp.rs;    // V block t = Σ_t
             for (int cc = 0; cc < nu; ++cc) acc += Sb[cc] * lu[cc];
             if (nd > 0) {
@@ -1625,9 +1648,25 @@ struct Step {
                         acc += Lf[(t * nu + cc) + (size_t)d.nU * r2] * (lu[r2 % nu] - ru);
                     }
             } else {
-                for (int t = qp.jl(j); t < d.Hp; ++t) {
-                    const double ru = io.Ru ? io.Ru[(size_t)b * d.nU + t * nu + cc] : 0.0;
-                    acc += Ld[t * nu + cc] * (lu[cc] - ru);
+                // every step of the horizon is loaded (eight at a time), the steps before the block's first count zero: the trip
+                // count is the same for every lane and the loads do not wait for each other
+                const int t0 = qp.jl(j);
+                const double* Lp = Ld + cc;
+                const double* Rp = io.Ru ? io.Ru + (size_t)b * d.nU + cc : nullptr;
+                const double luc = lu[cc];
+                for (int tb = 0; tb < d.Hp; tb += 8) {
+                    double lv[8], rv[8];
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = tb + u < d.Hp ? tb + u : d.Hp - 1;
+                        lv[u] = Lp[t * nu];
+                        rv[u] = Rp ? Rp[t * nu] : 0.0;
+                    }
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = tb + u;
+                        acc += (t >= t0 && t < d.Hp) ? lv[u] * (luc - rv[u]) : 0.0;
+                    }
                 }
             }
             q[k] += 2.0 * acc;       // same lane wrote q[k] in Et_apply_add
@@ -1687,11 +1726,16 @@ struct Step {
                     const double* bd = (g & 1) ? m.U0max : m.U0min;
                     if (bd) {
                         const int j = k / nu, cc = k - j * nu;
-                        const int t1 = (j + 1 < d.Hc) ? qp.jl(j + 1) : d.Hp;
+                        const int t0 = qp.jl(j), t1 = (j + 1 < d.Hc) ? qp.jl(j + 1) : d.Hp;
+                        const double* bp = bd + (size_t)b * d.nU + cc;
                         double v = (g & 1) ? INFINITY : -INFINITY;
-                        for (int t = qp.jl(j); t < t1; ++t) {
-                            const double x = bd[(size_t)b * d.nU + t * nu + cc];
-                            v = (g & 1) ? fmin(v, x) : fmax(v, x);
+                        // eight steps at a time, the index clamped to the interval's last step (min / max do not mind a repeat)
+                        for (int tb = t0; tb < t1; tb += 8) {
+                            double xv[8];
+                            MPCQP_UNROLL
+                            for (int u = 0; u < 8; ++u) { const int t = tb + u < t1 ? tb + u : t1 - 1; xv[u] = bp[t * nu]; }
+                            MPCQP_UNROLL
+                            for (int u = 0; u < 8; ++u) v = (g & 1) ? fmin(v, xv[u]) : fmax(v, xv[u]);
                         }
                         bound = (g & 1) ? v - lu[cc] : -v + lu[cc];
                     }
