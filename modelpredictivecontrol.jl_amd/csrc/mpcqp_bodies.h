@@ -278,6 +278,17 @@ MPCQP_HD constexpr bool one_row_per_lane() {
     else return false;
 }
 
+// Ŷ-row slots per lane whose output weights a one-row-per-lane kernel keeps in registers (Step::hwy_; 0: not cached)
+template <class DM>
+MPCQP_HD constexpr int hwq_() {
+    if constexpr (DM::is_static) {
+        constexpr int n = (DM::nY + WAVE - 1) / WAVE;
+        return (DM::nZ <= WAVE && n <= 4) ? n : 0;
+    } else {
+        return 0;
+    }
+}
+
 template <class DM>
 MPCQP_HD inline int stride_S(const DM& d) {
     if constexpr (DM::is_static) return DM::sp;
@@ -1417,6 +1428,17 @@ struct Step {
     bool fold_H = false;
     bool h_Lnz = false;       // some L weight of this controller is non-zero
     double h2n_ = 0.0, h2l_ = 0.0;      // one row per lane: lane k's 2 N_k (2 C on the slack's lane) and 2 sum_{t in block(k)} L_t
+    // 2 M_r of this lane's Ŷ rows r = lane + 64 q (one row per lane: read once in init_fold_H; the assembly asked global memory
+    // for them in every factorisation, one conditional block and one drained vmcnt per row)
+    static constexpr int HWQ = hwq_<DM>();
+    double hwy_[HWQ > 0 ? HWQ : 1] = {0.0};
+    MPCQP_HD static constexpr bool hwy_cached() { return hwq_<DM>() > 0; }
+    MPCQP_HD double hwy(int k) const {            // k = lane + 64 q
+        double v = hwy_[0];
+        MPCQP_UNROLL
+        for (int q_ = 1; q_ < HWQ; ++q_) v = (k >= WAVE * q_) ? hwy_[q_] : v;
+        return v;
+    }
 
     MPCQP_HD Step(Qp<W, DM>& qp_)
         : qp(qp_), w(qp_.w), d(qp_.d), m(qp_.m), b(qp_.b), sm(qp_.sm), c(qp_.c),
@@ -1932,17 +1954,36 @@ struct Step {
     MPCQP_HD double H2L_load(int k) const {
         if (k >= d.nDU) return 0.0;
         const int j = k / d.nu, cc = k - j * d.nu;
-        const int t1 = (j + 1 < d.Hc) ? qp.jl(j + 1) : d.Hp;
+        const int t0 = qp.jl(j), t1 = (j + 1 < d.Hc) ? qp.jl(j + 1) : d.Hp;
+        const double* Lp = m.Ldiag + (size_t)b * d.nU + cc;
         double acc = 0.0;
-        for (int t = qp.jl(j); t < t1; ++t) acc += m.Ldiag[(size_t)b * d.nU + t * d.nu + cc];
+        for (int tb = t0; tb < t1; tb += 8) {           // eight loads in flight (QP::stage)
+            double lv[8];
+            MPCQP_UNROLL
+            for (int u = 0; u < 8; ++u) { const int t = tb + u < t1 ? tb + u : t1 - 1; lv[u] = Lp[t * d.nu]; }
+            MPCQP_UNROLL
+            for (int u = 0; u < 8; ++u) acc += (tb + u < t1) ? lv[u] : 0.0;
+        }
         return 2.0 * acc;
     }
     MPCQP_HD double H2L(int k) const { return one_row_per_lane<DM>() ? h2l_ : H2L_load(k); }
     MPCQP_HD void init_fold_H() {
         double lmx = 0.0;
-        for (int k = w.lane; k < d.nDU; k += WAVE) lmx = fmax(lmx, fabs(H2L_load(k)));
+        if (one_row_per_lane<DM>()) {
+            h2l_ = H2L_load(w.lane);
+            h2n_ = H2N_load(w.lane);
+            lmx = fabs(h2l_);
+        } else {
+            for (int k = w.lane; k < d.nDU; k += WAVE) lmx = fmax(lmx, fabs(H2L_load(k)));
+        }
         h_Lnz = w.maxv(lmx) > 0.0;
-        if (one_row_per_lane<DM>()) { h2n_ = H2N_load(w.lane); h2l_ = H2L_load(w.lane); }
+        if (hwy_cached()) {
+            const double* Md = m.Mdiag + (size_t)b * d.nY;
+            MPCQP_UNROLL
+            for (int q_ = 0; q_ < HWQ; ++q_) { const int r = w.lane + WAVE * q_; hwy_[q_] = 2.0 * Md[r < d.nY ? r : 0]; }
+            MPCQP_UNROLL
+            for (int q_ = 0; q_ < HWQ; ++q_) { const int r = w.lane + WAVE * q_; hwy_[q_] = r < d.nY ? hwy_[q_] : 0.0; }
+        }
         fold_H = MPCQP_FOLD_H && !m.Mblk && !m.Mfull && !m.Ndense && !m.Ldense && qp.pair_on(P_Y) && d.nDU <= WAVE &&
                  (qp.pair_on(P_U) || !h_Lnz);
         if (fold_H) {           // pads of the packed layout hold zero from here on (load_H used to bring them)
@@ -1958,7 +1999,8 @@ struct Step {
         double* tY = sm + c.tA[P_Y];
         if (!Ez_ready) { qp.E_apply(z, tY); w.sync(); }
         const double* Md = m.Mdiag + (size_t)b * d.nY;
-        for (int r = w.lane; r < d.nY; r += WAVE) tY[r] *= Md[r];
+        if (hwy_cached()) { for (int r = w.lane; r < d.nY; r += WAVE) tY[r] *= 0.5 * hwy(r); }
+        else { for (int r = w.lane; r < d.nY; r += WAVE) tY[r] *= Md[r]; }
         for (int k = w.lane; k < d.nZ; k += WAVE) rd[k] = 0.0;
         w.sync();
         qp.Et_apply_add(tY, rd, 2.0);                       // (lane k owns rd[k])
@@ -2014,7 +2056,7 @@ struct Step {
             if (r1 && fin(*r1)) { dmax = dd(*r1); cmax = r1->cs; }
             double hw = 0.0;        // H̃'s own term of this primitive (fold_H)
             if (fold_H) {
-                if (p == P_Y) hw = k < d.nY ? 2.0 * m.Mdiag[(size_t)b * d.nY + k] : 0.0;
+                if (p == P_Y) hw = hwy_cached() ? hwy(k) : (k < d.nY ? 2.0 * m.Mdiag[(size_t)b * d.nY + k] : 0.0);
                 else if (p == P_U) hw = H2L(k);
             }
             sm[c.tA[p] + k] = dmin + dmax + hw;
