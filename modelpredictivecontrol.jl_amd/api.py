@@ -117,11 +117,12 @@ def _check_hip_runtime(lib):
 
 
 def load_library(path: str | None = None):
-    """Load (once) the HIP shared library.  `path` is for tests only."""
+    """Load (once) the HIP shared library.  `path` is for tests only; the environment variable MPCQP_LIB names another build
+    of the same library (developer A/B runs of bench.py, scripts/build_variant.sh)."""
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or DEFAULT_LIB
+    path = path or os.environ.get("MPCQP_LIB") or DEFAULT_LIB
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: the HIP extension is not built (run `python -c 'import "
