@@ -382,7 +382,9 @@ def secondary(args, local):
     #  spec_manifest.txt with several rows per lane; VERDICT r2 item 5 quotes this shape at B = 8192)
     # (fourth record: C2 dimensions with C3's constraint pattern -- soft ymax + hard umin / umax -- i.e. output-bound rows on
     #  the small-problem kernel, k_step_small_y)
-    for name, B in (("C2", 1024), ("C2", 65536), ("12,3,3,40,35", 8192), ("4,2,2,20,5", 65536)):
+    # (fifth record: nZ~ = 151, three rows per lane -- beyond the nZ~ = 128 the on-demand specialisations stopped at before
+    #  round 5; VERDICT r4 item 5 asked for a record in this range)
+    for name, B in (("C2", 1024), ("C2", 65536), ("12,3,3,40,35", 8192), ("4,2,2,20,5", 65536), ("12,3,3,50,50", 4096)):
         cfg = synth.get_config(name)
         sh = Shard(cfg, 0, B, args.seed, local)
         elapsed, kern_ms = timed_run(sh, args.steps, args.warmup, None)
@@ -393,7 +395,7 @@ def secondary(args, local):
         kms = float(np.mean(kern_ms))
         ach = flops * B / (kms * 1e-3) / 1e12
         pk = {("C2", 1024): "k_step_small_w1_12", ("C2", 65536): "k_step_small_12", ("12,3,3,40,35", 8192): "k_step_s_nZ106",
-              ("4,2,2,20,5", 65536): "k_step_small_y_12"}[(name, B)]
+              ("4,2,2,20,5", 65536): "k_step_small_y_12", ("12,3,3,50,50", 4096): "k_step_s_nZ151"}[(name, B)]
         tr_, trs_ = committed_traffic(pk, B)
         recs.append({"workload": cfg.name, "batch": B, "metric": "QP solves/sec (moveinput!)", "value": B * args.steps / elapsed,
                      "unit": "solves/s", "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kms,

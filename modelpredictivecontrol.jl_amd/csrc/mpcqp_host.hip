@@ -266,6 +266,11 @@ int mpcqp_get_sizes(mpcqp_handle h, mpcqp_sizes* out) {
 
 static bool terminal_on(const Dims& d) { return (d.gmask >> (2 * P_X)) & 3u; }
 
+// the condensed kernels keep one problem's tables in the LDS of a CU: a handle whose problem does not fit (nZ~ beyond ~185 at
+// C3-like shapes) has no condensed Hessian and no condensed step -- MPCQP_ERR_UNSUPPORTED from the step / mpcqp_get, the
+// MultipleShooting transcription is the way to run it
+static bool condensed_fits(const Dims& d) { return step_lds_bytes(d) <= 160 * 1024; }
+
 static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
     const Dims& d = h->d;
     if (!h->have_model || h->stage_only) return MPCQP_OK;
@@ -285,7 +290,7 @@ static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
     HIPCHK(launch_predmat(d, h->m, term, st));
     h->terminal_built = term;
     if (timed) HIPCHK(hipEventRecord(h->ev_cm, st));       // between K1 (prediction tables) and K2 (Hessian)
-    if (h->have_weights) HIPCHK(launch_hessian(d, h->m, st));
+    if (h->have_weights && condensed_fits(d)) HIPCHK(launch_hessian(d, h->m, st));
     if (timed) { HIPCHK(hipEventRecord(h->ev_c1, st)); h->cond_timed = true; }
     return MPCQP_OK;
 }
@@ -332,7 +337,7 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
     h->m.Ldiag = (const double*)h->Ldiag.p;
     h->m.Cwt = d.neps ? (const double*)h->Cwt.p : nullptr;
     h->have_weights = true;
-    if (h->have_model && !h->stage_only) {
+    if (h->have_model && !h->stage_only && condensed_fits(d)) {
         HIPCHK(launch_hessian(d, h->m, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -351,7 +356,7 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
     } else {
         h->m.Mblk = nullptr;
     }
-    if (h->have_model && !h->stage_only) {
+    if (h->have_model && !h->stage_only && condensed_fits(d)) {
         HIPCHK(launch_hessian(d, h->m, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -376,7 +381,7 @@ int mpcqp_set_dense_weights(mpcqp_handle h, const double* M_Hp, const double* N_
         }
     }
     d.dense_w = (h->m.Mfull || h->m.Ldense) ? 1 : 0;     // (a dense N_Hc only changes H̃: any step kernel serves it)
-    if (h->have_model && !h->stage_only) HIPCHK(launch_hessian(d, h->m, h->stream));
+    if (h->have_model && !h->stage_only && condensed_fits(d)) HIPCHK(launch_hessian(d, h->m, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -574,7 +579,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     const Dims& d = h->d;
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
-    if (!uses_stage_kernel(h) && step_lds_bytes(d) > 160 * 1024) return MPCQP_ERR_UNSUPPORTED;
+    if (!uses_stage_kernel(h) && !condensed_fits(d)) return MPCQP_ERR_UNSUPPORTED;
     ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     StepIO io{};
@@ -717,7 +722,7 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
     std::vector<double> tmp;
     switch (which) {
         case MPCQP_GET_HESSIAN: {
-            if (h->stage_only) return MPCQP_ERR_UNSUPPORTED;       // (nothing is condensed for nZ~ > 256)
+            if (h->stage_only || !condensed_fits(d)) return MPCQP_ERR_UNSUPPORTED;       // (nothing is condensed for nZ~ > 256; no Hessian kernel beyond the LDS)
             if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
             int rc = fetch(h->m.Hpk, B * d.npk, tmp);
             if (rc) return rc;

@@ -295,7 +295,8 @@ static bool jit_enabled() {
 // beyond one row per lane the specialisation keeps the several-rows-per-lane factorisation of the runtime dims but has
 // the matrix-core E'DE, register rows and constant trip counts)
 #ifndef MPCQP_SPEC_NZMAX
-#define MPCQP_SPEC_NZMAX 128
+#define MPCQP_SPEC_NZMAX 256      // (round 5: 128 before.  Whatever fits the LDS -- nZ~ up to ~185 -- gets its specialisation: nZ~ = 141 ... 161 run 3.6 - 4.3
+                                  //  times faster than on the runtime-dimension kernel, 450 - 470 VGPRs at one wavefront per SIMD, compiled in ~50 s)
 #endif
 static bool spec_eligible(const Dims& d) {
     return d.nZ <= MPCQP_SPEC_NZMAX;

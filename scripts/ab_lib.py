@@ -15,7 +15,8 @@ for path in sys.argv[1:]:
     hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt) if np.isfinite(cfg.Cwt) else None)
     full = lambda v, n: None if not np.isfinite(v) else np.full((B, n), float(v))
     hd.set_bounds(U0min=full(cfg.umin, hd.nU), U0max=full(cfg.umax, hd.nU), DUmin=full(cfg.dumin, hd.nDU), DUmax=full(cfg.dumax, hd.nDU),
-                  Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY))
+                  Y0min=full(cfg.ymin, hd.nY), Y0max=full(cfg.ymax, hd.nY),
+                  **({'C_ymax': np.ones((B, hd.nY)), 'C_ymin': np.ones((B, hd.nY))} if os.environ.get('AB_SOFT') else {}))   # AB_SOFT=1: explicit softness arrays
     hd.prepare()
     Z = np.zeros((B, hd.nZ)); ms = []
     for rep in range(4):

@@ -12,6 +12,7 @@ os.makedirs(dst, exist_ok=True)
 KERNELS = [
     (r"k_step_s<.*StaticDims<4, 4, 16, 30, 10", "k_step_s_C3", "QP solves (C3, B = 65536)", 65536, 4192),
     (r"k_step_s<.*StaticDims<3, 3, 15, 40, 35", "k_step_s_nZ106", "QP solves (nu = ny = 3, Hp = 40, Hc = 35, B = 8192)", 8192, None),
+    (r"k_step_s<.*StaticDims<3, 3, 15, 50, 50", "k_step_s_nZ151", "QP solves (nu = ny = 3, Hp = Hc = 50, B = 4096)", 4096, None),
     (r"k_step_small_w1<12", "k_step_small_w1_12", "QP solves (C2, B = 1024)", 1024, None),
     (r"k_step_small<12", "k_step_small_12", "QP solves (C2, B = 65536)", 65536, None),
     (r"k_step_small_y<12", "k_step_small_y_12", "QP solves (C2 dims, soft ymax + hard u, B = 65536)", 65536, None),

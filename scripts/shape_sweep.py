@@ -29,7 +29,11 @@ for pat in pats:
         cfg = dataclasses.replace(synth.get_config(name), **PATTERNS[pat])
         name = f"{pat}:{name}"
         from tests.parity_util import shape_vs_cport
-        r = shape_vs_cport(cfg, B)
+        try:
+            r = shape_vs_cport(cfg, B)
+        except mpcqp.api.MpcqpError as e:          # (a problem that does not fit the LDS: MPCQP_ERR_UNSUPPORTED)
+            print(f"{name:>20} {e}", flush=True)
+            continue
         # (a single ill-conditioned instance may sit 1e-4 from the C port at equal objective: the 99 % quantile decides, the
         #  maximum is printed; the small-problem kernel has no polish: about one iteration more)
         ok = (r["kind"] in (1, 2, 3) and r["optimal"] == 1.0 and r["optimal_cport"] == 1.0 and r["err99"] <= 1e-5 and

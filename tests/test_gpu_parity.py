@@ -22,15 +22,12 @@ TOL = 1e-5
 
 def assert_specialised(kinds):
     """Every handle of a family ran on the kernel its shape is entitled to: a specialisation (ahead-of-time, on-demand
-    or the small-problem kernel) up to nZ~ = 128, the runtime-dimension kernel beyond.  An on-demand kernel that
+    or the small-problem kernel) whatever its size (round 5: up to nZ~ = 128 before, the runtime-dimension kernel beyond).  An on-demand kernel that
     mpcqp_prepare rejected would show up here as KERNEL_GENERIC (round 3: a rejected object passed its family test on
     the fallback); conftest.py also turns the library's fallback warning into an error for every GPU test."""
     assert kinds, "the family did not report its kernel"
     for kind, nZ in kinds:
-        if nZ <= 128:
-            assert kind in (mpcqp.api.KERNEL_AOT, mpcqp.api.KERNEL_ONDEMAND, mpcqp.api.KERNEL_SMALL), (kind, nZ)
-        else:
-            assert kind == mpcqp.api.KERNEL_GENERIC, (kind, nZ)
+        assert kind in (mpcqp.api.KERNEL_AOT, mpcqp.api.KERNEL_ONDEMAND, mpcqp.api.KERNEL_SMALL), (kind, nZ)
 
 
 @pytest.mark.parametrize("name,B", [("C2", 256), ("C3", 192)])
@@ -109,10 +106,12 @@ def test_slack_row_of_shapes_with_nDU_a_multiple_of_16(name, hiplib):
 
 
 @pytest.mark.parametrize("name,pattern", [("4,1,1,16,16", "c3"), ("6,2,3,32,31", "c3"), ("6,3,3,21,21", "all"), ("6,2,2,40,32", "yband"),
-                                          ("8,4,4,24,20", "c3"), ("8,3,2,45,42", "all"), ("8,5,4,20,16", "box")])
+                                          ("8,4,4,24,20", "c3"), ("8,3,2,45,42", "all"), ("8,5,4,20,16", "box"),
+                                          ("12,3,3,50,50", "c3"), ("12,2,2,70,70", "all")])
 def test_shapes_and_constraint_patterns_against_the_c_port(name, pattern, hiplib):
     """A few hundred instances per shape on its on-demand specialisation (nZ~ = 17 .. 127, around the one-row-per-lane
-    limit, 16-multiples of nu*Hc, four constraint patterns) against the oracle's C port: every instance optimal, the
+    limit, 16-multiples of nu*Hc, four constraint patterns; nZ~ = 151 and 141: beyond the 128 the specialisations stopped at
+    before round 5, three rows per lane) against the oracle's C port: every instance optimal, the
     same optimum (99 % quantile; a single ill-conditioned instance may sit further at equal objective), the same number
     of iterations -- what a handful of instances per family cannot show (scripts/shape_sweep.py, profiles/r3/)."""
     import dataclasses
