@@ -354,6 +354,13 @@ static int build_spec(const Dims& d, std::string* path_out, std::string* err) {
     // beyond one row per lane the LDS footprint (Phi alone is 47 KB at nZ~ = 106) leaves at most one wavefront per SIMD:
     // the kernel may as well use the whole register file (row state of several rows per lane in registers, no spills)
     if (d.nZ > WAVE) argv.push_back("-DMPCQP_STEP_WAVES=1");
+    // `#pragma unroll` gives up beyond 16k unrolled instructions (LLVM's pragma-unroll-threshold): from eight tile rows on
+    // (nZ~ >= ~113) a loop over the tile rows stayed rolled, its accumulator / pointer arrays went to scratch memory and every
+    // LDS and global access of the kernel became a flat one -- found in round 5 from the counters of the nZ~ = 151 kernel
+    // (23 LDS instructions per solve).  With the threshold lifted: nZ~ = 125 24.3 -> 15.5 ms, 151 37.3 -> 23.7 ms, 161 39.4 ->
+    // 25.8 ms per 2048 controllers (no scratch, no flat access); smaller shapes compile to the same code.
+    argv.push_back("-mllvm");
+    argv.push_back("-pragma-unroll-threshold=1048576");
     if (d.dense_w) argv.push_back("-DMPCQP_SPEC_DENSE=1");
     if (d.nw > 0) argv.push_back("-DMPCQP_SPEC_NW=" + std::to_string(d.nw));
     if (const char* extra = getenv("MPCQP_JIT_FLAGS")) {
