@@ -325,7 +325,9 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
 #define MPCQP_KERNEL_ONDEMAND  2
 #define MPCQP_KERNEL_SMALL     3   /* nZ~ <= 16 with box, input-bound and (<= 64 in all) output-bound / terminal rows: four controllers per wavefront
                                     * (csrc/mpcqp_small_bodies.h); a step that fuses the Kalman steps (mpcqp_loop_device)
-                                    * runs on the kernel the other rules select */
+                                    * runs on the kernel the other rules select, and so does a handle WITH output-bound / terminal
+                                    * rows of at most 1024 controllers when its own specialisation is available (measured 1.5 times
+                                    * faster there; MPCQP_SMALL_Y=1 keeps it on this kernel) */
 #define MPCQP_KERNEL_MS        4   /* MultipleShooting handles (mpcqp_set_transcription): the stage-structured kernel
                                     * (csrc/ms_bodies.h): Riccati recursion over the horizon, H̃ and E never formed */
 int mpcqp_prepare(mpcqp_handle h);

@@ -269,6 +269,7 @@ static bool terminal_on(const Dims& d) { return (d.gmask >> (2 * P_X)) & 3u; }
 // the condensed kernels keep one problem's tables in the LDS of a CU: a handle whose problem does not fit (nZ~ beyond ~185 at
 // C3-like shapes) has no condensed Hessian and no condensed step -- MPCQP_ERR_UNSUPPORTED from the step / mpcqp_get, the
 // MultipleShooting transcription is the way to run it
+static bool aot_or_generic_other(const Dims& d) { return step_kernel_kind_other(d) == MPCQP_KERNEL_AOT; }
 static bool condensed_fits(const Dims& d) { return step_lds_bytes(d) <= 160 * 1024; }
 
 static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
@@ -985,7 +986,9 @@ int mpcqp_prepare(mpcqp_handle h) {
     int kind = prepare_step(h->d, h->m, &g_build_err);
     // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
     // it with the runtime-dimension kernel once; needs the model and weights (BatchLinMPC prepares before its first step)
-    const bool ondemand = kind == MPCQP_KERNEL_ONDEMAND || (kind == MPCQP_KERNEL_SMALL && step_kernel_kind_other(h->d) == MPCQP_KERNEL_ONDEMAND);
+    // (a handle of the small-problem kernel has its specialisation verified too: steps that ask for Ŷ or fuse the Kalman steps
+    //  run on it, and so do the dense-row handles of small batches -- mpcqp_kernels.hip: small_takes)
+    const bool ondemand = kind == MPCQP_KERNEL_ONDEMAND || (kind == MPCQP_KERNEL_SMALL && !aot_or_generic_other(h->d) && spec_present(h->d));
     if (ondemand && !spec_verified(h->d) && h->have_model && h->have_weights &&
         step_lds_bytes(h->d) <= 160 * 1024) {
         ON_DEVICE(h);
@@ -997,6 +1000,7 @@ int mpcqp_prepare(mpcqp_handle h) {
         const double tol = tol_env ? atof(tol_env) : 1e-6;
         if (worst <= tol) {
             mark_spec_verified(h->d);
+            if (kind == MPCQP_KERNEL_SMALL) kind = step_kernel_kind(h->d, h->m);      // (a small batch with dense rows moves to it)
         } else {
             reject_spec(h->d);
             g_build_err = "the on-demand specialisation disagrees with the runtime-dimension kernel (relative difference " +

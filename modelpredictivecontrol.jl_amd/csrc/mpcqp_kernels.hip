@@ -422,8 +422,21 @@ static bool aot_matches(const Dims& d) {
 
 // Which kernel a step of `d` runs on: 0 the runtime-dimension kernel, 1 an ahead-of-time
 // specialisation, 2 an on-demand one (already loaded or loadable from the cache).
+// The small-problem kernel takes the step -- unless it is its dense-row variant on a grid of the latency regime (at most one
+// controller per SIMD as one-per-wavefront grid: B <= 1024) and the handle's own specialisation is there: measured on C2
+// dimensions with a soft ymax (40 dense rows; scripts/small_vs_wave.py 4,2,2,20,5), one controller per wavefront with the
+// matrix-core assembly and the polish is 1.5 times faster at B <= 1024 (0.25 against 0.38 ms), the two tie from 4096 on.
+// MPCQP_SMALL_Y=1 keeps the dense-row variant whatever the batch (tests of that kernel).
+static bool small_takes(const Dims& d, const Model& m, const StepIO& io) {
+    if (force_generic() || !small_eligible(d, m, io)) return false;
+    const char* e = getenv("MPCQP_SMALL_Y");           // (read at every call: tests switch it inside one process)
+    const bool keep_y = e && e[0] == '1';
+    if (small_has_y(d) && !keep_y && d.B <= 1024 && ((!d.dense_w && aot_matches(d)) || find_verified_spec(d))) return false;
+    return true;
+}
+
 int step_kernel_kind(const Dims& d, const Model& m) {
-    if (!force_generic() && small_eligible(d, m, StepIO{})) return 3;
+    if (small_takes(d, m, StepIO{})) return 3;
     return step_kernel_kind_other(d);
 }
 
@@ -454,7 +467,7 @@ static int prepare_step_other(const Dims& d, std::string* err) {
 int prepare_step(const Dims& d, const Model& m, std::string* err) {
     // (the kernel behind the small one is prepared as well: steps that ask for Ŷ or fuse the Kalman steps run on it)
     const int other = prepare_step_other(d, err);
-    return (!force_generic() && small_eligible(d, m, StepIO{})) ? 3 : other;
+    return small_takes(d, m, StepIO{}) ? 3 : other;
 }
 
 // compile only (no device, no load): for build pipelines
@@ -467,6 +480,8 @@ int prebuild_step(const Dims& d, std::string* err) {
 // A freshly built specialisation is checked once against the runtime-dimension kernel (mpcqp_prepare, host side)
 // before it is trusted: `<object>.ok` records that it passed, a failing object is renamed `<object>.bad` and never
 // loaded again (the local hipcc builds these kernels: a compiler that miscompiles them must not go unnoticed).
+bool spec_present(const Dims& d) { return !force_generic() && jit_enabled() && spec_eligible(d) && find_spec(d, true) != nullptr; }
+
 bool spec_verified(const Dims& d) {
     const SpecLib* sl = find_spec(d, true);
     if (!sl) return false;
@@ -540,7 +555,7 @@ hipError_t launch_hessian(const Dims& d, const Model& m, hipStream_t st) {
 }
 
 hipError_t launch_step(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
-    if (!force_generic() && small_eligible(d, m, io)) return launch_step_small(d, m, io, st);
+    if (small_takes(d, m, io)) return launch_step_small(d, m, io, st);
     return launch_step_spec_or_aot(d, m, io, st);
 }
 

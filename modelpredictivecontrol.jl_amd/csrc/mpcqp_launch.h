@@ -20,6 +20,7 @@ int prepare_step(const Dims& d, const Model& m, std::string* err);     // compil
 int prebuild_step(const Dims& d, std::string* err);    // compile only; -1 on failure
 // one-time check of an on-demand kernel against the runtime-dimension kernel (see mpcqp_prepare)
 bool spec_verified(const Dims& d);
+bool spec_present(const Dims& d);      // an on-demand object of this shape is loaded / loadable (verified or not)
 void mark_spec_verified(const Dims& d);
 void reject_spec(const Dims& d);
 hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, hipStream_t st);

@@ -98,6 +98,7 @@ int step_kernel_kind_other(const Dims&) { return 0; }
 int prepare_step(const Dims& d, const Model& m, std::string*) { return small_eligible(d, m, StepIO{}) ? 3 : 0; }
 int prebuild_step(const Dims&, std::string*) { return 0; }
 bool spec_verified(const Dims&) { return true; }
+bool spec_present(const Dims&) { return false; }
 void mark_spec_verified(const Dims&) {}
 void reject_spec(const Dims&) {}
 hipError_t launch_step_generic(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) { return launch_step(d, m, io, st); }

@@ -719,9 +719,10 @@ def test_rejected_specialisation_falls_back_to_generic_kernel(hiplib, tmp_path, 
 
 
 @pytest.mark.parametrize("which", [("N",), ("M",), ("L",), ("M", "N", "L")], ids=["N_Hc", "M_Hp", "L_Hp", "all"])
-def test_dense_weight_matrices_on_gpu(hiplib, which):
+def test_dense_weight_matrices_on_gpu(hiplib, which, monkeypatch):
     """Full Hermitian M_Hp (coupling prediction steps), N_Hc, L_Hp through the C-ABI vs the oracle (ΔU and J)."""
     from tests.parity_util import dense_weight_case
+    monkeypatch.setenv("MPCQP_SMALL_Y", "1")      # (the dense-N case on the small-problem kernel whatever the batch size)
     worst, kind = dense_weight_case(B=5, which=which)
     assert worst <= TOL, worst
     # (a dense M_Hp / L_Hp handle gets an on-demand variant of its own that carries the dense gradient products,
@@ -753,15 +754,27 @@ def test_small_problem_kernel_on_gpu(hiplib):
     assert kinds == [mpcqp.api.KERNEL_SMALL] * 4
 
 
-def test_small_problem_kernel_with_output_bounds_on_gpu(hiplib):
+def test_small_problem_kernel_with_output_bounds_on_gpu(hiplib, monkeypatch):
     """Output-bound rows on the small-problem kernel (k_step_small_y: soft band with an active ϵ, hard horizon-long bound
     with +-Inf holes, soft y + soft u, ymin with move blocking, soft and hard terminal rows): every member vs the oracle, rows on
-    their bounds."""
+    their bounds.  (MPCQP_SMALL_Y=1: at this batch size the handle's own specialisation would take the steps, see below.)"""
     from tests.parity_util import small_kernel_cases
+    monkeypatch.setenv("MPCQP_SMALL_Y", "1")
     worst, kinds, yact = small_kernel_cases(B=9, with_y=True)
     assert worst <= TOL, worst
     assert kinds == [mpcqp.api.KERNEL_SMALL] * 6
     assert all(n > 0 for n, _ in yact) and max(e for _, e in yact) > 1e-3, yact
+
+
+def test_small_batches_with_output_bounds_take_their_specialisation(hiplib, monkeypatch):
+    """Round 5: with dense rows and at most 1024 controllers (one per SIMD as one-controller-per-wavefront grid) the handle's
+    own specialisation is 1.5 times faster than the four-per-wavefront kernel's dense-row variant (scripts/small_vs_wave.py):
+    the same cases as above run on it, with the same answers."""
+    from tests.parity_util import small_kernel_cases
+    monkeypatch.delenv("MPCQP_SMALL_Y", raising=False)
+    worst, kinds, yact = small_kernel_cases(B=9, with_y=True)
+    assert worst <= TOL, worst
+    assert kinds == [mpcqp.api.KERNEL_ONDEMAND] * 6, kinds
 
 
 def test_small_problem_kernel_with_soft_ymax_full_batch(hiplib):
