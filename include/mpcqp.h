@@ -143,7 +143,9 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
  * Size: a SingleShooting handle with nZ̃ = nu Hc + nϵ > 256 has no condensed kernel (its Newton matrix does not fit the
  * LDS); it runs the same QP on the stage-structured kernel, whose cost is linear in the horizons -- the reference has no
  * size limit (transcription.jl:2-4).  mpcqp_kernel_kind reports MPCQP_KERNEL_MS for it; the condensed tables
- * (MPCQP_GET_HESSIAN, _STEPRESP, _KMAT, _BVEC) do not exist for such a handle (MPCQP_ERR_UNSUPPORTED). */
+ * (MPCQP_GET_HESSIAN, _STEPRESP, _KMAT, _BVEC) do not exist for such a handle (MPCQP_ERR_UNSUPPORTED).  The same holds for a
+ * handle of nZ̃ <= 256 whose condensed problem does not fit the 160 KB of LDS of a CU (nZ̃ beyond ~165 at nu = ny = 3 ... 4): its
+ * steps run on the stage-structured kernel (MPCQP_KERNEL_MS), its prediction tables exist, its packed Hessian does not. */
 #define MPCQP_SINGLE_SHOOTING    0
 #define MPCQP_MULTIPLE_SHOOTING  1
 int mpcqp_set_transcription(mpcqp_handle h, int32_t transcription);

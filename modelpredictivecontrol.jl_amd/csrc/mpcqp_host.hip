@@ -533,7 +533,11 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
 }
 
 // the handle is routed to the stage-structured kernel: asked for (MultipleShooting), or the condensed kernels cannot take it
-static bool uses_stage_kernel(mpcqp_handle h) { return h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only || h->stage_rows; }
+// (round 5: also a condensed problem of nZ~ <= 256 that does not fit the LDS of a CU -- nZ~ beyond ~165 at C3-like shapes -- whatever
+//  its transcription: the SAME QP, solved in stage form)
+static bool uses_stage_kernel(mpcqp_handle h) {
+    return h->transcription == MPCQP_MULTIPLE_SHOOTING || h->stage_only || h->stage_rows || !condensed_fits(h->d);
+}
 
 // 0 when the MultipleShooting kernel takes this handle; else the reason (bit mask): 1 dense weight matrices, 2 custom
 // linear constraints, 4 the stage data does not fit the 160 KB of LDS, 8 flags of the condensed kernels only

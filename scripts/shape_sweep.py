@@ -36,8 +36,9 @@ for pat in pats:
             continue
         # (a single ill-conditioned instance may sit 1e-4 from the C port at equal objective: the 99 % quantile decides, the
         #  maximum is printed; the small-problem kernel has no polish: about one iteration more)
-        ok = (r["kind"] in (1, 2, 3) and r["optimal"] == 1.0 and r["optimal_cport"] == 1.0 and r["err99"] <= 1e-5 and
-              abs(r["iters"] - r["iters_cport"]) <= (1.5 if r["kind"] == 3 else 1.0))
+        # (kind 4: a condensed problem beyond the LDS runs in stage form -- another iteration, the same optimum)
+        ok = (r["kind"] in (1, 2, 3, 4) and r["optimal"] == 1.0 and r["optimal_cport"] == 1.0 and r["err99"] <= 1e-5 and
+              abs(r["iters"] - r["iters_cport"]) <= (1.5 if r["kind"] in (3, 4) else 1.0))
         bad += not ok
         print(f"{name:>20} nZ {r['nZ']:3d} kind {r['kind']} ms {r['ms']:7.2f} optimal {r['optimal']:.4f} (C port {r['optimal_cport']:.4f}) "
               f"iters {r['iters']:5.2f} (C port {r['iters_cport']:5.2f}) rel dU diff 99 % {r['err99']:.1e} max {r['errmax']:.1e} {'ok' if ok else 'FAIL'}", flush=True)

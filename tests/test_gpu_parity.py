@@ -126,6 +126,17 @@ def test_shapes_and_constraint_patterns_against_the_c_port(name, pattern, hiplib
     assert abs(r["iters"] - r["iters_cport"]) <= 1.0, r
 
 
+def test_condensed_problem_beyond_the_lds_runs_in_stage_form(hiplib):
+    """nZ~ = 185 (nu = 4, Hc = Hp = 46): the condensed problem does not fit the 160 KB of LDS of a CU -- the handle keeps
+    its SingleShooting transcription and its steps run on the stage-structured kernel (round 5: MPCQP_ERR_UNSUPPORTED before),
+    same optimum as the oracle's C port."""
+    from tests.parity_util import shape_vs_cport
+    r = shape_vs_cport(synth.get_config("12,4,4,46,46"), B=64)
+    assert r["kind"] == mpcqp.api.KERNEL_MS, r
+    assert r["optimal"] >= 0.98 and r["optimal_cport"] == 1.0, r
+    assert r["err99"] <= TOL, r
+
+
 def test_full_size_properties_C3(hiplib):
     """BASELINE configs[2] at full size (B = 65536): size-independent properties."""
     cfg = synth.C3
