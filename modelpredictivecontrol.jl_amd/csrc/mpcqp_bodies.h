@@ -3607,8 +3607,10 @@ struct Step {
 
 template <class W, class DM>
 MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int b, double* sm) {
+    const long long t_in_ = Step<W, DM>::clock64_();
     Qp<W, DM> qp(w, d, m, b, sm);
     qp.load_tables();
+    const long long t_tab_ = Step<W, DM>::clock64_();
     // x̂0 of this period into LDS; with kf_y0m the SteadyKalmanFilter correction first
     // (correct_estimate_obsv!, src/estimator/kalman.jl:284-295; same arithmetic order as kf_correct_lane)
     {
@@ -3642,7 +3644,9 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
         }
     }
     Step<W, DM> st(qp);
+    const long long t_b0_ = Step<W, DM>::clock64_();
     st.build(io);
+    const long long t_b1_ = Step<W, DM>::clock64_();
     if ((d.flags & 4u) && io.q_keep) {
         for (int k = w.lane; k < d.nZ; k += WAVE) io.q_keep[(size_t)b * d.nZ + k] = st.q[k];
         for (int r = w.lane; r < d.nY; r += WAVE) io.F_keep[(size_t)b * d.nY + r] = st.F[r];
@@ -3654,6 +3658,12 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
     const int status = st.run(io, iters);
     if (io.prof) {
         st.prof_[15] = (double)(Step<W, DM>::clock64_() - t_run0);
+#ifdef MPCQP_PROFILE_SETUP      // (developer switch: the set-up of the step in the slots of the Newton sub-phases)
+        st.prof_[8] = (double)(t_tab_ - t_in_);       // table staging
+        st.prof_[9] = (double)(t_b0_ - t_tab_);       // x̂0 (+ Kalman correction), Step construction
+        st.prof_[10] = (double)(t_b1_ - t_b0_);       // build(): F, q̃, bounds, rows
+        st.prof_[11] = (double)(t_run0 - t_b1_);      // between build() and run()
+#endif
         if (w.lane == 0)
             for (int i = 0; i < 16; ++i) io.prof[(size_t)b * 16 + i] = st.prof_[i];
     }
