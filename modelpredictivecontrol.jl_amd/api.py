@@ -921,6 +921,12 @@ class BatchLinMPC:
                 else:
                     self._ms_kernel = True
             self.kernel = KERNEL_MS if self._ms_kernel else self.hd.prepare()
+            if self.kernel == KERNEL_MS and not self._ms_kernel and self.nZ <= 256 and self.hd.lds_bytes() > 160 * 1024:
+                # (the reroute used to be silent -- the condensed problem does not fit the LDS of a CU in the
+                #  carve-up of the runtime-dimension kernel; same QP, solved in stage form, an order of magnitude slower)
+                warnings.warn(f"mpcqp: the condensed problem (nZ̃ = {self.nZ}, {self.hd.lds_bytes()} B of LDS) does not fit one "
+                              "compute unit: the SingleShooting controller's steps run on the stage-structured "
+                              "(MultipleShooting) kernel", RuntimeWarning)
             self._ms_kernel = self.kernel == KERNEL_MS       # (also: nZ̃ > 256, which only the stage-structured kernel takes)
             self._prepared = True
         out = self.hd.step(xhat0, lastu0, (ry - self.yop) if held else (Rhaty - self.Yop), self.Z,

@@ -117,6 +117,21 @@
 #define MPCQP_ETDE_UNROLL 2
 #endif
 #endif
+// E'DE with the matrix-core operands in REGISTERS (round 6).  E is block-Toeplitz: the operand of tile column J at K step kk is
+// the operand of tile column 0 at K step kk - DJ J (DJ = K steps per 16 columns), so ONE vector V[0 .. NK-1] per lane -- read
+// from the Sigma table once per assembly -- serves every tile of every pass: the K loops become a straight stream of v_mul /
+// v_mfma with the row factors d streaming in behind it (NK + NK + (eps row) LDS reads per assembly instead of one per tile
+// column and K step, no address arithmetic, no selects in the loop).  Shapes: ny a multiple of 4, nu a divisor of 16, default
+// move blocking, NK = Hp ny / 4 <= MPCQP_ETDE_VREG_MAX (2 VGPRs per entry).  0: operands from LDS at every K step (rounds 1-5).
+#ifndef MPCQP_ETDE_VREG
+#define MPCQP_ETDE_VREG 1
+#endif
+#ifndef MPCQP_ETDE_VREG_MAX
+#define MPCQP_ETDE_VREG_MAX 32
+#endif
+#ifndef MPCQP_ETDE_VREG_CHUNK
+#define MPCQP_ETDE_VREG_CHUNK 4   // K steps per batch of row-factor loads (one batch in flight ahead of the matrix-core stream)
+#endif
 #ifndef MPCQP_HZ_UNROLL
 #define MPCQP_HZ_UNROLL 4         // terms per unrolled pass of the two loops of H~ z (dual_residual)
 #endif
@@ -762,6 +777,19 @@ struct Qp {
         // first block column (E is block lower triangular).
         constexpr int IE = NDU / 16, LE = NDU % 16;     // tile row / lane column of the ϵ row
         int eps_t0 = -1;
+        // operands in registers (MPCQP_ETDE_VREG): V[k] = operand of tile column 0 at K step k = (t, a0): Sigma(t - li / nu)[a0 + row, li % nu]
+        // (zero blocks in front of the table for t < li / nu)
+        constexpr int QK = NY % 4 == 0 ? NY / 4 : 1;                  // K steps per step of the horizon
+        constexpr int DJ = (16 % NU == 0) ? QK * (16 / NU) : 1;       // K steps by which a tile column's operands lag those of the one before
+        constexpr bool VREG = MPCQP_ETDE_VREG && NY % 4 == 0 && 16 % NU == 0 && DM::zpad > 0 && DM::zpad >= 16 / NU - 1 &&
+                              NK <= MPCQP_ETDE_VREG_MAX;
+        double V[VREG ? NK : 1];
+        if constexpr (VREG) {
+            const int cbv = li / NU, civ = li - cbv * NU;
+            const double* Vb = S - cbv * SP + lkp * RS + civ;
+            MPCQP_UNROLL
+            for (int k = 0; k < NK; ++k) V[k] = Vb[(k / QK) * SP + 4 * (k % QK) * RS];
+        }
         // (one instantiation per pass: with the pass index a run-time value -- a loop the compiler declines to unroll at
         // seven tile rows -- the accumulator arrays are indexed dynamically and end up in scratch memory)
         auto pass = [&](auto I0c) {
@@ -793,8 +821,10 @@ struct Qp {
                 return 8 * G * (G + 1) + 16 * J + 4 * (G + 1) * lk + li;
             };
             // H̃ in the accumulator layout, requested now and consumed by the write-back
+            // (register-operand form: requested after the K loop instead -- 24 more doubles live next to V, the accumulators and
+            //  the row state do not fit the two-waves budget; only block / dense weight handles come this way)
             double hreg[2][MAXT][4];
-            if (Hg) {
+            auto hload = [&]() {
                 MPCQP_UNROLL
                 for (int I = I0; I <= I1; ++I) {
                     MPCQP_UNROLL
@@ -804,7 +834,8 @@ struct Qp {
                             hreg[I - I0][J][reg] = Hg[entry_ok(I, J, reg) ? (unsigned)entry_idx(I, J, reg) : 0u];
                     }
                 }
-            }
+            };
+            if (Hg && !VREG) hload();
             // First K step at which tile row I sees a block column that has started (t >= j_l of
             // its first column); the ϵ row needs every step.  The K loop is split at these points
             // so that its bodies are branch-free (accumulators stay in place across iterations).
@@ -858,6 +889,50 @@ struct Qp {
                         acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, o.e[J], acc[I - I0][J], 0, 0, 0);
                 }
             };
+            if constexpr (VREG) {
+                // compile-time K ranges (default move blocking; with ny a multiple of 4 a tile row's first K step is a whole
+                // number of steps, so the ϵ row rides from there: kfirst() above gives the same values)
+                constexpr int kA_ = (DJ * I0 < NK) ? DJ * I0 : NK;
+                constexpr int kB_ = (I1 > I0) ? ((DJ * I1 < NK) ? DJ * I1 : NK) : NK;
+                if (erow) eps_t0 = (4 * ((DJ * IE < NK) ? DJ * IE : NK)) / NY;
+                constexpr int CH = MPCQP_ETDE_VREG_CHUNK;
+                constexpr bool EP = DM::neps != 0 && IE >= I0 && IE <= I1;      // the ϵ row can ride in this pass
+                double dvb[2][CH], tbb[2][EP ? CH : 1];
+                const double* ddl = dd + lkp;
+                const double* tbl = erow ? tb + lkp : dd + lkp;
+                auto ldc = [&](int c0, int buf) {
+                    MPCQP_UNROLL
+                    for (int u = 0; u < CH; ++u) {
+                        const int kk = c0 + u;
+                        if (kk >= NK) break;
+                        dvb[buf][u] = ddl[4 * kk];
+                        if constexpr (EP) { if (erow) tbb[buf][u] = tbl[4 * kk]; }
+                    }
+                };
+                ldc(kA_, 0);
+                MPCQP_UNROLL
+                for (int c0 = kA_; c0 < NK; c0 += CH) {
+                    const int buf = ((c0 - kA_) / CH) & 1;
+                    if (c0 + CH < NK) ldc(c0 + CH, buf ^ 1);
+                    MPCQP_SCHED_FENCE();
+                    MPCQP_UNROLL
+                    for (int u = 0; u < CH; ++u) {
+                        const int kk = c0 + u;
+                        if (kk >= NK) break;
+                        MPCQP_UNROLL
+                        for (int I = I0; I <= I1; ++I) {
+                            if (I > I0 && kk < kB_) continue;
+                            const bool eI = erow && I == IE;
+                            double ad = V[kk - DJ * I] * dvb[buf][u];
+                            if constexpr (EP) { if (eI && li == LE) ad = tbb[buf][u]; }
+                            MPCQP_UNROLL
+                            for (int J = 0; J <= I; ++J)
+                                acc[I - I0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, V[kk - DJ * J], acc[I - I0][J], 0, 0, 0);
+                        }
+                    }
+                    MPCQP_SCHED_FENCE();
+                }
+            } else {
             // (the request one step past the end reads whatever follows in LDS and is never used)
             constexpr bool PIPE = (NY % 4 == 0) && DM::zpad > 0;
             Ops cur, nxt;
@@ -874,6 +949,8 @@ struct Qp {
                     else { kload(kk, cur); kcomp(cur, true, true); }
                 }
             }
+            }
+            if (Hg && VREG) hload();
             if (ow) {
                 // plain stores of H̃ + scale acc (or scale acc alone) on the stored triangle
                 MPCQP_UNROLL

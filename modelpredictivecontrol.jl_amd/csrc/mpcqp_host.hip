@@ -33,6 +33,10 @@ struct mpcqp_handle_s {
     hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_cm = nullptr;
     bool step_timed = false, cond_timed = false;
     bool have_model = false, have_weights = false, terminal_built = false;
+    // Model::Hpk holds K2's result for the CURRENT tables and weights.  Cleared whenever an input of K2 changes or its
+    // launch is skipped (the problem did not fit the LDS at that moment: condensed_fits depends on the row groups, which
+    // set_bounds / set_custom_bounds may shrink later); ensure_hessian() launches K2 lazily wherever H~ is about to be read.
+    bool hessian_valid = false;
     std::vector<int> nb, jl, blk;
     std::vector<void*> owned;
     // model / weights / bounds storage
@@ -266,11 +270,22 @@ int mpcqp_get_sizes(mpcqp_handle h, mpcqp_sizes* out) {
 
 static bool terminal_on(const Dims& d) { return (d.gmask >> (2 * P_X)) & 3u; }
 
-// the condensed kernels keep one problem's tables in the LDS of a CU: a handle whose problem does not fit (nZ~ beyond ~185 at
-// C3-like shapes) has no condensed Hessian and no condensed step -- MPCQP_ERR_UNSUPPORTED from the step / mpcqp_get, the
+// the condensed kernels keep one problem's tables in the LDS of a CU: a handle whose problem does not fit (nZ~ beyond ~165 at
+// C3-like shapes; the fit test is the carve-up of the runtime-dimension kernel, which mpcqp_prepare's comparison needs) has no condensed Hessian and no condensed step -- MPCQP_ERR_UNSUPPORTED from the step / mpcqp_get, the
 // MultipleShooting transcription is the way to run it
 static bool aot_or_generic_other(const Dims& d) { return step_kernel_kind_other(d) == MPCQP_KERNEL_AOT; }
 static bool condensed_fits(const Dims& d) { return step_lds_bytes(d) <= 160 * 1024; }
+
+// K2 for the handle's current tables and weights, or -- when it cannot run now -- the note that Hpk is stale
+static int refresh_hessian(mpcqp_handle h, hipStream_t st) {
+    h->hessian_valid = false;
+    if (h->have_model && h->have_weights && !h->stage_only && condensed_fits(h->d)) {
+        HIPCHK(launch_hessian(h->d, h->m, st));
+        h->hessian_valid = true;
+    }
+    return MPCQP_OK;
+}
+static int ensure_hessian(mpcqp_handle h, hipStream_t st) { return h->hessian_valid ? MPCQP_OK : refresh_hessian(h, st); }
 
 static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
     const Dims& d = h->d;
@@ -291,7 +306,7 @@ static int condense(mpcqp_handle h, hipStream_t st, bool timed) {
     HIPCHK(launch_predmat(d, h->m, term, st));
     h->terminal_built = term;
     if (timed) HIPCHK(hipEventRecord(h->ev_cm, st));       // between K1 (prediction tables) and K2 (Hessian)
-    if (h->have_weights && condensed_fits(d)) HIPCHK(launch_hessian(d, h->m, st));
+    { int rc = refresh_hessian(h, st); if (rc) return rc; }
     if (timed) { HIPCHK(hipEventRecord(h->ev_c1, st)); h->cond_timed = true; }
     return MPCQP_OK;
 }
@@ -338,9 +353,7 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
     h->m.Ldiag = (const double*)h->Ldiag.p;
     h->m.Cwt = d.neps ? (const double*)h->Cwt.p : nullptr;
     h->have_weights = true;
-    if (h->have_model && !h->stage_only && condensed_fits(d)) {
-        HIPCHK(launch_hessian(d, h->m, h->stream));
-    }
+    { int rc = refresh_hessian(h, h->stream); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -357,9 +370,7 @@ int mpcqp_set_output_weight_blocks(mpcqp_handle h, const double* Mblk) {
     } else {
         h->m.Mblk = nullptr;
     }
-    if (h->have_model && !h->stage_only && condensed_fits(d)) {
-        HIPCHK(launch_hessian(d, h->m, h->stream));
-    }
+    { int rc = refresh_hessian(h, h->stream); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -382,7 +393,7 @@ int mpcqp_set_dense_weights(mpcqp_handle h, const double* M_Hp, const double* N_
         }
     }
     d.dense_w = (h->m.Mfull || h->m.Ldense) ? 1 : 0;     // (a dense N_Hc only changes H̃: any step kernel serves it)
-    if (h->have_model && !h->stage_only && condensed_fits(d)) HIPCHK(launch_hessian(d, h->m, h->stream));
+    { int rc = refresh_hessian(h, h->stream); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -422,6 +433,7 @@ int mpcqp_set_custom_constraints(mpcqp_handle h, int nw, const double* Wy, const
         m.w_op = w_op ? (const double*)h->w_op.p : nullptr;
     }
     layout_rows(h);
+    { int rc = ensure_hessian(h, h->stream); if (rc) return rc; }      // (the row groups decide whether the problem fits the LDS)
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -464,6 +476,7 @@ int mpcqp_set_custom_bounds(mpcqp_handle h, const double* Wmin, const double* Wm
     if (m.Wmin) d.gmask |= 1u << (2 * P_W);
     if (m.Wmax) d.gmask |= 1u << (2 * P_W + 1);
     layout_rows(h);
+    { int rc = ensure_hessian(h, h->stream); if (rc) return rc; }      // (the row groups decide whether the problem fits the LDS)
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -528,6 +541,7 @@ int mpcqp_set_bounds(mpcqp_handle h, const mpcqp_bounds* bin) {
         int rc = condense(h, h->stream, false);
         if (rc) return rc;
     }
+    { int rc = ensure_hessian(h, h->stream); if (rc) return rc; }      // (the row groups decide whether the problem fits the LDS)
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
@@ -544,6 +558,7 @@ static bool uses_stage_kernel(mpcqp_handle h) {
 static int ms_unsupported(mpcqp_handle h) {
     int why = 0;
     if (h->m.Mfull || h->m.Ndense || h->m.Ldense) why |= 1;          // (a block-diagonal M_Hp, e.g. a terminal cost, is taken since round 5)
+    if (h->m.Mblk && h->d.ny > 4 * WAVE) why |= 1;                   // (the block-weight sweep of ms_bodies.h keeps a column in four registers per lane)
     if (h->d.nw > 0) why |= 2;
     if (ms_lds_bytes(h->d, h->m) > 160 * 1024) why |= 4;
     if (h->d.flags & (MPCQP_FLAG_KEEP_QP | MPCQP_FLAG_WARM_DUAL)) why |= 8;
@@ -584,7 +599,6 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     const Dims& d = h->d;
     if (d.nd > 0 && (!d0 || !Dhat0)) return MPCQP_ERR_NULL;
     if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
-    if (!uses_stage_kernel(h) && !condensed_fits(d)) return MPCQP_ERR_UNSUPPORTED;
     ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     StepIO io{};
@@ -650,6 +664,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
         Dims dm = d;
         HIPCHK(launch_ms_step(dm, h->m, io, ms, st));
     } else {
+        { int rc = ensure_hessian(h, st); if (rc) return rc; }      // (skipped while the problem did not fit the LDS: see hessian_valid)
         HIPCHK(launch_step(d, h->m, io, st));
     }
     HIPCHK(hipEventRecord(h->ev_s1, st));
@@ -729,7 +744,10 @@ int mpcqp_get(mpcqp_handle h, int which, double* out) {
         case MPCQP_GET_HESSIAN: {
             if (h->stage_only || !condensed_fits(d)) return MPCQP_ERR_UNSUPPORTED;       // (nothing is condensed for nZ~ > 256; no Hessian kernel beyond the LDS)
             if (!h->have_model || !h->have_weights) return MPCQP_ERR_ORDER;
-            int rc = fetch(h->m.Hpk, B * d.npk, tmp);
+            int rc = ensure_hessian(h, h->stream);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(h->stream));
+            rc = fetch(h->m.Hpk, B * d.npk, tmp);
             if (rc) return rc;
             for (size_t b = 0; b < B; ++b)
                 for (int i = 0; i < d.nZ; ++i)
@@ -987,6 +1005,7 @@ int mpcqp_prepare(mpcqp_handle h) {
         // as its steps are (mpcqp_step*: MPCQP_ERR_UNSUPPORTED) -- the answer is what the steps WILL do
         return ms_unsupported(h) ? MPCQP_ERR_UNSUPPORTED : MPCQP_KERNEL_MS;
     }
+    { ON_DEVICE(h); int rc = ensure_hessian(h, h->stream); if (rc) return rc; }
     int kind = prepare_step(h->d, h->m, &g_build_err);
     // an on-demand kernel that has not been checked yet (fresh build, or a cache some other process filled): compare
     // it with the runtime-dimension kernel once; needs the model and weights (BatchLinMPC prepares before its first step)
@@ -1062,6 +1081,13 @@ int mpcqp_prebuild(const mpcqp_dims* in, uint32_t row_groups) {
             if (in->nb[i] != (i == d.Hc - 1 ? d.Hp - d.Hc + 1 : 1)) d.default_nb = 0;
     g_build_err.clear();
     const int k = prebuild_step(d, &g_build_err);
+    // Kernel revision 10 (round 5) moved the row -eps <= 0 into a Y group when one exists: mpcqp_set_bounds no longer sets bit 0
+    // for it (C3: 0x8d -> 0x8c).  A manifest line written before that still compiles, but no handle matches the object unless
+    // it really has hard dUmin rows: say so (mpcqp_last_build_error) instead of leaving the deployment on the JIT silently.
+    if (k >= 0 && d.neps && (row_groups & 1u) && !(row_groups & 2u) && (row_groups & (3u << (2 * P_Y))) && g_build_err.empty())
+        g_build_err = "row_groups has bit 0 (box lower) together with an output-bound group and no box upper group: since kernel "
+                      "revision 10 the slack's own row rides in the output group, so only a controller with hard dUmin bounds "
+                      "and no dUmax matches this object -- a pre-revision-10 manifest line? (drop bit 0: e.g. 0x8d -> 0x8c)";
     return k < 0 ? MPCQP_ERR_DEVICE : k;
 }
 

@@ -395,7 +395,13 @@ static const SpecLib* find_spec(const Dims& d, bool load) {
     if (it != g_spec.end()) return it->second.step ? &it->second : nullptr;
     if (!load) return nullptr;
     const std::string so = locate_spec(d);
-    if (so.empty()) return nullptr;                              // not built (yet): nothing is remembered
+    if (so.empty()) {
+        // not built (yet).  The miss is remembered (a step of a small dense-row handle asked again at every launch --
+        // stat / opendir / readdir over the cache directories under g_spec_mu, and a dlopen inside a step once another
+        // process had filled the cache); mpcqp_prepare forgets it before it builds or looks again (prepare_step_other).
+        g_spec.emplace(key, SpecLib{});
+        return nullptr;
+    }
     SpecLib sl;
     void* hdl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (hdl) {
@@ -453,6 +459,11 @@ static int prepare_step_other(const Dims& d, std::string* err) {
     if (force_generic()) return 0;
     if (!d.dense_w && aot_matches(d)) return 1;
     if (!jit_enabled() || !spec_eligible(d)) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_spec_mu);            // a remembered miss (find_spec) is looked up again by a prepare
+        auto it = g_spec.find(spec_key(d));
+        if (it != g_spec.end() && !it->second.step) g_spec.erase(it);
+    }
     if (find_spec(d, true)) return 2;
     if (build_spec(d, nullptr, err) != 0) return 0;
     {

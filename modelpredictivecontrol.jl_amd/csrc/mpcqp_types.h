@@ -55,7 +55,7 @@
 
 // Revision of the kernel sources / device structs: part of the name of cached on-demand
 // specialisations, so that objects built from older sources are never loaded.
-#define MPCQP_KERNEL_REV 11       // 11: on-demand objects compiled with the pragma-unroll threshold lifted (no scratch arrays / flat accesses from eight tile rows on); 10: the row eps >= 0 rides in a Ŷ group (eps_host_group); 9: a blocked step (alpha < 1/2) no longer passes the last-step test; 8: MPCQP_FLAG_KEEP_ITERATE
+#define MPCQP_KERNEL_REV 12       // 12: matrix-core operands of E'DE in registers (MPCQP_ETDE_VREG); 11: on-demand objects compiled with the pragma-unroll threshold lifted (no scratch arrays / flat accesses from eight tile rows on); 10: the row eps >= 0 rides in a Ŷ group (eps_host_group); 9: a blocked step (alpha < 1/2) no longer passes the last-step test; 8: MPCQP_FLAG_KEEP_ITERATE
 
 namespace mpcqp {
 

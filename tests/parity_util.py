@@ -302,7 +302,7 @@ def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
 EXTRA_KW = None      # (experiments: extra BatchLinMPC keywords for run_random_case)
 
 
-def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, kinds=None, transcription="SingleShooting"):
+def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, kinds=None, transcription="SingleShooting", huge2=False):
     """One randomly drawn controller family (dimensions, move blocking, which bounds exist, hard /
     soft mix, terminal bounds, measured disturbance, Cwt finite or Inf) as a batch of B DIFFERENT
     controllers of that family -- every member has its own model, weights, operating points, bound
@@ -316,9 +316,11 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, k
     nx = int(rng.integers(2, 4 if small else 7)); nu = int(rng.integers(1, 3 if small else 5))
     ny = int(rng.integers(1, 3 if small else 4)); nd = int(rng.integers(0, 2))
     Hp = int(rng.integers(4, 9 if small else 24))
-    if huge:                                # beyond one row per lane: 64 < nZ~ <= ~130
+    if huge and not huge2:                  # beyond one row per lane: 64 < nZ~ <= ~130
         nu = int(rng.integers(2, 5)); Hp = int(rng.integers(32, 46))
         Hc = min(Hp, int(rng.integers(66, 130)) // nu)
+    elif huge2:                             # beyond two rows per lane: 130 < nZ~ <= 165 (round 6; three row slots per lane)
+        nu = int(rng.integers(3, 5)); Hc = int(rng.integers(131, 165)) // nu; Hp = Hc + int(rng.integers(0, 5))
     elif large:                             # close to the one-wavefront limit nZ~ = 64
         nu = int(rng.integers(2, 5)); Hp = int(rng.integers(16, 31))
         Hc = min(Hp, 63 // nu) - int(rng.integers(0, 3))
@@ -942,3 +944,53 @@ def varying_softness_case(lib=None, B=2):
         eps0 = o.Zt[-1] if eps0 is None else eps0
         x0 = Ah @ x0 + Bhu @ uo
     return worst, g.kernel, np.concatenate(sts), eps0
+
+
+def hessian_after_refit_case(lib=None, B=2, nu=4, ny=2, nx=3, Hp=40, seed=5):
+    """K2 is skipped while a handle's problem does not fit the LDS of a CU, and whether it fits depends
+    on the row groups.  The handle here gets bounds on every group (does not fit: stage-structured kernel), then its weights
+    (K2 skipped), then the bounds are reduced to the input bounds (fits: condensed kernel).  nΔU > 64, so the step reads the
+    packed H̃ -- which must have been computed by then.  Returns (kinds seen, lds bytes seen, worst relative ΔU difference to a
+    handle that was given the final bounds straight away, max |H̃ - H̃_fresh|)."""
+    rng = np.random.default_rng(seed)
+    nxh = nx + ny
+    def one():
+        lam = rng.uniform(0.5, 0.95, nx)
+        Q, _ = np.linalg.qr(rng.standard_normal((nx, nx)))
+        A = Q @ np.diag(lam) @ Q.T
+        Bu = rng.standard_normal((nx, nu)) / np.sqrt(nx); Cm = rng.standard_normal((ny, nx)) / np.sqrt(nx)
+        Ah = np.block([[A, np.zeros((nx, ny))], [np.zeros((ny, nx)), np.eye(ny)]])
+        return Ah, np.vstack([Bu, np.zeros((ny, nu))]), np.hstack([Cm, np.eye(ny)])
+    ms = [one() for _ in range(B)]
+    Ah, Bh, Ch = (np.stack([m[i] for m in ms]) for i in range(3))
+    Hc = Hp
+    x0 = 0.5 * rng.standard_normal((B, nxh)); lu = 0.1 * rng.standard_normal((B, nu)); ry = rng.standard_normal((B, ny)) * 2.0
+
+    def handle():
+        hd = mpcqp.Handle(B, nxh, nu, ny, 0, Hp, Hc, neps=1, flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_COLD_START, lib=lib)
+        hd.set_model(mpcqp.colmajor(Ah), mpcqp.colmajor(Bh), mpcqp.colmajor(Ch))
+        return hd
+    full = lambda v, n: np.full((B, n), float(v))
+    weights = lambda hd: hd.set_weights(np.full((B, hd.nY), 1.0), np.full((B, hd.nDU), 0.1), np.full((B, hd.nU), 0.05), np.full(B, 1e5))
+    final = lambda hd: hd.set_bounds(U0min=full(-0.4, hd.nU), U0max=full(0.4, hd.nU))
+    # the handle under test
+    hd = handle()
+    hd.set_bounds(U0min=full(-0.4, hd.nU), U0max=full(0.4, hd.nU), DUmin=full(-0.2, hd.nDU), DUmax=full(0.2, hd.nDU),
+                  Y0min=full(-3.0, hd.nY), Y0max=full(3.0, hd.nY), C_dumin=full(1.0, hd.nDU), C_dumax=full(1.0, hd.nDU))
+    lds, kinds = [hd.lds_bytes()], [hd.kernel_kind()]
+    weights(hd)
+    final(hd)
+    lds.append(hd.lds_bytes()); kinds.append(hd.kernel_kind())
+    Z = np.zeros((B, hd.nZ))
+    _, st, _ = hd.step(x0, lu, ry, Z)
+    H = hd.get(mpcqp.api.GET_HESSIAN)
+    hd.close()
+    # the same controllers, final bounds from the start
+    h2 = handle()
+    final(h2); weights(h2)
+    Z2 = np.zeros((B, h2.nZ))
+    _, st2, _ = h2.step(x0, lu, ry, Z2)
+    H2 = h2.get(mpcqp.api.GET_HESSIAN)
+    h2.close()
+    assert (st == 0).all() and (st2 == 0).all(), (st, st2)
+    return kinds, lds, float(rel_err(Z, Z2, nu * Hc).max()), float(np.abs(H - H2).max())
