@@ -56,7 +56,8 @@ def algorithmic_bytes(cfg):
     """Compulsory HBM bytes per solve in the on-device-condensation accounting of SURVEY 8(d)."""
     nxh = cfg.nx + cfg.ny
     n = cfg.nu * cfg.Hc + (0 if np.isinf(cfg.Cwt) else 1)
-    ins = nxh * nxh + nxh * cfg.nu + cfg.ny * nxh + nxh + 2 * cfg.nu + 2 * cfg.ny + 13 + 16 + n
+    # (model, x̂0, lastu0 and ry, weights M / N / L / C, bounds u / y both sides, warm start; C3: 478 doubles in)
+    ins = (nxh * nxh + nxh * cfg.nu + cfg.ny * nxh + nxh + cfg.nu + cfg.ny + (cfg.ny + 2 * cfg.nu + 1) + (2 * cfg.nu + 2 * cfg.ny) + n)
     outs = n + cfg.nu + 1
     return 8 * (ins + outs)
 
@@ -404,6 +405,8 @@ def secondary(args, local):
                                 3: "small-problem kernel (four controllers per wavefront)"}[sh.kernel],
                      "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr_, "traffic_source": trs_, "profile": pk,
+                                  "algorithmic_bytes_per_unit": algorithmic_bytes(cfg),
+                                  "traffic_over_algorithmic": (tr_ / B / algorithmic_bytes(cfg)) if tr_ else None,
                                   "flops_per_solve": flops}})
         del sh
         torch.cuda.empty_cache()
@@ -460,6 +463,9 @@ def secondary(args, local):
                      "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / FP64_PEAK_TFLOPS, "traffic": committed_traffic("k_ms_step_g", B)[0],
                                   "traffic_source": committed_traffic("k_ms_step_g", B)[1], "profile": "k_ms_step_g",
+                                  "algorithmic_bytes_per_unit": algorithmic_bytes(cfg),
+                                  "traffic_over_algorithmic": (committed_traffic("k_ms_step_g", B)[0] / B / algorithmic_bytes(cfg))
+                                  if committed_traffic("k_ms_step_g", B)[0] else None,
                                   "flops_per_solve": flops}})
         del sh
         torch.cuda.empty_cache()

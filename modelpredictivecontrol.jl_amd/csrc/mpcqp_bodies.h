@@ -130,7 +130,7 @@
 #define MPCQP_ETDE_VREG_MAX 32
 #endif
 #ifndef MPCQP_ETDE_VREG_CHUNK
-#define MPCQP_ETDE_VREG_CHUNK 4   // K steps per batch of row-factor loads (one batch in flight ahead of the matrix-core stream)
+#define MPCQP_ETDE_VREG_CHUNK 2   // K steps per batch of row-factor loads (one batch in flight ahead of the matrix-core stream)
 #endif
 #ifndef MPCQP_HZ_UNROLL
 #define MPCQP_HZ_UNROLL 4         // terms per unrolled pass of the two loops of H~ z (dual_residual)
@@ -540,11 +540,17 @@ struct Qp {
     }
 
     // out[r] = sum_k E[r,k] v[k]   (r < nY; v has >= nDU entries)
+    // (a team of wavefronts splits the row slots of the zero-padded form: W::NTEAM, mpcqp_devwave.h)
     MPCQP_HD void E_apply(const double* v, double* out) {
+        if constexpr (W::NTEAM > 1) w.post(TJ_EV, (int)(v - sm), (int)(out - sm));
+        E_apply_share(v, out);
+        if constexpr (W::NTEAM > 1) w.join();
+    }
+    MPCQP_HD void E_apply_share(const double* v, double* out) {
         MPCQP_RELANE(0);
         const int ny = d.ny, nu = d.nu;
         if constexpr (DM::is_static) {
-            if (DM::nu == 4 && DM::nY <= 2 * WAVE && DM::Hc <= MPCQP_EAPPLY44_HCMAX && d.default_nb) {
+            if (W::NTEAM == 1 && DM::nu == 4 && DM::nY <= 2 * WAVE && DM::Hc <= MPCQP_EAPPLY44_HCMAX && d.default_nb) {
                 // every lane owns rows r0 = lane and r1 = lane + 64: the (wave-uniform) v[j,:]
                 // loads are shared by both rows; a block column j > t reads a zero block (zpad)
                 const int r0 = w.lane, r1 = w.lane + WAVE;
@@ -576,7 +582,9 @@ struct Qp {
             if (DM::zpad > 0 && d.default_nb) {
                 // any nu, ny with the zero-padded table: every block column for every row (no lane-dependent trip
                 // count), the wave-uniform v[j,:] loads shared by the lane's rows r = lane, lane + 64, ..
+                // (team: row slot q belongs to wavefront q mod NTEAM -- `mine` is a compile-time test after unrolling)
                 constexpr int NR = (DM::nY + WAVE - 1) / WAVE;
+                auto mine = [](int q_) { return q_ % W::NTEAM == W::WV; };
                 const double* Sa[NR];
                 double acc[NR][2];
                 MPCQP_UNROLL
@@ -586,24 +594,28 @@ struct Qp {
                     Sa[q_] = S + (rr / DM::ny) * DM::sp + (rr % DM::ny) * DM::rs;
                     acc[q_][0] = acc[q_][1] = 0.0;
                 }
+                if constexpr (NR > W::WV) {
                 MPCQP_PRAGMA(unroll MPCQP_EV_UNROLL)
                 for (int j = 0; j < DM::Hc; ++j) {
                     MPCQP_UNROLL
                     for (int cc = 0; cc < DM::nu; ++cc) {
                         const double vv = v[j * DM::nu + cc];
                         MPCQP_UNROLL
-                        for (int q_ = 0; q_ < NR; ++q_) acc[q_][cc & 1] = fma(Sa[q_][cc - j * DM::sp], vv, acc[q_][cc & 1]);
+                        for (int q_ = 0; q_ < NR; ++q_)
+                            if (mine(q_)) acc[q_][cc & 1] = fma(Sa[q_][cc - j * DM::sp], vv, acc[q_][cc & 1]);
                     }
+                }
                 }
                 MPCQP_UNROLL
                 for (int q_ = 0; q_ < NR; ++q_) {
                     const int r = w.lane + WAVE * q_;
-                    if (r < DM::nY) out[r] = acc[q_][0] + acc[q_][1];
+                    if (mine(q_) && r < DM::nY) out[r] = acc[q_][0] + acc[q_][1];
                 }
                 return;
             }
         }
 #endif
+        if constexpr (W::WV != 0) return;         // (forms without a team split: wavefront 0 alone)
         for (int r = w.lane; r < d.nY; r += WAVE) {
             const int t = r / ny, a = r - t * ny;
             double acc0 = 0.0;
@@ -620,11 +632,16 @@ struct Qp {
     // later block columns just start contributing later), so wv[t,a] is a broadcast LDS read and
     // there is no divergent branch in the loop.
     MPCQP_HD void Et_apply_add(const double* wv, double* out, double scale = 1.0, int t_hi = -1) {
+        if constexpr (W::NTEAM > 1) w.post(TJ_ETW, (int)(wv - sm), (int)(out - sm), t_hi, 0, scale);
+        Et_apply_share(wv, out, scale, t_hi);
+        if constexpr (W::NTEAM > 1) w.join();
+    }
+    MPCQP_HD void Et_apply_share(const double* wv, double* out, double scale, int t_hi) {
         MPCQP_RELANE(1);
         const int ny = d.ny, nu = d.nu;
         if (t_hi < 0) t_hi = d.Hp;          // only the steps t < t_hi contribute
         if constexpr (DM::is_static) {
-            if (DM::ny == 4 && DM::nu == 4 && DM::nDU <= WAVE && d.default_nb) {
+            if (W::NTEAM == 1 && DM::ny == 4 && DM::nu == 4 && DM::nDU <= WAVE && d.default_nb) {
                 // lane (j, a) reads whole rows S_{t-j}[a][0..3] (two 16-byte loads instead of four
                 // strided 8-byte ones) and keeps one partial sum per channel c; the four a-lanes
                 // of a block column are then added with two quad permutes and lane a keeps c = a.
@@ -673,7 +690,9 @@ struct Qp {
             if (DM::zpad > 0 && d.default_nb) {
                 // any nu, ny with the zero-padded table: no select on t >= j, the wave-uniform w[t,:] loads shared by the
                 // lane's columns k = lane, lane + 64, ..
+                // (team: column slot q belongs to wavefront q mod NTEAM)
                 constexpr int NQ = (DM::nDU + WAVE - 1) / WAVE;
+                auto mine = [](int q_) { return q_ % W::NTEAM == W::WV; };
                 const double* Sk[NQ];
                 double acc[NQ][2];
                 MPCQP_UNROLL
@@ -683,6 +702,7 @@ struct Qp {
                     Sk[q_] = S - (kk / DM::nu) * DM::sp + (kk % DM::nu);
                     acc[q_][0] = acc[q_][1] = 0.0;
                 }
+                if constexpr (NQ > W::WV) {
                 MPCQP_PRAGMA(unroll MPCQP_EV_UNROLL)
                 for (int t = 0; t < DM::Hp; ++t) {
                     if (t >= t_hi) break;
@@ -690,18 +710,21 @@ struct Qp {
                     for (int a = 0; a < DM::ny; ++a) {
                         const double wt = wv[t * DM::ny + a];
                         MPCQP_UNROLL
-                        for (int q_ = 0; q_ < NQ; ++q_) acc[q_][a & 1] = fma(Sk[q_][t * DM::sp + a * DM::rs], wt, acc[q_][a & 1]);
+                        for (int q_ = 0; q_ < NQ; ++q_)
+                            if (mine(q_)) acc[q_][a & 1] = fma(Sk[q_][t * DM::sp + a * DM::rs], wt, acc[q_][a & 1]);
                     }
+                }
                 }
                 MPCQP_UNROLL
                 for (int q_ = 0; q_ < NQ; ++q_) {
                     const int k = w.lane + WAVE * q_;
-                    if (k < DM::nDU) out[k] += scale * (acc[q_][0] + acc[q_][1]);
+                    if (mine(q_) && k < DM::nDU) out[k] += scale * (acc[q_][0] + acc[q_][1]);
                 }
                 return;
             }
         }
 #endif
+        if constexpr (W::WV != 0) return;         // (forms without a team split: wavefront 0 alone)
         for (int k = w.lane; k < d.nDU; k += WAVE) {
             const int j = k / nu, cc = k - j * nu, t0 = jl(j);
             const double* Sk = S + cc;
@@ -753,6 +776,13 @@ struct Qp {
     // ride in dd, Step::fold_H)
     __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb,
                                                  const double* Hg = nullptr, bool ow = false) {
+        // (a team of wavefronts splits the passes over the tile rows: W::NTEAM, mpcqp_devwave.h)
+        if constexpr (W::NTEAM > 1) w.post(TJ_ETDE, (int)(dd - sm), (int)(P - sm), tb ? (int)(tb - sm) : -1, (ow ? 1 : 0) | (Hg ? 2 : 0), scale);
+        const int e = EtDE_share(dd, P, scale, tb, Hg, ow);
+        if constexpr (W::NTEAM > 1) w.join();
+        return e;
+    }
+    __device__ __forceinline__ int EtDE_share(const double* dd, double* P, double scale, const double* tb, const double* Hg, bool ow) {
         MPCQP_RELANE(2);
         ow = ow || Hg != nullptr;
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp, RS = DM::rs;
@@ -776,7 +806,15 @@ struct Qp {
         // then every further row on its own.  A pass starts at the first K step that reaches its
         // first block column (E is block lower triangular).
         constexpr int IE = NDU / 16, LE = NDU % 16;     // tile row / lane column of the ϵ row
+        // first step whose rows the ϵ row is accumulated for by the pass of its tile row (kfirst() below; known up front: in a
+        // team that pass may run on another wavefront)
         int eps_t0 = -1;
+        if (DM::neps && tb != nullptr && IE < NT) {
+            int v = (jl((16 * IE) / NU) * NY) / 4;
+            v = v < NK ? v : NK;
+            if ((4 * v) % NY != 0) v = 0;
+            eps_t0 = (4 * v) / NY;
+        }
         // operands in registers (MPCQP_ETDE_VREG): V[k] = operand of tile column 0 at K step k = (t, a0): Sigma(t - li / nu)[a0 + row, li % nu]
         // (zero blocks in front of the table for t < li / nu)
         constexpr int QK = NY % 4 == 0 ? NY / 4 : 1;                  // K steps per step of the horizon
@@ -794,6 +832,9 @@ struct Qp {
         // seven tile rows -- the accumulator arrays are indexed dynamically and end up in scratch memory)
         auto pass = [&](auto I0c) {
             constexpr int I0 = decltype(I0c)::value;
+            if constexpr (W::NTEAM > 1) {                 // pass number (I0 == 0 ? 0 : I0 - 1) mod NTEAM owns the pass
+                if constexpr ((I0 == 0 ? 0 : I0 - 1) % W::NTEAM != W::WV) return;
+            }
             constexpr int MAXT = NT + 1;
             constexpr int I1 = (I0 == 0 && NT > 1) ? 1 : I0;          // last tile row of the pass
             v4d acc[2][MAXT];
@@ -844,7 +885,7 @@ struct Qp {
                 v = v < NK ? v : NK;
                 // the ϵ row rides from its tile row's own start when that is a whole number of
                 // steps (the few steps before are left to the caller, Et_apply_add), else from 0
-                if (erow && I == IE) { if ((4 * v) % NY != 0) v = 0; eps_t0 = (4 * v) / NY; }
+                if (erow && I == IE) { if ((4 * v) % NY != 0) v = 0; }
                 return v;
             };
             const int kB = (I1 > I0) ? kfirst(I1) : NK;               // second row of the pass joins here
@@ -894,7 +935,6 @@ struct Qp {
                 // number of steps, so the ϵ row rides from there: kfirst() above gives the same values)
                 constexpr int kA_ = (DJ * I0 < NK) ? DJ * I0 : NK;
                 constexpr int kB_ = (I1 > I0) ? ((DJ * I1 < NK) ? DJ * I1 : NK) : NK;
-                if (erow) eps_t0 = (4 * ((DJ * IE < NK) ? DJ * IE : NK)) / NY;
                 constexpr int CH = MPCQP_ETDE_VREG_CHUNK;
                 constexpr bool EP = DM::neps != 0 && IE >= I0 && IE <= I1;      // the ϵ row can ride in this pass
                 double dvb[2][CH], tbb[2][EP ? CH : 1];
@@ -986,7 +1026,7 @@ struct Qp {
             }
         };
         etde_passes<0, NT>(pass);
-        if constexpr (DM::neps != 0) {
+        if constexpr (DM::neps != 0 && W::WV == 0) {
             if (ow && !Hg) {             // (same as below with H̃'s ϵ row: zero off the diagonal; the caller adds 2 C to the diagonal)
                 if constexpr (IE >= NT) {
                     for (int k = w.lane; k < NDU; k += WAVE) P[pk(NDU, k)] = 0.0;
@@ -2120,6 +2160,51 @@ struct Step {
 #endif
     }
 
+    // Parts of G'DG whose inputs (scratch vectors of the row pass) and outputs (Phi) live in LDS: the lanes of every wavefront of
+    // a team take their share (W::NTEAM, W::WV; one wavefront: the loops of rounds 1-5).
+    // U rows of problems with several variables per lane: the suffix sums (tA[P_U], scanned in place) along the rows of Pu'dU Pu
+    MPCQP_HD void GtDG_urows_share() {
+        const int nu = d.nu, nDU = d.nDU;
+        const double* tU = sm + c.tA[P_U];
+        for (int k = w.lane + WAVE * W::WV; k < nDU; k += WAVE * W::NTEAM) {
+            const int j = k / nu, cc = k - j * nu;
+            const double suf = tU[k];
+            MPCQP_PRAGMA(unroll MPCQP_URMW_UNROLL)
+            for (int j2 = 0; j2 <= j; ++j2) Phi[pk(k, j2 * nu + cc)] += suf;
+        }
+    }
+    // terminal rows: ex̂' dX ex̂
+    MPCQP_HD void GtDG_xrows_share() {
+        const int nDU = d.nDU, ntri = nDU * (nDU + 1) / 2;
+        const double* tX = sm + c.tA[P_X];
+        for (int idx = w.lane + WAVE * W::WV; idx < ntri; idx += WAVE * W::NTEAM) {
+            int i, ip;
+            Qp<W, DM>::unpack_idx(idx, i, ip);
+            double acc = 0.0;
+            for (int r = 0; r < d.nxh; ++r) acc += qp.Xat(r, i) * tX[r] * qp.Xat(r, ip);
+            Phi[pk(i, ip)] += acc;
+        }
+    }
+    // custom rows: E_w' dW E_w, rows formed on the fly (set-up-grade path)
+    MPCQP_HD void GtDG_wrows_share() {
+        if constexpr (has_w<DM>()) {
+            const int nu = d.nu, nDU = d.nDU, ntri = nDU * (nDU + 1) / 2, nw = d.nw;
+            const double* dW = sm + c.tA[P_W];
+            for (int idx = w.lane + WAVE * W::WV; idx < ntri; idx += WAVE * W::NTEAM) {
+                int i, ip;
+                Qp<W, DM>::unpack_idx(idx, i, ip);
+                const int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
+                double acc = 0.0;
+                for (int t = 0; t <= d.Hp; ++t)
+                    for (int iw = 0; iw < nw; ++iw) {
+                        const double dk = dW[t * nw + iw];
+                        if (dk != 0.0) acc += dk * qp.Ew_at(t, iw, j, cc) * qp.Ew_at(t, iw, j2, c2);
+                    }
+                Phi[pk(i, ip)] += acc;
+            }
+        }
+    }
+
     // ---- Phi (+)= G' diag(dd) G, dd(Row&) evaluated on finite rows (see phi_direct) ---------------
     template <class Fn>
     MPCQP_HD void add_GtDG(Fn dd) {
@@ -2207,42 +2292,22 @@ struct Step {
             double* tU = sm + c.tA[P_U];
             w.sync();
             block_scan(tU, tU, true);              // (nothing reads the per-block sums after this point: in place)
-            for (int k = w.lane; k < nDU; k += WAVE) {
-                const int j = k / nu, cc = k - j * nu;
-                const double suf = tU[k];
-                MPCQP_PRAGMA(unroll MPCQP_URMW_UNROLL)
-                for (int j2 = 0; j2 <= j; ++j2) Phi[pk(k, j2 * nu + cc)] += suf;
-            }
+            if constexpr (W::NTEAM > 1) w.post(TJ_UROWS);
+            GtDG_urows_share();
+            if constexpr (W::NTEAM > 1) w.join();
         }
         if (qp.pair_on(P_X)) {
             w.sync();
-            const int ntri = nDU * (nDU + 1) / 2;
-            const double* tX = sm + c.tA[P_X];
-            for (int idx = w.lane; idx < ntri; idx += WAVE) {
-                int i, ip;
-                Qp<W, DM>::unpack_idx(idx, i, ip);
-                double acc = 0.0;
-                for (int r = 0; r < d.nxh; ++r) acc += qp.Xat(r, i) * tX[r] * qp.Xat(r, ip);
-                Phi[pk(i, ip)] += acc;
-            }
+            if constexpr (W::NTEAM > 1) w.post(TJ_XROWS);
+            GtDG_xrows_share();
+            if constexpr (W::NTEAM > 1) w.join();
         }
         if constexpr (has_w<DM>()) {
             if (qp.pair_on(P_W)) {        // E_w' dW E_w, rows formed on the fly (set-up-grade path)
                 w.sync();
-                const int ntri = nDU * (nDU + 1) / 2, nw = d.nw;
-                const double* dW = sm + c.tA[P_W];
-                for (int idx = w.lane; idx < ntri; idx += WAVE) {
-                    int i, ip;
-                    Qp<W, DM>::unpack_idx(idx, i, ip);
-                    const int j = i / nu, cc = i - j * nu, j2 = ip / nu, c2 = ip - j2 * nu;
-                    double acc = 0.0;
-                    for (int t = 0; t <= d.Hp; ++t)
-                        for (int iw = 0; iw < nw; ++iw) {
-                            const double dk = dW[t * nw + iw];
-                            if (dk != 0.0) acc += dk * qp.Ew_at(t, iw, j, cc) * qp.Ew_at(t, iw, j2, c2);
-                        }
-                    Phi[pk(i, ip)] += acc;
-                }
+                if constexpr (W::NTEAM > 1) w.post(TJ_WROWS);
+                GtDG_wrows_share();
+                if constexpr (W::NTEAM > 1) w.join();
             }
         }
         w.sync();
@@ -2321,10 +2386,18 @@ struct Step {
     // rows / columns that are not written back.
     template <int P>
     __device__ __forceinline__ void chol_panel_update() {
+        // (a team of wavefronts splits the row tiles below the panel: W::NTEAM, mpcqp_devwave.h)
+        if constexpr (W::NTEAM > 1) w.post(TJ_PANEL, P);
+        chol_panel_share<P>();
+        if constexpr (W::NTEAM > 1) w.join();
+    }
+    template <int P>
+    __device__ __forceinline__ void chol_panel_share() {
         typedef double v4d_ __attribute__((ext_vector_type(4)));
         constexpr int n = DM::nZ, NT = (n + 15) / 16;
         if constexpr (P < NT) {
             const int li = w.lane & 15, lk = w.lane >> 4;
+            auto mine = [](int I) { return (I - P) % W::NTEAM == W::WV; };       // row tile I of this wavefront (compile-time after unrolling)
             const double* X[NT];
             v4d_ acc[NT];
             MPCQP_UNROLL
@@ -2333,20 +2406,23 @@ struct Step {
                 X[I] = Phi + pk(row, 0) + lk;
                 acc[I] = v4d_{0.0, 0.0, 0.0, 0.0};
             }
+            if constexpr (NT - P > W::WV) {
             MPCQP_PRAGMA(unroll MPCQP_PANEL_UNROLL)
             for (int kk = 0; kk < 4 * P; ++kk) {
                 const double bb = X[P][4 * kk];
                 // (one row per lane, M D M' form: one operand carries d of its column, the d vector sits in gt; the
                 //  several-rows-per-lane factorisation that shares this function is LL')
                 const double bs = (MPCQP_CHOL_LDL && !MPCQP_CHOL_REDUNDANT && one_row_per_lane<DM>()) ? bb * gt[4 * kk + lk] : bb;
-                acc[P] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb, bs, acc[P], 0, 0, 0);
+                if (mine(P)) acc[P] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb, bs, acc[P], 0, 0, 0);
                 MPCQP_UNROLL
                 for (int I = P + 1; I < NT; ++I)
-                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[I][4 * kk], bs, acc[I], 0, 0, 0);
+                    if (mine(I)) acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[I][4 * kk], bs, acc[I], 0, 0, 0);
+            }
             }
             double* const trash = sm + c.zero + 4;        // unconditional write-back, see EtDE_add_mfma
             MPCQP_UNROLL
             for (int I = P; I < NT; ++I) {
+                if (!mine(I)) continue;
                 double* pp_[4];
                 double old_[4];
                 MPCQP_UNROLL
@@ -2359,6 +2435,17 @@ struct Step {
                 for (int reg = 0; reg < 4; ++reg) *pp_[reg] = old_[reg] - acc[I][reg];
             }
             w.sync();
+        }
+    }
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    // helper wavefronts of a team: the share of the panel update the mailbox names
+    template <int P>
+    __device__ __forceinline__ void panel_dispatch(int p) {
+        if constexpr (P < (DM::nZ + 15) / 16) {
+            if (p == P) chol_panel_share<P>();
+            else panel_dispatch<P + 1>(p);
         }
     }
 #endif
@@ -3774,6 +3861,51 @@ MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int
     }
 }
 
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Wavefronts 1 .. T-1 of a team (DevWaveT, mpcqp_devwave.h): wait for a job, run this wavefront's share, meet wavefront 0.
+template <class W, class DM>
+__device__ __forceinline__ void team_helper(W& w, const DM& d, const Model& m, int b, double* sm) {
+    Qp<W, DM> qp(w, d, m, b, sm);
+    Step<W, DM> st(qp);
+    for (;;) {
+        w.join();
+        const int* mi = reinterpret_cast<const int*>(w.mbox);
+        const int job = __builtin_amdgcn_readfirstlane(mi[0]);
+        if (job == TJ_EXIT) break;
+        const int a0 = __builtin_amdgcn_readfirstlane(mi[1]), a1 = __builtin_amdgcn_readfirstlane(mi[2]);
+        const int a2 = __builtin_amdgcn_readfirstlane(mi[3]), a3 = __builtin_amdgcn_readfirstlane(mi[4]);
+        const double sc = w.mbox[3];
+        switch (job) {
+            case TJ_ETDE:
+                if constexpr (DM::is_static)
+                    (void)qp.EtDE_share(sm + a0, sm + a1, sc, a2 >= 0 ? sm + a2 : nullptr, (a3 & 2) ? m.Hpk + (size_t)b * d.npk : nullptr, (a3 & 1) != 0);
+                break;
+            case TJ_PANEL: st.template panel_dispatch<1>(a0); break;
+            case TJ_EV: qp.E_apply_share(sm + a0, sm + a1); break;
+            case TJ_ETW: qp.Et_apply_share(sm + a0, sm + a1, sc, a2); break;
+            case TJ_UROWS: st.GtDG_urows_share(); break;
+            case TJ_XROWS: st.GtDG_xrows_share(); break;
+            case TJ_WROWS: st.GtDG_wrows_share(); break;
+            default: break;
+        }
+        w.join();
+    }
+}
+
+#endif
+
+// wavefronts per problem of a specialised kernel: MPCQP_TEAM when given, else by the LDS footprint -- one problem per CU
+// (beyond 80 KB): four, one per SIMD; two problems per CU: two; otherwise one wavefront per problem as before
+template <class DM>
+constexpr int auto_team() {
+    if constexpr (!DM::is_static) return 1;
+    else {
+        if (DM::nZ <= WAVE) return 1;
+        const long bytes = 8L * ((long)(DM::Hp + DM::zpad) * DM::sp + DM::npk + 8L * DM::nZ + 3L * DM::nY + 2L * DM::nDU);
+        return bytes > 80 * 1024 ? 4 : bytes > 160 * 1024 / 3 ? 2 : 1;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // SteadyKalmanFilter steps.  One lane per state of one problem; a problem's nx̂

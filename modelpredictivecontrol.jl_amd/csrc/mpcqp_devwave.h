@@ -19,6 +19,10 @@ namespace mpcqp {
 // critical path is a chain of ~120 broadcasts + ~12 reductions per IPM iteration.)
 struct DevWave {
     int lane;
+    // one wavefront per problem: no team (see DevWaveT)
+    static constexpr int NTEAM = 1, WV = 0;
+    __device__ __forceinline__ void post(int, int = 0, int = 0, int = 0, int = 0, double = 0.0) {}
+    __device__ __forceinline__ void join() {}
     // One wavefront per workgroup: LDS operations of a wave execute in issue order, so ordering
     // LDS traffic between lanes needs no s_barrier and no s_waitcnt -- only a fence the compiler
     // may not move memory operations across.
@@ -146,6 +150,29 @@ struct DevWave {
 
 extern __shared__ __attribute__((aligned(16))) double mpcqp_smem[];
 
+// ---- a TEAM of T wavefronts per problem (round 6; problems beyond one row per lane, whose LDS footprint leaves SIMDs idle) ----
+// Wavefront 0 runs the step exactly as the one-wavefront kernel does.  Wavefronts 1 .. T-1 are helpers: they wait at a
+// workgroup barrier, read a job from the mailbox (LDS, behind the problem's carve-up), run THEIR SHARE of it -- tile rows of
+// E'DE and of the panel updates of the factorisation, row slots of E v, column slots of E'w, rows of Pu'dU Pu: everything
+// whose operands and results live in LDS -- and meet wavefront 0 at a second barrier.  The shares are compile-time (WV is a
+// template parameter: one instantiation of the shared functions per wavefront, no run-time ownership tests); wavefront 0
+// does its own share between the two barriers.  Row state, pivot chains and substitutions stay with wavefront 0.
+template <int T, int WV_>
+struct DevWaveT : DevWave {
+    static constexpr int NTEAM = T, WV = WV_;
+    double* mbox;            // 8 doubles of LDS: [0] job, args as ints in [1..2], scale in [3]
+    // wavefront 0: publish a job (LDS stores of every wavefront before the barrier are visible after it)
+    __device__ __forceinline__ void post(int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, double sc = 0.0) {
+        if (lane == 0) {
+            int* mi = reinterpret_cast<int*>(mbox);
+            mi[0] = job; mi[1] = a0; mi[2] = a1; mi[3] = a2; mi[4] = a3;
+            mbox[3] = sc;
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void join() { __syncthreads(); }
+};
+
 // specialised on compile-time dimensions
 template <class SD>
 // (waves_per_eu >= 2 caps the kernel at 256 registers, which makes the compiler select the VGPR
@@ -164,6 +191,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_STEP_W
     step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem);
 }
 
+template <class DM> constexpr int auto_team();          // (mpcqp_bodies.h)
+
+// a team of T wavefronts per problem (DevWaveT): wavefront 0 runs the step, the others serve it
+template <class SD, int T, int WV>
+__device__ __forceinline__ void team_run(int wv, int lane, double* mbox, const SD& sd, const Model& m, const StepIO& io) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (WV < T) {
+        if (wv == WV) {
+            DevWaveT<T, WV> w;
+            w.lane = lane; w.mbox = mbox;
+            if constexpr (WV == 0) { step_body(w, sd, m, io, (int)blockIdx.x, mpcqp_smem); w.post(TJ_EXIT); }
+            else team_helper(w, sd, m, (int)blockIdx.x, mpcqp_smem);
+        } else {
+            team_run<SD, T, WV + 1>(wv, lane, mbox, sd, m, io);
+        }
+    }
+#endif
+}
+template <class SD, int T>
+__global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(1, 8))) void k_step_team(Dims d, Model m, StepIO io) {
+    const SD sd(d);
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    double* mbox = mpcqp_smem + make_carve(sd).total;
+    team_run<SD, T, 0>(wv, (int)threadIdx.x & 63, mbox, sd, m, io);
+}
+#ifndef MPCQP_TEAM
+#define MPCQP_TEAM 0            // wavefronts per problem of the specialised step kernel; 0: auto_team() (mpcqp_bodies.h)
+#endif
+
 inline hipError_t ensure_lds(const void* fn, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -173,10 +229,19 @@ template <class SD>
 inline hipError_t launch_step_static(const Dims& d, const Model& m, const StepIO& io, hipStream_t st) {
     size_t lds = (size_t)make_carve(SD(d)).total * sizeof(double);
     if (const char* pad = getenv("MPCQP_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
-    hipError_t e = ensure_lds((const void*)k_step_s<SD>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_step_s<SD>, dim3(d.B), dim3(WAVE), lds, st, d, m, io);
-    return hipGetLastError();
+    constexpr int T = MPCQP_TEAM > 0 ? MPCQP_TEAM : auto_team<SD>();
+    if constexpr (T > 1) {
+        lds += 8 * sizeof(double);                // the team's mailbox
+        hipError_t e = ensure_lds((const void*)k_step_team<SD, T>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_step_team<SD, T>), dim3(d.B), dim3(WAVE * T), lds, st, d, m, io);
+        return hipGetLastError();
+    } else {
+        hipError_t e = ensure_lds((const void*)k_step_s<SD>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_step_s<SD>, dim3(d.B), dim3(WAVE), lds, st, d, m, io);
+        return hipGetLastError();
+    }
 }
 
 template <class SD>

@@ -8,15 +8,24 @@ import csv, glob, json, os, re, shutil, sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 
+def step_algorithmic_bytes(nx, nu, ny, Hp, Hc, neps=1):
+    """SURVEY 8(d), on-device condensation: what one LinMPC step must read and write once -- model, state, last input, set
+    point, weights, bounds, warm start in; Z~, u and two ints out (bench.py: algorithmic_bytes; C3: 4192 B)."""
+    nxh, n = nx + ny, nu * Hc + neps
+    ins = nxh * nxh + nxh * nu + ny * nxh + nxh + nu + ny + (ny + 2 * nu + 1) + (2 * nu + 2 * ny) + n
+    return 8 * (ins + n + nu + 1)
+
+
 # (kernel-name pattern, short name, what one launch processes, units per launch, algorithmic bytes per unit or None)
+# (team kernels of round 6: k_step_team<StaticDims<..>, T>)
 KERNELS = [
-    (r"k_step_s<.*StaticDims<4, 4, 16, 30, 10", "k_step_s_C3", "QP solves (C3, B = 65536)", 65536, 4192),
-    (r"k_step_s<.*StaticDims<3, 3, 15, 40, 35", "k_step_s_nZ106", "QP solves (nu = ny = 3, Hp = 40, Hc = 35, B = 8192)", 8192, None),
-    (r"k_step_s<.*StaticDims<3, 3, 15, 50, 50", "k_step_s_nZ151", "QP solves (nu = ny = 3, Hp = Hc = 50, B = 4096)", 4096, None),
-    (r"k_step_small_w1<12", "k_step_small_w1_12", "QP solves (C2, B = 1024)", 1024, None),
-    (r"k_step_small<12", "k_step_small_12", "QP solves (C2, B = 65536)", 65536, None),
-    (r"k_step_small_y<12", "k_step_small_y_12", "QP solves (C2 dims, soft ymax + hard u, B = 65536)", 65536, None),
-    (r"k_ms_step_g", "k_ms_step_g", "QP solves (MultipleShooting, Hp = Hc = 50, B = 8192)", 8192, None),
+    (r"k_step_s<.*StaticDims<4, 4, 16, 30, 10", "k_step_s_C3", "QP solves (C3, B = 65536)", 65536, step_algorithmic_bytes(12, 4, 4, 30, 10)),
+    (r"k_step_(s|team)<.*StaticDims<3, 3, 15, 40, 35", "k_step_s_nZ106", "QP solves (nu = ny = 3, Hp = 40, Hc = 35, B = 8192)", 8192, step_algorithmic_bytes(12, 3, 3, 40, 35)),
+    (r"k_step_(s|team)<.*StaticDims<3, 3, 15, 50, 50", "k_step_s_nZ151", "QP solves (nu = ny = 3, Hp = Hc = 50, B = 4096)", 4096, step_algorithmic_bytes(12, 3, 3, 50, 50)),
+    (r"k_step_small_w1<12", "k_step_small_w1_12", "QP solves (C2, B = 1024)", 1024, step_algorithmic_bytes(4, 2, 2, 20, 5, 0)),
+    (r"k_step_small<12", "k_step_small_12", "QP solves (C2, B = 65536)", 65536, step_algorithmic_bytes(4, 2, 2, 20, 5, 0)),
+    (r"k_step_small_y<12", "k_step_small_y_12", "QP solves (C2 dims, soft ymax + hard u, B = 65536)", 65536, step_algorithmic_bytes(4, 2, 2, 20, 5)),
+    (r"k_ms_step_g", "k_ms_step_g", "QP solves (MultipleShooting, Hp = Hc = 50, B = 8192)", 8192, step_algorithmic_bytes(6, 2, 2, 50, 50)),
     (r"k_mhe_step<12, 1u>", "k_mhe_step_12_hard", "estimator periods (C5, B = 65536)", 65536, None),
     (r"k_mhe_step<12, 15u>", "k_mhe_step_12_soft", "estimator periods (C5 soft, B = 65536)", 65536, None),
 ]

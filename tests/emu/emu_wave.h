@@ -21,6 +21,9 @@ struct EmuShared {
 };
 
 struct EmuWave {
+    static constexpr int NTEAM = 1, WV = 0;      // (teams of wavefronts are a device-only form: mpcqp_devwave.h)
+    void post(int, int = 0, int = 0, int = 0, int = 0, double = 0.0) {}
+    void join() {}
     int lane;
     EmuShared* sh;
     unsigned n = 0;

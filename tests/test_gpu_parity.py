@@ -131,10 +131,12 @@ def test_condensed_problem_beyond_the_lds_runs_in_stage_form(hiplib):
     its SingleShooting transcription and its steps run on the stage-structured kernel (round 5: MPCQP_ERR_UNSUPPORTED before),
     same optimum as the oracle's C port."""
     from tests.parity_util import shape_vs_cport
-    r = shape_vs_cport(synth.get_config("12,4,4,46,46"), B=64)
+    r = shape_vs_cport(synth.get_config("12,4,4,46,46"), B=256)
     assert r["kind"] == mpcqp.api.KERNEL_MS, r
-    assert r["optimal"] >= 0.98 and r["optimal_cport"] == 1.0, r
-    assert r["err99"] <= TOL, r
+    # (round 6: the bar of the condensed kernels -- every instance OPTIMAL, the worst one within TOL; round 5 accepted 98 % and
+    #  the 99 % quantile.  Measured: 256 of 256 OPTIMAL, worst difference 1.1e-9, profiles/r6a/stage_diag.txt)
+    assert r["optimal"] == 1.0 and r["optimal_cport"] == 1.0, r
+    assert r["errmax"] <= TOL, r
 
 
 def test_full_size_properties_C3(hiplib):
