@@ -102,7 +102,13 @@
 #define MPCQP_EAPPLY44_UNROLL 2   // block columns per group of loads in flight of the row-load form of E v (nu = ny = 4)
 #endif
 #ifndef MPCQP_EV_UNROLL
+#if defined(MPCQP_STEP_WAVES) && MPCQP_STEP_WAVES == 1
+// (one wavefront per SIMD has nobody to hide an LDS round trip behind and 512 registers: profiles/r6c -- E v of nZ~ = 151 took
+//  21k cycles per product for 150 multiply-adds per lane, one round trip per group of four block columns)
+#define MPCQP_EV_UNROLL 16
+#else
 #define MPCQP_EV_UNROLL 4         // block columns / steps per unrolled pass of the general E v and E'w forms
+#endif
 #endif
 #define MPCQP_PRAGMA_(x) _Pragma(#x)
 #define MPCQP_PRAGMA(x) MPCQP_PRAGMA_(x)
@@ -131,6 +137,32 @@
 #endif
 #ifndef MPCQP_ETDE_VREG_CHUNK
 #define MPCQP_ETDE_VREG_CHUNK 2   // K steps per batch of row-factor loads (one batch in flight ahead of the matrix-core stream)
+#endif
+// chunks of four columns per unrolled pass of the several-rows-per-lane substitutions (solve_big_static): the factor entries
+// of a pass are requested together, so one LDS round trip is paid per pass (profiles/r6c: 86 cycles per column at 2)
+#ifndef MPCQP_SOLVEBIG_UNROLL
+#if defined(MPCQP_STEP_WAVES) && MPCQP_STEP_WAVES == 1
+#define MPCQP_SOLVEBIG_UNROLL 8
+#else
+#define MPCQP_SOLVEBIG_UNROLL 2
+#endif
+#endif
+// Issue priority of the wavefront by phase (s_setprio; two wavefronts share a SIMD's FP64 pipe, a 64-cycle v_mfma_f64 of one
+// holds up the other's next dependent instruction): bit 0 factorisation high, bit 1 triangular solves high, bit 2 everything
+// high except the matrix-core stream of E'DE.  0: no priority changes (rounds 1-5).
+#ifndef MPCQP_PRIO
+#define MPCQP_PRIO 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPCQP_SETPRIO(bit, p) do { if ((MPCQP_PRIO) & (bit)) __builtin_amdgcn_s_setprio(p); } while (0)
+#else
+#define MPCQP_SETPRIO(bit, p) ((void)0)
+#endif
+// teams of three or more wavefronts: 0 keeps wavefront 0 (which carries the row state of the whole problem in registers) out of
+// the matrix-core shares (E'DE passes, panel updates): the helpers split them among themselves.  Measured at nZ~ = 151, four
+// wavefronts (profiles/r6f): with wavefront 0 in 826 spilled registers and 20.8 ms per 2048 solves, without 352 and 17.8 ms
+#ifndef MPCQP_TEAM_MAIN_MFMA
+#define MPCQP_TEAM_MAIN_MFMA 0
 #endif
 #ifndef MPCQP_HZ_UNROLL
 #define MPCQP_HZ_UNROLL 4         // terms per unrolled pass of the two loops of H~ z (dual_residual)
@@ -364,6 +396,21 @@ MPCQP_HD inline Carve make_carve(const DM& d) {
     return c;
 }
 
+// which wavefront of a team takes item `idx` of a matrix-core job (helpers first; see MPCQP_TEAM_MAIN_MFMA), and whether this
+// wavefront has any of `count` items
+template <class W>
+MPCQP_HD constexpr bool team_mine_mfma(int idx) {
+    if (W::NTEAM == 1) return true;
+    if (W::NTEAM >= 3 && !MPCQP_TEAM_MAIN_MFMA) return W::WV != 0 && idx % (W::NTEAM - 1) == W::WV - 1;
+    return (idx + 1) % W::NTEAM == W::WV;
+}
+template <class W>
+MPCQP_HD constexpr bool team_any_mfma(int count) {
+    for (int i = 0; i < count; ++i)
+        if (team_mine_mfma<W>(i)) return true;
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------
 // condensed problem resident in LDS + structured products with E, Pu, ex̂
 // ------------------------------------------------------------------------------------------
@@ -584,7 +631,7 @@ struct Qp {
                 // count), the wave-uniform v[j,:] loads shared by the lane's rows r = lane, lane + 64, ..
                 // (team: row slot q belongs to wavefront q mod NTEAM -- `mine` is a compile-time test after unrolling)
                 constexpr int NR = (DM::nY + WAVE - 1) / WAVE;
-                auto mine = [](int q_) { return q_ % W::NTEAM == W::WV; };
+                auto mine = [](int q_) { return (q_ + 1) % W::NTEAM == W::WV; };
                 const double* Sa[NR];
                 double acc[NR][2];
                 MPCQP_UNROLL
@@ -594,7 +641,7 @@ struct Qp {
                     Sa[q_] = S + (rr / DM::ny) * DM::sp + (rr % DM::ny) * DM::rs;
                     acc[q_][0] = acc[q_][1] = 0.0;
                 }
-                if constexpr (NR > W::WV) {
+                if constexpr (W::NTEAM == 1 || (W::WV == 0 ? NR >= W::NTEAM : NR >= W::WV)) {
                 MPCQP_PRAGMA(unroll MPCQP_EV_UNROLL)
                 for (int j = 0; j < DM::Hc; ++j) {
                     MPCQP_UNROLL
@@ -692,7 +739,7 @@ struct Qp {
                 // lane's columns k = lane, lane + 64, ..
                 // (team: column slot q belongs to wavefront q mod NTEAM)
                 constexpr int NQ = (DM::nDU + WAVE - 1) / WAVE;
-                auto mine = [](int q_) { return q_ % W::NTEAM == W::WV; };
+                auto mine = [](int q_) { return (q_ + 1) % W::NTEAM == W::WV; };
                 const double* Sk[NQ];
                 double acc[NQ][2];
                 MPCQP_UNROLL
@@ -702,7 +749,7 @@ struct Qp {
                     Sk[q_] = S - (kk / DM::nu) * DM::sp + (kk % DM::nu);
                     acc[q_][0] = acc[q_][1] = 0.0;
                 }
-                if constexpr (NQ > W::WV) {
+                if constexpr (W::NTEAM == 1 || (W::WV == 0 ? NQ >= W::NTEAM : NQ >= W::WV)) {
                 MPCQP_PRAGMA(unroll MPCQP_EV_UNROLL)
                 for (int t = 0; t < DM::Hp; ++t) {
                     if (t >= t_hi) break;
@@ -777,12 +824,19 @@ struct Qp {
     __device__ __forceinline__ int EtDE_add_mfma(const double* dd, double* P, double scale, const double* tb,
                                                  const double* Hg = nullptr, bool ow = false) {
         // (a team of wavefronts splits the passes over the tile rows: W::NTEAM, mpcqp_devwave.h)
-        if constexpr (W::NTEAM > 1) w.post(TJ_ETDE, (int)(dd - sm), (int)(P - sm), tb ? (int)(tb - sm) : -1, (ow ? 1 : 0) | (Hg ? 2 : 0), scale);
-        const int e = EtDE_share(dd, P, scale, tb, Hg, ow);
+        if constexpr (W::NTEAM > 1) w.post(TJ_ETDE, (int)(dd - sm), (int)(P - sm), tb ? (int)(tb - sm) : 0, (ow ? 1 : 0) | (Hg ? 2 : 0) | (tb ? 4 : 0), scale);
+        const int e = EtDE_share(dd, P, scale, tb ? tb : dd, Hg, ow, tb != nullptr);
         if constexpr (W::NTEAM > 1) w.join();
         return e;
     }
-    __device__ __forceinline__ int EtDE_share(const double* dd, double* P, double scale, const double* tb, const double* Hg, bool ow) {
+    __device__ __forceinline__ int EtDE_share(const double* dd, double* P, double scale, const double* tb, const double* Hg, bool ow, bool has_tb) {
+        MPCQP_SETPRIO(4, 0);
+        const int e = EtDE_share_(dd, P, scale, tb, Hg, ow, has_tb);
+        MPCQP_SETPRIO(4, 1);
+        return e;
+    }
+    // (tb: a pointer into LDS also when there is no ϵ row to ride -- has_tb says so: a select with nullptr makes the pointer generic)
+    __device__ __forceinline__ int EtDE_share_(const double* dd, double* P, double scale, const double* tb, const double* Hg, bool ow, bool has_tb) {
         MPCQP_RELANE(2);
         ow = ow || Hg != nullptr;
         constexpr int NU = DM::nu, NY = DM::ny, NDU = DM::nDU, NYR = DM::nY, SP = DM::sp, RS = DM::rs;
@@ -809,7 +863,7 @@ struct Qp {
         // first step whose rows the ϵ row is accumulated for by the pass of its tile row (kfirst() below; known up front: in a
         // team that pass may run on another wavefront)
         int eps_t0 = -1;
-        if (DM::neps && tb != nullptr && IE < NT) {
+        if (DM::neps && has_tb && IE < NT) {
             int v = (jl((16 * IE) / NU) * NY) / 4;
             v = v < NK ? v : NK;
             if ((4 * v) % NY != 0) v = 0;
@@ -833,7 +887,7 @@ struct Qp {
         auto pass = [&](auto I0c) {
             constexpr int I0 = decltype(I0c)::value;
             if constexpr (W::NTEAM > 1) {                 // pass number (I0 == 0 ? 0 : I0 - 1) mod NTEAM owns the pass
-                if constexpr ((I0 == 0 ? 0 : I0 - 1) % W::NTEAM != W::WV) return;
+                if constexpr (!team_mine_mfma<W>(I0 == 0 ? 0 : I0 - 1)) return;
             }
             constexpr int MAXT = NT + 1;
             constexpr int I1 = (I0 == 0 && NT > 1) ? 1 : I0;          // last tile row of the pass
@@ -845,7 +899,7 @@ struct Qp {
             }
             // ϵ row (index NDU, when present): row NDU of Phi is sum_r tb[r] E[r,:], i.e. the same
             // contraction with A operand tb instead of E*dd -- rides in its tile row for free
-            const bool erow = DM::neps && tb != nullptr && IE >= I0 && IE <= I1;
+            const bool erow = DM::neps && has_tb && IE >= I0 && IE <= I1;
             // entry (reg) of tile (I, J) held by this lane: row i = 16 I + 4 reg + lk, column ip = 16 J + li; with
             // G = 4 I + reg the packed index pk(i, ip) = 8 G (G + 1) + 16 J + 4 (G + 1) lk + li is linear in the lane's
             // (lk, li) with compile-time coefficients
@@ -876,7 +930,11 @@ struct Qp {
                     }
                 }
             };
-            if (Hg && !VREG) hload();
+            // (problems of many tile rows: H̃ is requested in the LAST QUARTER of the K loop instead of in front of it -- up to
+            //  NT + 1 tiles of four doubles live next to as many accumulators and the row state of several rows per lane
+            //  spilled; the loop is long enough there to cover the loads from its last steps on)
+            constexpr bool LATEH = !VREG && NT > 4;
+            if (Hg && !VREG && !LATEH) hload();
             // First K step at which tile row I sees a block column that has started (t >= j_l of
             // its first column); the ϵ row needs every step.  The K loop is split at these points
             // so that its bodies are branch-free (accumulators stay in place across iterations).
@@ -939,7 +997,7 @@ struct Qp {
                 constexpr bool EP = DM::neps != 0 && IE >= I0 && IE <= I1;      // the ϵ row can ride in this pass
                 double dvb[2][CH], tbb[2][EP ? CH : 1];
                 const double* ddl = dd + lkp;
-                const double* tbl = erow ? tb + lkp : dd + lkp;
+                const double* tbl = tb + lkp;
                 auto ldc = [&](int c0, int buf) {
                     MPCQP_UNROLL
                     for (int u = 0; u < CH; ++u) {
@@ -977,12 +1035,24 @@ struct Qp {
             constexpr bool PIPE = (NY % 4 == 0) && DM::zpad > 0;
             Ops cur, nxt;
             if (PIPE) kload(kA, cur);
+            // (one-row passes run kA .. NK in the first loop; with LATEH it stops three quarters of the way for the H̃ requests)
+            const int kB1 = (LATEH && I1 == I0) ? kA + (3 * (kB - kA)) / 4 : kB;
             MPCQP_PRAGMA(unroll MPCQP_ETDE_UNROLL)
-            for (int kk = kA; kk < kB; ++kk) {
+            for (int kk = kA; kk < kB1; ++kk) {
                 if (PIPE) { kload(kk + 1, nxt); MPCQP_SCHED_FENCE(); kcomp(cur, true, false); MPCQP_SCHED_FENCE(); cur = nxt; }
                 else { kload(kk, cur); kcomp(cur, true, false); }
             }
+            if (LATEH && I1 == I0) {
+                if (Hg) hload();
+                MPCQP_SCHED_FENCE();
+                MPCQP_PRAGMA(unroll MPCQP_ETDE_UNROLL)
+                for (int kk = kB1; kk < kB; ++kk) {
+                    if (PIPE) { kload(kk + 1, nxt); MPCQP_SCHED_FENCE(); kcomp(cur, true, false); MPCQP_SCHED_FENCE(); cur = nxt; }
+                    else { kload(kk, cur); kcomp(cur, true, false); }
+                }
+            }
             if (I1 > I0) {
+                if (LATEH && Hg) hload();
                 MPCQP_PRAGMA(unroll MPCQP_ETDE_UNROLL)
                 for (int kk = kB; kk < NK; ++kk) {
                     if (PIPE) { kload(kk + 1, nxt); MPCQP_SCHED_FENCE(); kcomp(cur, true, true); MPCQP_SCHED_FENCE(); cur = nxt; }
@@ -2137,9 +2207,24 @@ struct Step {
     // ---- Phi <- H̃ (global -> LDS) ------------------------------------------------------------
     MPCQP_HD void load_H() {
         MPCQP_RELANE(11);
-        const double* H = m.Hpk + (size_t)b * d.npk;
-        for (int i = w.lane; i < d.npk; i += WAVE) Phi[i] = H[i];
+        if constexpr (W::NTEAM > 1) w.post(TJ_LOADH);
+        load_H_share();
+        if constexpr (W::NTEAM > 1) w.join();
         w.sync();
+    }
+    // (eight loads of a lane in flight -- Qp::stage; a plain copy loop is one memory latency per trip: 180 trips at nZ~ = 151 --
+    //  and a team's wavefronts take interleaved chunks of 64)
+    MPCQP_HD void load_H_share() {
+        const double* H = m.Hpk + (size_t)b * d.npk;
+        constexpr int NB = 8;
+        const int n = d.npk, stride = WAVE * W::NTEAM;
+        for (int i0 = WAVE * W::WV; i0 < n; i0 += NB * stride) {
+            double v[NB];
+            MPCQP_UNROLL
+            for (int q_ = 0; q_ < NB; ++q_) { const int i = i0 + w.lane + stride * q_; v[q_] = H[i < n ? i : 0]; }
+            MPCQP_UNROLL
+            for (int q_ = 0; q_ < NB; ++q_) { const int i = i0 + w.lane + stride * q_; if (i < n) Phi[i] = v[q_]; }
+        }
     }
 
     // true: add_GtDG() builds Phi = H̃ + G'DG itself, H̃ read from global memory by the matrix-core pass of the Ŷ rows
@@ -2166,7 +2251,7 @@ struct Step {
     MPCQP_HD void GtDG_urows_share() {
         const int nu = d.nu, nDU = d.nDU;
         const double* tU = sm + c.tA[P_U];
-        for (int k = w.lane + WAVE * W::WV; k < nDU; k += WAVE * W::NTEAM) {
+        for (int k = w.lane + WAVE * ((W::WV + W::NTEAM - 1) % W::NTEAM); k < nDU; k += WAVE * W::NTEAM) {
             const int j = k / nu, cc = k - j * nu;
             const double suf = tU[k];
             MPCQP_PRAGMA(unroll MPCQP_URMW_UNROLL)
@@ -2397,7 +2482,7 @@ struct Step {
         constexpr int n = DM::nZ, NT = (n + 15) / 16;
         if constexpr (P < NT) {
             const int li = w.lane & 15, lk = w.lane >> 4;
-            auto mine = [](int I) { return (I - P) % W::NTEAM == W::WV; };       // row tile I of this wavefront (compile-time after unrolling)
+            auto mine = [](int I) { return team_mine_mfma<W>(I - P); };       // row tile I of this wavefront (compile-time after unrolling)
             const double* X[NT];
             v4d_ acc[NT];
             MPCQP_UNROLL
@@ -2406,7 +2491,7 @@ struct Step {
                 X[I] = Phi + pk(row, 0) + lk;
                 acc[I] = v4d_{0.0, 0.0, 0.0, 0.0};
             }
-            if constexpr (NT - P > W::WV) {
+            if constexpr (team_any_mfma<W>(NT - P)) {
             MPCQP_PRAGMA(unroll MPCQP_PANEL_UNROLL)
             for (int kk = 0; kk < 4 * P; ++kk) {
                 const double bb = X[P][4 * kk];
@@ -2659,6 +2744,11 @@ struct Step {
     // coordinate for this Newton step (zero column, 1/L = 1e-32) instead of poisoning the factor.
     MPCQP_HD_CHOL void cholesky() {
         if (d.nZ > WAVE) { cholesky_big(); return; }      // (a compile-time branch with compile-time dims)
+        MPCQP_SETPRIO(1, 1);
+        cholesky_();
+        MPCQP_SETPRIO(1, 0);
+    }
+    MPCQP_HD_CHOL void cholesky_() {
         MPCQP_RELANE(8);
         MPCQP_TIC();
         const int n = d.nZ;
@@ -2913,8 +3003,13 @@ struct Step {
     // block the zero diagonal slot / pad entries do the masking.  The chunk of the next group is fetched ahead of the dependent chain, which is then
     // v_mul -> v_readlane -> v_fma per column.
     MPCQP_HD void solve_into_dz() {
-        MPCQP_RELANE(4);
         if (d.nZ > WAVE) { solve_big(); return; }
+        MPCQP_SETPRIO(2, 1);
+        solve_into_dz_();
+        MPCQP_SETPRIO(2, 0);
+    }
+    MPCQP_HD void solve_into_dz_() {
+        MPCQP_RELANE(4);
         MPCQP_TIC();
 #if defined(__HIP_DEVICE_COMPILE__) && MPCQP_SOLVE_DPP
         if constexpr (one_row_per_lane<DM>()) {
@@ -3054,8 +3149,65 @@ struct Step {
     // broadcasts of the pivot lane's, one multiply-add per later column and row slot.  No LDS round trip and no fence
     // inside the panel (the column-at-a-time loop of the runtime dims needs two fences and several dependent LDS reads
     // per column).  thr: pivot thresholds of the lane's rows (1e-14 of the original diagonal).
+    // A team of wavefronts (W::NTEAM > 1): wavefront 0 factors the pivot slot only (NSE = so + 1: the 16 x 16 diagonal block and
+    // the other rows of its slot); the row slots below take their 16 panel entries through a triangular solve with the
+    // diagonal block read back from LDS (wave-uniform addresses: broadcast reads, no v_readlane), one slot per wavefront
+    // (chol_big_panel_rows).  profiles/r6c: the one-wavefront form took 11k cycles per panel at nZ~ = 151 (three slots,
+    // 240 v_readlane + 408 FP64 instructions per panel on the pivot chain's wavefront), 110k of the 347k cycles of an iteration.
+    template <int P, int NS>
+    __device__ __forceinline__ void chol_big_panel_rows() {
+        constexpr int n = DM::nZ, K0 = 16 * P, KC = (n - K0 < 16) ? n - K0 : 16, so = K0 / WAVE;
+        if constexpr (KC == 16) {                      // (a shorter last panel has no rows below it)
+            const double* dinv = sm + c.dinv;
+            auto lk = [&](int r, int cc) { return Phi[pk(K0 + r, 0) + K0 + cc]; };      // L[K0 + r][K0 + cc], wave-uniform
+            MPCQP_UNROLL
+            for (int s_ = so + 1; s_ < NS; ++s_) {
+                if ((s_ - so) % W::NTEAM != W::WV) continue;             // (slot so + 1 to wavefront 1, ..: wavefront 0 last)
+                const int i = w.lane + WAVE * s_;
+                const bool mine = i < n;
+                double* row = Phi + pk(mine ? i : 0, 0) + K0;
+                double x[16];
+                MPCQP_UNROLL
+                for (int u = 0; u < 4; ++u) load4(mine ? row + 4 * u : sm + c.zero, &x[4 * u]);
+                MPCQP_UNROLL
+                for (int cc = 0; cc < 16; ++cc) {
+                    const double dv = dinv[K0 + cc];
+                    x[cc] *= dv > 1e-32 ? dv : 0.0;                   // (a pivot below its threshold: zero column, as in the pivot slot)
+                    MPCQP_UNROLL
+                    for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] = fma(-x[cc], lk(c2, cc), x[c2]);
+                    if (cc % 4 == 3) MPCQP_SCHED_FENCE();            // (bounds the broadcast reads in flight: registers)
+                }
+                if (mine) {
+                    MPCQP_UNROLL
+                    for (int u = 0; u < 4; ++u) store4(row + 4 * u, &x[4 * u]);
+                }
+            }
+        }
+    }
+    template <int P>
+    __device__ __forceinline__ void panel_rows_dispatch(int p) {
+        if constexpr (P < (DM::nZ + 15) / 16) {
+            if (p == P) chol_big_panel_rows<P, (DM::nZ + WAVE - 1) / WAVE>();
+            else panel_rows_dispatch<P + 1>(p);
+        }
+    }
     template <int P, int NS>
     __device__ __forceinline__ void chol_big_panel_reg(const double (&thr)[NS], bool& broke) {
+        if constexpr (W::NTEAM > 1) {
+            constexpr int so_ = (16 * P) / WAVE;
+            chol_big_panel_slots<P, NS, (so_ + 1 < NS ? so_ + 1 : NS)>(thr, broke);      // (ends with a wave fence: its stores are issued)
+            if constexpr (so_ + 1 < NS && DM::nZ - 16 * P >= 16 && !(MPCQP_ABLATE & 1024)) {
+                w.post(TJ_PANELROWS, P);
+                chol_big_panel_rows<P, NS>();
+                w.join();
+            }
+        } else {
+            chol_big_panel_slots<P, NS, NS>(thr, broke);
+        }
+    }
+    // (row slots so .. NSE-1 of the panel)
+    template <int P, int NS, int NSE>
+    __device__ __forceinline__ void chol_big_panel_slots(const double (&thr)[NS], bool& broke) {
         constexpr int n = DM::nZ, K0 = 16 * P, KC = (n - K0 < 16) ? n - K0 : 16, NCH = (KC + 3) / 4;
         constexpr int so = K0 / WAVE, lb = K0 % WAVE;
         const double* zero4 = sm + c.zero;
@@ -3064,7 +3216,7 @@ struct Step {
         bool mine[NS];
         int rowo[NS];
         MPCQP_UNROLL
-        for (int s_ = so; s_ < NS; ++s_) {
+        for (int s_ = so; s_ < NSE; ++s_) {
             const int i = w.lane + WAVE * s_;
             mine[s_] = i < n && i >= K0;
             rowo[s_] = pk(mine[s_] ? i : 0, 0) + K0;
@@ -3082,19 +3234,19 @@ struct Step {
             const double idb = w.bcast(idl, lb + cc);
             mydinv = (w.lane == lb + cc) ? idl : mydinv;
             MPCQP_UNROLL
-            for (int s_ = so; s_ < NS; ++s_) v[s_][cc] *= idb;            // rows below the pivot: L[i][k]
+            for (int s_ = so; s_ < NSE; ++s_) v[s_][cc] *= idb;            // rows below the pivot: L[i][k]
             MPCQP_UNROLL
             for (int c2 = cc + 1; c2 < KC; ++c2) {
                 const double bv = w.bcast(v[so][cc], lb + c2);            // L[K0 + c2][k]
                 MPCQP_UNROLL
-                for (int s_ = so; s_ < NS; ++s_) v[s_][c2] = fma(-v[s_][cc], bv, v[s_][c2]);
+                for (int s_ = so; s_ < NSE; ++s_) v[s_][c2] = fma(-v[s_][cc], bv, v[s_][c2]);
             }
         }
         // rows of the panel itself keep zeros on and right of the diagonal; stores only where the row is that long
         MPCQP_UNROLL
         for (int cc = 0; cc < KC; ++cc) v[so][cc] = (w.lane > lb + cc) ? v[so][cc] : 0.0;
         MPCQP_UNROLL
-        for (int s_ = so; s_ < NS; ++s_) {
+        for (int s_ = so; s_ < NSE; ++s_) {
             const int i = w.lane + WAVE * s_;
             MPCQP_UNROLL
             for (int u = 0; u < NCH; ++u)
@@ -3164,7 +3316,7 @@ struct Step {
         MPCQP_UNROLL
         for (int so = 0; so < NS; ++so) {
             const int nch = (((n - WAVE * so < WAVE) ? n - WAVE * so : WAVE) + 3) / 4;
-            _Pragma("unroll 2")
+            MPCQP_PRAGMA(unroll MPCQP_SOLVEBIG_UNROLL)
             for (int g = 0; g < nch; ++g) {
                 const int k0 = WAVE * so + 4 * g;
                 double x[NS][4];
@@ -3189,7 +3341,7 @@ struct Step {
         MPCQP_UNROLL
         for (int so = NS - 1; so >= 0; --so) {
             const int nch = (((n - WAVE * so < WAVE) ? n - WAVE * so : WAVE) + 3) / 4;
-            _Pragma("unroll 2")
+            MPCQP_PRAGMA(unroll MPCQP_SOLVEBIG_UNROLL)
             for (int g = nch - 1; g >= 0; --g) {
                 const int k0 = WAVE * so + 4 * g;
                 const double* pg = Phi + pk(k0, 0);
@@ -3256,9 +3408,33 @@ struct Step {
 
     // rd = H̃ z + q + gt (gt = G' multipliers) with H̃ packed at Hp_ (LDS or global memory);
     // returns max |rd| and 1 + the largest term of the sum
+    // rd[k] <- (H̃ z)[k] for the rows k of this wavefront's slots (team form of the loop in dual_residual)
+    MPCQP_HD void Hz_rows_share(const double* Hp_) {
+        const int n = d.nZ;
+        for (int k = w.lane + WAVE * ((W::WV + W::NTEAM - 1) % W::NTEAM); k < n; k += WAVE * W::NTEAM) {
+            double h0 = 0.0, h1 = 0.0;
+            const double* Hk = Hp_ + pk(k, 0);
+            int j = 0;
+            MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
+            for (; j + 1 <= k; j += 2) { h0 += Hk[j] * z[j]; h1 += Hk[j + 1] * z[j + 1]; }
+            if (j <= k) h0 += Hk[j] * z[j];
+            MPCQP_PRAGMA(unroll MPCQP_HZ_UNROLL)
+            for (int jj = k + 1; jj < n; ++jj) h1 += Hp_[pk(jj, k)] * z[jj];
+            rd[k] = h0 + h1;
+        }
+    }
     MPCQP_HD void dual_residual(const double* Hp_, double& rdn, double& nd_) {
         const int n = d.nZ;
         double mx = 0.0, sc = 0.0;
+        if constexpr (W::NTEAM > 1) {
+            if (Hp_) {                  // the rows of H̃ z over the team, then the rest as if rd held H̃ z already
+                w.post(TJ_HZ, Hp_ == Phi ? 1 : 0);
+                if (Hp_ == Phi) Hz_rows_share(Phi);
+                else Hz_rows_share(m.Hpk + (size_t)b * d.npk);          // (the only other caller's argument: polish)
+                w.join();
+                Hp_ = nullptr;
+            }
+        }
         for (int k = w.lane; k < n; k += WAVE) {
             // H̃ z with the packed lower triangle: row k up to the diagonal is contiguous,
             // the rest of the (symmetric) row comes from column k of the rows below
@@ -3771,6 +3947,7 @@ struct Step {
 
 template <class W, class DM>
 MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int b, double* sm) {
+    MPCQP_SETPRIO(4, 1);
     const long long t_in_ = Step<W, DM>::clock64_();
     Qp<W, DM> qp(w, d, m, b, sm);
     qp.load_tables();
@@ -3873,13 +4050,16 @@ __device__ __forceinline__ void team_helper(W& w, const DM& d, const Model& m, i
         const int* mi = reinterpret_cast<const int*>(w.mbox);
         const int job = __builtin_amdgcn_readfirstlane(mi[0]);
         if (job == TJ_EXIT) break;
+        // (the lane id laundered per job: otherwise the address arithmetic of EVERY job's share is hoisted in front of this
+        //  loop and kept in -- spilled -- registers: 500 spill slots and 87 scratch stores in the helper's prologue, nZ~ = 151)
+        w.relane();
         const int a0 = __builtin_amdgcn_readfirstlane(mi[1]), a1 = __builtin_amdgcn_readfirstlane(mi[2]);
         const int a2 = __builtin_amdgcn_readfirstlane(mi[3]), a3 = __builtin_amdgcn_readfirstlane(mi[4]);
         const double sc = w.mbox[3];
         switch (job) {
             case TJ_ETDE:
                 if constexpr (DM::is_static)
-                    (void)qp.EtDE_share(sm + a0, sm + a1, sc, a2 >= 0 ? sm + a2 : nullptr, (a3 & 2) ? m.Hpk + (size_t)b * d.npk : nullptr, (a3 & 1) != 0);
+                    (void)qp.EtDE_share(sm + a0, sm + a1, sc, sm + a2, (a3 & 2) ? m.Hpk + (size_t)b * d.npk : nullptr, (a3 & 1) != 0, (a3 & 4) != 0);
                 break;
             case TJ_PANEL: st.template panel_dispatch<1>(a0); break;
             case TJ_EV: qp.E_apply_share(sm + a0, sm + a1); break;
@@ -3887,6 +4067,12 @@ __device__ __forceinline__ void team_helper(W& w, const DM& d, const Model& m, i
             case TJ_UROWS: st.GtDG_urows_share(); break;
             case TJ_XROWS: st.GtDG_xrows_share(); break;
             case TJ_WROWS: st.GtDG_wrows_share(); break;
+            case TJ_PANELROWS: st.template panel_rows_dispatch<0>(a0); break;
+            case TJ_LOADH: st.load_H_share(); break;
+            case TJ_HZ:          // (two calls: a select between an LDS and a global pointer would make every access a flat one)
+                if (a0) st.Hz_rows_share(st.Phi);
+                else st.Hz_rows_share(m.Hpk + (size_t)b * d.npk);
+                break;
             default: break;
         }
         w.join();

@@ -60,7 +60,7 @@
 namespace mpcqp {
 
 // jobs a team's wavefront 0 hands to its helpers (DevWaveT, mpcqp_devwave.h; W::NTEAM == 1: never posted)
-enum TeamJob { TJ_EXIT = 0, TJ_ETDE = 1, TJ_PANEL = 2, TJ_EV = 3, TJ_ETW = 4, TJ_UROWS = 5, TJ_WROWS = 6, TJ_XROWS = 7 };
+enum TeamJob { TJ_EXIT = 0, TJ_ETDE = 1, TJ_PANEL = 2, TJ_EV = 3, TJ_ETW = 4, TJ_UROWS = 5, TJ_WROWS = 6, TJ_XROWS = 7, TJ_PANELROWS = 8, TJ_LOADH = 9, TJ_HZ = 10 };
 
 
 enum { P_BOX = 0, P_U = 1, P_DU = 2, P_Y = 3, P_X = 4, P_W = 5, NPAIR = 6, NGROUP = 12 };

@@ -14,6 +14,6 @@ for v in "$@"; do
   dir=$ROOT/modelpredictivecontrol.jl_amd/lib/ab/jit/$name; mkdir -p $dir; chmod 700 $dir; rm -f $dir/*
   so=$dir/spec_r${REV}_c${CID}_${nu}_${ny}_${nxh}_${Hp}_${Hc}_${neps}_$(printf %x $rows)_${dnb}.so
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -w -I$CSRC \
-      -DMPCQP_SPEC_DIMS=$nu,$ny,$nxh,$Hp,$Hc,$neps,${rows}u,$dnb $WAVES $flags $CSRC/mpcqp_spec.hip -o $so && echo "built $name: $flags" ) &
+      -DMPCQP_SPEC_DIMS=$nu,$ny,$nxh,$Hp,$Hc,$neps,${rows}u,$dnb $WAVES -mllvm -pragma-unroll-threshold=1048576 $flags $CSRC/mpcqp_spec.hip -o $so && echo "built $name: $flags" ) &
 done
 wait

@@ -9,7 +9,8 @@ from tests.parity_util import make_controller, rel_err
 cfg = synth.get_config(sys.argv[1] if len(sys.argv) > 1 else "C3")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 DR = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0        # dual regularisation of the MultipleShooting run (0: default)
-bt = synth.make_batch(cfg, B, seed=5)
+import os
+bt = synth.make_batch(cfg, B, seed=int(os.environ.get("MS_SEED", 5)))
 out = {}
 for tr in ("SingleShooting", "MultipleShooting"):
     with warnings.catch_warnings():

@@ -67,7 +67,7 @@ def test_transcriptions_agree_on_C3(hiplib):
     specialisation return the same ΔU, ϵ and Ŷ."""
     from tests.parity_util import make_controller
     cfg = synth.C3
-    bt = synth.make_batch(cfg, 512, seed=5)
+    bt = synth.make_batch(cfg, 2048, seed=5)
     out = {}
     import warnings
     for tr in ("SingleShooting", "MultipleShooting"):
@@ -85,13 +85,14 @@ def test_transcriptions_agree_on_C3(hiplib):
     # iteration limit where the condensed kernel converges (3 of 8192 in the bench batch): such a solve is FLAGGED
     # (status 1, the reference's @warn branch keeps the iterate, execute.jl:491-496) and is adjudicated here against the
     # condensed optimum -- the kept iterate must still be that optimum to 1e-3; every solve called OPTIMAL agrees to TOL.
+    # (round 6: held to the condensed kernels' bar -- every controller OPTIMAL and within TOL; rounds 4-5 accepted 0.5 % at the
+    #  iteration limit with 1e-3.  Measured: 2048 of 2048 on this seed, 8192 of 8192 on the bench batch, worst difference
+    #  3.8e-7: profiles/r6e/ms_c3_seed0.txt, profiles/r6c/stage_diag.txt)
     ok = st_ms == 0
-    assert ok.mean() >= 0.995, ok.mean()
+    assert ok.all(), (ok.mean(), np.flatnonzero(~ok)[:8])
     nDU = cfg.nu * cfg.Hc
-    assert rel_err(out["MultipleShooting"][0][ok], out["SingleShooting"][0][ok], nDU).max() <= TOL
-    assert np.abs(out["MultipleShooting"][1][ok] - out["SingleShooting"][1][ok]).max() <= 1e-4
-    if not ok.all():
-        assert rel_err(out["MultipleShooting"][0][~ok], out["SingleShooting"][0][~ok], nDU).max() <= 1e-3
+    assert rel_err(out["MultipleShooting"][0], out["SingleShooting"][0], nDU).max() <= TOL
+    assert np.abs(out["MultipleShooting"][1] - out["SingleShooting"][1]).max() <= 1e-4
 
 
 def test_multiple_shooting_known_answers_run_on_the_ms_kernel(hiplib):
