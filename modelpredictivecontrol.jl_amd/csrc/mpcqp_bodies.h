@@ -160,9 +160,10 @@
 #endif
 // teams of three or more wavefronts: 0 keeps wavefront 0 (which carries the row state of the whole problem in registers) out of
 // the matrix-core shares (E'DE passes, panel updates): the helpers split them among themselves.  Measured at nZ~ = 151, four
-// wavefronts (profiles/r6f): with wavefront 0 in 826 spilled registers and 20.8 ms per 2048 solves, without 352 and 17.8 ms
+// wavefronts, 4096 controllers (profiles/r6h, after the spill of the substitution's relane site was repaired): 31.3 ms with
+// wavefront 0 in, 31.8 ms without
 #ifndef MPCQP_TEAM_MAIN_MFMA
-#define MPCQP_TEAM_MAIN_MFMA 0
+#define MPCQP_TEAM_MAIN_MFMA 1
 #endif
 #ifndef MPCQP_HZ_UNROLL
 #define MPCQP_HZ_UNROLL 4         // terms per unrolled pass of the two loops of H~ z (dual_residual)
@@ -3003,13 +3004,13 @@ struct Step {
     // block the zero diagonal slot / pad entries do the masking.  The chunk of the next group is fetched ahead of the dependent chain, which is then
     // v_mul -> v_readlane -> v_fma per column.
     MPCQP_HD void solve_into_dz() {
+        MPCQP_RELANE(4);          // (in front of the several-rows-per-lane form too: without it the nZ~ = 106 kernel spills 748 registers instead of 6)
         if (d.nZ > WAVE) { solve_big(); return; }
         MPCQP_SETPRIO(2, 1);
         solve_into_dz_();
         MPCQP_SETPRIO(2, 0);
     }
     MPCQP_HD void solve_into_dz_() {
-        MPCQP_RELANE(4);
         MPCQP_TIC();
 #if defined(__HIP_DEVICE_COMPILE__) && MPCQP_SOLVE_DPP
         if constexpr (one_row_per_lane<DM>()) {
@@ -3160,11 +3161,12 @@ struct Step {
         if constexpr (KC == 16) {                      // (a shorter last panel has no rows below it)
             const double* dinv = sm + c.dinv;
             auto lk = [&](int r, int cc) { return Phi[pk(K0 + r, 0) + K0 + cc]; };      // L[K0 + r][K0 + cc], wave-uniform
+            // (the pivot slot's rows below the diagonal block are rows like any other: chol_big_panel_diag)
             MPCQP_UNROLL
-            for (int s_ = so + 1; s_ < NS; ++s_) {
-                if ((s_ - so) % W::NTEAM != W::WV) continue;             // (slot so + 1 to wavefront 1, ..: wavefront 0 last)
+            for (int s_ = so; s_ < NS; ++s_) {
+                if ((s_ - so + 1) % W::NTEAM != W::WV) continue;         // (slot so to wavefront 1, ..: wavefront 0 last)
                 const int i = w.lane + WAVE * s_;
-                const bool mine = i < n;
+                const bool mine = i < n && i >= K0 + 16;
                 double* row = Phi + pk(mine ? i : 0, 0) + K0;
                 double x[16];
                 MPCQP_UNROLL
@@ -3191,15 +3193,72 @@ struct Step {
             else panel_rows_dispatch<P + 1>(p);
         }
     }
+    // The 16 x 16 diagonal block of panel P alone, in the 16 lanes of its DPP row (16 P is a multiple of 16, so the block's rows
+    // are one row of lanes): the column step broadcasts inside the row with the DPP modifier of the instructions themselves
+    // (v_mov_b64_dpp / v_fmac_f64_dpp row_newbcast) -- one instruction per (column, later column) pair where the v_readlane
+    // form of chol_big_panel_slots takes three.  The other lanes run along on zeros.
+    template <int P, int NS>
+    __device__ __forceinline__ void chol_big_panel_diag(const double (&thr)[NS], bool& broke) {
+        constexpr int K0 = 16 * P, so = K0 / WAVE, lb = K0 % WAVE;
+        const int lr = w.lane & 15;
+        const bool inblk = (w.lane >> 4) == (lb >> 4);
+        double* row = Phi + pk(K0 + lr, 0) + K0;
+        double* dinv = sm + c.dinv;
+        double v[16];
+        MPCQP_UNROLL
+        for (int u = 0; u < 4; ++u) load4((inblk && lr >= 4 * u) ? row + 4 * u : sm + c.zero, &v[4 * u]);
+        double mydinv = 0.0;
+        MPCQP_UNROLL
+        for (int cc = 0; cc < 16; ++cc) chol_diag_col(cc, v, thr[so], lr, mydinv);
+        MPCQP_UNROLL
+        for (int cc = 0; cc < 16; ++cc) v[cc] = (lr > cc) ? v[cc] : 0.0;       // zeros on and right of the diagonal
+        MPCQP_UNROLL
+        for (int u = 0; u < 4; ++u)
+            if (inblk && lr >= 4 * u) store4(row + 4 * u, &v[4 * u]);
+        if (inblk) dinv[K0 + lr] = fmx(mydinv, 1e-32);
+        broke = broke || (inblk && mydinv <= 1e-32);
+        w.sync();
+    }
+    __device__ __forceinline__ void chol_diag_col(int cc, double (&v)[16], double thr, int lr, double& mydinv) {
+        // (cc is a compile-time value after unrolling; the DPP lane is an immediate: one case per column)
+        switch (cc) {
+#define MPCQP_DIAG_COL_(C) case C: chol_diag_col_<C>(v, thr, lr, mydinv); break;
+            MPCQP_DIAG_COL_(0) MPCQP_DIAG_COL_(1) MPCQP_DIAG_COL_(2) MPCQP_DIAG_COL_(3) MPCQP_DIAG_COL_(4) MPCQP_DIAG_COL_(5)
+            MPCQP_DIAG_COL_(6) MPCQP_DIAG_COL_(7) MPCQP_DIAG_COL_(8) MPCQP_DIAG_COL_(9) MPCQP_DIAG_COL_(10) MPCQP_DIAG_COL_(11)
+            MPCQP_DIAG_COL_(12) MPCQP_DIAG_COL_(13) MPCQP_DIAG_COL_(14) MPCQP_DIAG_COL_(15)
+#undef MPCQP_DIAG_COL_
+            default: break;
+        }
+    }
+    template <int C>
+    __device__ __forceinline__ void chol_diag_col_(double (&v)[16], double thr, int lr, double& mydinv) {
+        const double piv = v[C];
+        const double idl = (piv > thr) ? rsqrt_(piv) : 0.0;          // lane C of the row: 1/sqrt(pivot), 0 if bad
+        const double idb = W::template rowbc<C>(idl);
+        mydinv = (lr == C) ? idl : mydinv;
+        v[C] *= idb;                                                 // rows below the pivot: L[i][k]
+        chol_diag_upd_<C, C + 1>(v);
+    }
+    template <int C, int C2>
+    __device__ __forceinline__ void chol_diag_upd_(double (&v)[16]) {
+        if constexpr (C2 < 16) {
+            W::template rowbc_fms<C2, C2 == C + 1>(v[C2], v[C], v[C]);       // v[c2] -= L[K0 + c2][k] * L[i][k]
+            chol_diag_upd_<C, C2 + 1>(v);
+        }
+    }
     template <int P, int NS>
     __device__ __forceinline__ void chol_big_panel_reg(const double (&thr)[NS], bool& broke) {
         if constexpr (W::NTEAM > 1) {
             constexpr int so_ = (16 * P) / WAVE;
-            chol_big_panel_slots<P, NS, (so_ + 1 < NS ? so_ + 1 : NS)>(thr, broke);      // (ends with a wave fence: its stores are issued)
-            if constexpr (so_ + 1 < NS && DM::nZ - 16 * P >= 16 && !(MPCQP_ABLATE & 1024)) {
-                w.post(TJ_PANELROWS, P);
-                chol_big_panel_rows<P, NS>();
-                w.join();
+            if constexpr (DM::nZ - 16 * P >= 16) {
+                chol_big_panel_diag<P, NS>(thr, broke);                 // (ends with a wave fence: its stores are issued)
+                if constexpr (DM::nZ - 16 * P > 16 && !(MPCQP_ABLATE & 1024)) {
+                    w.post(TJ_PANELROWS, P);
+                    chol_big_panel_rows<P, NS>();
+                    w.join();
+                }
+            } else {
+                chol_big_panel_slots<P, NS, (so_ + 1 < NS ? so_ + 1 : NS)>(thr, broke);      // (a shorter last panel: nothing below it)
             }
         } else {
             chol_big_panel_slots<P, NS, NS>(thr, broke);

@@ -135,6 +135,18 @@ struct DevWave {
                 : "+v"(r)
                 : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "n"(K), "n"(K + 1), "n"(K + 2), "n"(K + 3), "n"(ROWS));
     }
+    // value of v in lane C of this lane's 16-lane row (one v_mov_b64_dpp row_newbcast)
+    template <int C>
+    static __device__ __forceinline__ double rowbc(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + C, 0xf, 0xf, true); }
+    // a -= (x of lane L of this lane's row) * y: the row broadcast is the multiply-add's own DPP modifier.  NOP: x may have been
+    // written by the VALU instruction right before (two wait states the compiler does not see inside the asm)
+    template <int L, bool NOP>
+    static __device__ __forceinline__ void rowbc_fms(double& a, double x, double y) {
+        if constexpr (NOP)
+            asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(x), "v"(y), "n"(L));
+        else
+            asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(x), "v"(y), "n"(L));
+    }
     // acc += sum_u (x of lane K+u of this lane's row) * c_u, rows of ROWS only (x is not written inside the block)
     template <int K, int ROWS>
     static __device__ __forceinline__ void fmabc4(double& acc, double x, double c0, double c1, double c2, double c3) {

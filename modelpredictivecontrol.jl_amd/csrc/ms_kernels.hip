@@ -32,6 +32,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPCQP_MS_WAV
     // its iteration limit (80 iterations against a mean of 13) then delays its own wavefront, not a fixed share of the
     // batch -- with the static assignment b = blockIdx + k gridDim one such controller set the time of the whole launch
     // (measured: 131 ms for 2048 C3 controllers of which one is at the limit, 25 ms of work per wavefront otherwise)
+#ifdef MPCQP_MS_CONST_EXP
+    // (experiment: what compile-time dimensions would buy this kernel -- the bench shape 6,2,2,50,50 with its dimensions as constants)
+    if (d.nxh == 8 && d.nu == 2 && d.ny == 2 && d.Hp == 50 && d.Hc == 50 && d.neps == 1 && d.nd == 0 && d.nw == 0 && d.default_nb == 1) {
+        Dims dc = d;
+        dc.nxh = 8; dc.nu = 2; dc.ny = 2; dc.Hp = 50; dc.Hc = 50; dc.neps = 1; dc.nd = 0; dc.nD = 0; dc.nw = 0; dc.nW = 0;
+        dc.nDU = 100; dc.nZ = 101; dc.nU = 100; dc.nY = 100; dc.default_nb = 1;
+        for (;;) {
+            int b = 0;
+            if (threadIdx.x == 0) b = atomicAdd(ms.next, 1);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= dc.B) break;
+            ms_step_body<true>(w, dc, m, io, ms, b, mpcqp_smem, scratch);
+            w.sync();
+        }
+        return;
+    }
+#endif
     for (;;) {
         int b = 0;
         if (threadIdx.x == 0) b = atomicAdd(ms.next, 1);

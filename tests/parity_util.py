@@ -242,9 +242,11 @@ def run_custom_constraint_cases(lib=None, B=2, Hp=50, which=(0, 1, 2, 3)):
     return worst
 
 
-def run_soft_custom_constraints(lib=None, B=2, seed=4, kinds=None):
+def run_soft_custom_constraints(lib=None, B=2, seed=4, kinds=None, Hp=8, Hc=(1, 2, 2), terminal=False, periods=3):
     """Two soft custom rows mixing outputs, inputs, a measured disturbance and the set point, on top
-    of ordinary u / y constraints, against the oracle (exercises the ϵ row of the custom block)."""
+    of ordinary u / y constraints, against the oracle (exercises the ϵ row of the custom block).
+    Hp, Hc: the horizons (round 6: Hp = Hc = 60, nZ̃ = 121 puts the handle on a team of wavefronts, whose helpers take the
+    custom-row and terminal-row parts of the Newton matrix); terminal: a soft bound on one terminal state on top."""
     from oracle import estim as es
     rng = np.random.default_rng(seed)
     A = np.diag([0.85, 0.6, 0.3]); Bu = rng.standard_normal((3, 2)); C = rng.standard_normal((2, 3))
@@ -253,18 +255,21 @@ def run_soft_custom_constraints(lib=None, B=2, seed=4, kinds=None):
     kf = es.SteadyKalmanFilterOracle(model)
     Wy, Wu = rng.standard_normal((2, 2)), rng.standard_normal((2, 2))
     Wd, Wr = rng.standard_normal((2, 1)), 0.3 * rng.standard_normal((2, 2))
-    kw = dict(Hp=8, Hc=[1, 2, 2], Lwt=[0.05, 0.02], uop=model.uop, yop=model.yop, dop=model.dop,
+    kw = dict(Hp=Hp, Hc=list(Hc) if not np.isscalar(Hc) else int(Hc), Lwt=[0.05, 0.02], uop=model.uop, yop=model.yop, dop=model.dop,
               xhop=kf.xhop, fhop=kf.fhop, Wy=Wy, Wu=Wu, Wd=Wd, Wr=Wr)
     rep = lambda a: np.broadcast_to(a, (B,) + a.shape).copy()
     orc = cd.LinMPCOracle(kf.Ah, kf.Bhu, kf.Ch, kf.Bhd, kf.Dhd, **kw)
     gpu = mpcqp.BatchLinMPC(rep(kf.Ah), rep(kf.Bhu), rep(kf.Ch), rep(kf.Bhd), rep(kf.Dhd), lib=lib, **kw)
     con = dict(umin=[-0.6, -1.0], umax=[1.4, 0.9], ymax=[2.6, 1.8], wmin=[0.2, -np.inf], wmax=[1.5, 0.9],
                c_wmin=[0.7, 1.0], c_wmax=[1.3, 0.4])
-    orc.setconstraint(**con); gpu.setconstraint(**con)
+    if terminal:
+        xm = np.full(kf.nxh, np.inf); xm[0] = 0.4
+        con["xhatmax"] = kf.xhop + xm
+    orc.setconstraint(**con); gpu.setconstraint(**{("x̂max" if k == "xhatmax" else k): v for k, v in con.items()})
     x0 = 0.3 * rng.standard_normal(kf.nxh)
     gpu.initstate([0.6, 0.0]); orc.lastu0 = np.array([0.6, 0.0]) - model.uop
     worst = 0.0
-    for k in range(3):
+    for k in range(periods):
         ry, d = [2.5 + 0.2 * k, 0.4], [0.5 - 0.1 * k]
         ug = gpu.moveinput(np.tile(x0, (B, 1)), ry, d, want_info=True)
         uo = orc.moveinput(x0, ry, d)

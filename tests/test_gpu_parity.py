@@ -606,6 +606,17 @@ def test_custom_linear_constraints_on_gpu(hiplib):
     assert run_custom_constraint_cases(B=5) <= TOL
 
 
+def test_team_kernel_with_custom_rows_and_terminal_bound(hiplib):
+    """Round 6: beyond one row per lane the on-demand kernels run a TEAM of wavefronts per controller (k_step_team); the
+    helpers also take the custom-row, terminal-row and input-row parts of the Newton matrix.  nZ̃ = 121 (nu = 2, Hp = Hc = 60)
+    with two soft custom rows per step, a soft terminal bound, u / y bounds and a measured disturbance, against the oracle."""
+    from tests.parity_util import run_soft_custom_constraints
+    kinds = []
+    e = run_soft_custom_constraints(B=5, kinds=kinds, Hp=60, Hc=60, terminal=True, periods=2)
+    assert kinds == [mpcqp.api.KERNEL_ONDEMAND], kinds
+    assert e <= 1e-6, e
+
+
 def test_dual_warm_start_closed_loop_on_gpu(hiplib):
     """MPCQP_FLAG_WARM_DUAL in a noisy closed loop (C3, 512 controllers, 5 periods): the same optimum
     as the plain start at every period, in fewer iterations from the second period on."""
