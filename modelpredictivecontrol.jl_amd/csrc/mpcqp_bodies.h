@@ -162,6 +162,9 @@
 // the matrix-core shares (E'DE passes, panel updates): the helpers split them among themselves.  Measured at nZ~ = 151, four
 // wavefronts, 4096 controllers (profiles/r6h, after the spill of the substitution's relane site was repaired): 31.3 ms with
 // wavefront 0 in, 31.8 ms without
+#ifndef MPCQP_TEAM_DIAG
+#define MPCQP_TEAM_DIAG 1       // teams of three or more: diagonal block of a panel in its DPP row (Step::chol_big_panel_diag)
+#endif
 #ifndef MPCQP_TEAM_MAIN_MFMA
 #define MPCQP_TEAM_MAIN_MFMA 1
 #endif
@@ -3161,10 +3164,11 @@ struct Step {
         if constexpr (KC == 16) {                      // (a shorter last panel has no rows below it)
             const double* dinv = sm + c.dinv;
             auto lk = [&](int r, int cc) { return Phi[pk(K0 + r, 0) + K0 + cc]; };      // L[K0 + r][K0 + cc], wave-uniform
-            // (the pivot slot's rows below the diagonal block are rows like any other: chol_big_panel_diag)
+            // (diagonal-block form: the pivot slot's rows below the block are rows like any other, chol_big_panel_diag)
+            constexpr int s0 = (MPCQP_TEAM_DIAG && W::NTEAM >= 3) ? so : so + 1;
             MPCQP_UNROLL
-            for (int s_ = so; s_ < NS; ++s_) {
-                if ((s_ - so + 1) % W::NTEAM != W::WV) continue;         // (slot so to wavefront 1, ..: wavefront 0 last)
+            for (int s_ = s0; s_ < NS; ++s_) {
+                if ((s_ - s0 + 1) % W::NTEAM != W::WV) continue;         // (first slot to wavefront 1, ..: wavefront 0 last)
                 const int i = w.lane + WAVE * s_;
                 const bool mine = i < n && i >= K0 + 16;
                 double* row = Phi + pk(mine ? i : 0, 0) + K0;
@@ -3250,9 +3254,14 @@ struct Step {
     __device__ __forceinline__ void chol_big_panel_reg(const double (&thr)[NS], bool& broke) {
         if constexpr (W::NTEAM > 1) {
             constexpr int so_ = (16 * P) / WAVE;
+            // three or more wavefronts: the diagonal block alone on wavefront 0, every other row through the team's triangular
+            // solves; two: the whole pivot slot on wavefront 0, the slots below on the team (measured, profiles/r6j: nZ~ = 151,
+            // four wavefronts 31.3 -> 29.7 ms per 4096 with the diagonal-block form; nZ~ = 106, two wavefronts 19.3 -> 20.0 ms)
+            constexpr bool DIAG = MPCQP_TEAM_DIAG && W::NTEAM >= 3;
             if constexpr (DM::nZ - 16 * P >= 16) {
-                chol_big_panel_diag<P, NS>(thr, broke);                 // (ends with a wave fence: its stores are issued)
-                if constexpr (DM::nZ - 16 * P > 16 && !(MPCQP_ABLATE & 1024)) {
+                if constexpr (DIAG) chol_big_panel_diag<P, NS>(thr, broke);                 // (ends with a wave fence: its stores are issued)
+                else chol_big_panel_slots<P, NS, (so_ + 1 < NS ? so_ + 1 : NS)>(thr, broke);
+                if constexpr ((DIAG ? DM::nZ - 16 * P > 16 : so_ + 1 < NS) && !(MPCQP_ABLATE & 1024)) {
                     w.post(TJ_PANELROWS, P);
                     chol_big_panel_rows<P, NS>();
                     w.join();

@@ -22,8 +22,8 @@ KERNELS = [
     (r"k_step_s<.*StaticDims<4, 4, 16, 30, 10", "k_step_s_C3", "QP solves (C3, B = 65536)", 65536, step_algorithmic_bytes(12, 4, 4, 30, 10)),
     (r"k_step_(s|team)<.*StaticDims<3, 3, 15, 40, 35", "k_step_s_nZ106", "QP solves (nu = ny = 3, Hp = 40, Hc = 35, B = 8192)", 8192, step_algorithmic_bytes(12, 3, 3, 40, 35)),
     (r"k_step_(s|team)<.*StaticDims<3, 3, 15, 50, 50", "k_step_s_nZ151", "QP solves (nu = ny = 3, Hp = Hc = 50, B = 4096)", 4096, step_algorithmic_bytes(12, 3, 3, 50, 50)),
-    (r"k_step_small_w1<12", "k_step_small_w1_12", "QP solves (C2, B = 1024)", 1024, step_algorithmic_bytes(4, 2, 2, 20, 5, 0)),
-    (r"k_step_small<12", "k_step_small_12", "QP solves (C2, B = 65536)", 65536, step_algorithmic_bytes(4, 2, 2, 20, 5, 0)),
+    (r"k_step_small_w1<12", "k_step_small_w1_12", "QP solves (C2, B = 1024)", 1024, step_algorithmic_bytes(4, 2, 2, 20, 5)),
+    (r"k_step_small<12", "k_step_small_12", "QP solves (C2, B = 65536)", 65536, step_algorithmic_bytes(4, 2, 2, 20, 5)),
     (r"k_step_small_y<12", "k_step_small_y_12", "QP solves (C2 dims, soft ymax + hard u, B = 65536)", 65536, step_algorithmic_bytes(4, 2, 2, 20, 5)),
     (r"k_ms_step_g", "k_ms_step_g", "QP solves (MultipleShooting, Hp = Hc = 50, B = 8192)", 8192, step_algorithmic_bytes(6, 2, 2, 50, 50)),
     (r"k_mhe_step<12, 1u>", "k_mhe_step_12_hard", "estimator periods (C5, B = 65536)", 65536, None),
