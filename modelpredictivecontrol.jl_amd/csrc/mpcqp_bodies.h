@@ -4016,6 +4016,11 @@ struct Step {
 template <class W, class DM>
 MPCQP_HD void step_body(W& w, const DM& d, const Model& m, const StepIO& io, int b, double* sm) {
     MPCQP_SETPRIO(4, 1);
+#ifdef MPCQP_TEAM_PINGTEST      // (measurement only: the cost of a job hand-off -- that many empty jobs in front of the step)
+    if constexpr (W::NTEAM > 1) {
+        for (int i_ = 0; i_ < MPCQP_TEAM_PINGTEST; ++i_) { w.post(99); w.join(); }
+    }
+#endif
     const long long t_in_ = Step<W, DM>::clock64_();
     Qp<W, DM> qp(w, d, m, b, sm);
     qp.load_tables();
