@@ -140,6 +140,12 @@
 #endif
 // chunks of four columns per unrolled pass of the several-rows-per-lane substitutions (solve_big_static): the factor entries
 // of a pass are requested together, so one LDS round trip is paid per pass (profiles/r6c: 86 cycles per column at 2)
+#ifndef MPCQP_SOLVEBIG_DPP
+#define MPCQP_SOLVEBIG_DPP 0       // several rows per lane: 1 = substitutions blocked by DPP rows (Step::solve_big_dpp), 0 = column at a time.
+                                   // Measured (profiles/r6u): nZ~ = 106 / 8192 19.30 -> 19.29 ms, nZ~ = 151 / 4096 29.74 -> 29.74 ms, same
+                                   // optima to 1e-10 -- no gain (the loads, the scaling by 1/L_ii and the ds_bpermute of a tile cost what the
+                                   // v_readlane chain did), so the simpler form stays the default
+#endif
 #ifndef MPCQP_SOLVEBIG_UNROLL
 #if defined(MPCQP_STEP_WAVES) && MPCQP_STEP_WAVES == 1
 #define MPCQP_SOLVEBIG_UNROLL 8
@@ -3437,11 +3443,133 @@ struct Step {
         w.sync();
     }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Round 6: the same substitutions blocked by the 16-lane DPP rows, like solve_static's (one row per lane): unknown
+    // i = lane + 64 s sits in DPP row (lane >> 4) of slot s, i.e. tile (s, T) of 16 unknowns is one DPP row of register r[s].
+    // Inside a tile the substitution is a chain of v_fmac_f64_dpp row_newbcast (the broadcast is the multiply-add's own
+    // modifier: one instruction and two wait states per unknown); the finished tile is copied to every row (one ds_bpermute
+    // pair) and all unknowns still to come take their 16-column update from the copy, again with the row broadcast in the
+    // multiply-add.  The column-at-a-time form above pays two v_readlane, their scalar-operand hazards and a multiply-add on
+    // the dependent chain of EVERY unknown: 80 cycles per unknown and sweep measured at nZ~ = 151 (profiles/r6i).
+    template <int NS, int SO, int T>
+    __device__ __forceinline__ void sbd_fwd(double (&r)[NS], const double (&ndi)[NS], const int (&rowo)[NS], const bool (&act)[NS]) {
+        constexpr int n = DM::nZ, K0 = WAVE * SO + 16 * T;
+        if constexpr (K0 < n) {
+            constexpr int KT = (n - K0 < 16) ? n - K0 : 16, NC = (KT + 3) / 4;
+            const double* zero4 = sm + c.zero;
+            double cf[NS][4][4];
+            MPCQP_UNROLL
+            for (int s_ = SO; s_ < NS; ++s_) {
+                const int i = w.lane + WAVE * s_;
+                MPCQP_UNROLL
+                for (int u = 0; u < NC; ++u) {
+                    load4((act[s_] && i >= K0 + 4 * u) ? Phi + rowo[s_] + K0 + 4 * u : zero4, cf[s_][u]);
+                    MPCQP_UNROLL
+                    for (int e = 0; e < 4; ++e) cf[s_][u][e] *= ndi[s_];
+                }
+            }
+            MPCQP_UNROLL
+            for (int u = 0; u < NC; ++u) chain_sw<1 << T, false>(u, r[SO], cf[SO][u]);
+            if constexpr (K0 + 16 < n) {
+                const double y = w.fetch(r[SO], 16 * T + (w.lane & 15));
+                if constexpr (T < 3 && WAVE * SO + 16 * (T + 1) < n) {
+                    double a0 = 0.0, a1 = 0.0;
+                    MPCQP_UNROLL
+                    for (int u = 0; u < NC; ++u) rows_sw<0xf & ~((2 << T) - 1)>(u, (u & 1) ? a1 : a0, y, cf[SO][u]);
+                    r[SO] += a0 + a1;
+                }
+                MPCQP_UNROLL
+                for (int s_ = SO + 1; s_ < NS; ++s_) {
+                    double a0 = 0.0, a1 = 0.0;
+                    MPCQP_UNROLL
+                    for (int u = 0; u < NC; ++u) rows_sw<0xf>(u, (u & 1) ? a1 : a0, y, cf[s_][u]);
+                    r[s_] += a0 + a1;
+                }
+            }
+            MPCQP_SCHED_FENCE();
+            if constexpr (T < 3) sbd_fwd<NS, SO, T + 1>(r, ndi, rowo, act);
+            else sbd_fwd<NS, SO + 1, 0>(r, ndi, rowo, act);
+        }
+    }
+    template <int NS, int SO, int T>
+    __device__ __forceinline__ void sbd_bwd(double (&r)[NS], const double (&ndi)[NS], const bool (&act)[NS]) {
+        constexpr int n = DM::nZ, K0 = WAVE * SO + 16 * T;
+        if constexpr (K0 < n) {
+            constexpr int KT = (n - K0 < 16) ? n - K0 : 16, NC = (KT + 3) / 4;
+            // column entries L[k0 + e][i] of the rows k0 .. k0 + 3 of a chunk (they share the stride k0 + 4; zeros on and right
+            // of the diagonal), for the lane's unknown of every slot up to SO; a lane whose unknown lies beyond the chunk's rows
+            // reads column 0 and scales it by zero
+            double cb[NS][4][4];
+            MPCQP_UNROLL
+            for (int s_ = 0; s_ <= SO; ++s_) {
+                const int i = w.lane + WAVE * s_;
+                MPCQP_UNROLL
+                for (int u = 0; u < NC; ++u) {
+                    const int k0 = K0 + 4 * u;
+                    const bool on = act[s_] && i < k0 + 4;
+                    const double sc = on ? ndi[s_] : 0.0;
+                    const double* p_ = Phi + pk(k0, 0) + (i < k0 + 4 ? i : 0);
+                    MPCQP_UNROLL
+                    for (int e = 0; e < 4; ++e) cb[s_][u][e] = (k0 + e < n) ? p_[e * (k0 + 4)] * sc : 0.0;
+                }
+            }
+            MPCQP_UNROLL
+            for (int u = NC - 1; u >= 0; --u) chain_sw<1 << T, true>(u, r[SO], cb[SO][u]);
+            if constexpr (K0 > 0) {
+                const double x = w.fetch(r[SO], 16 * T + (w.lane & 15));
+                if constexpr (T > 0) {
+                    double a0 = 0.0, a1 = 0.0;
+                    MPCQP_UNROLL
+                    for (int u = 0; u < NC; ++u) rows_sw<(1 << T) - 1>(u, (u & 1) ? a1 : a0, x, cb[SO][u]);
+                    r[SO] += a0 + a1;
+                }
+                MPCQP_UNROLL
+                for (int s_ = 0; s_ < SO; ++s_) {
+                    double a0 = 0.0, a1 = 0.0;
+                    MPCQP_UNROLL
+                    for (int u = 0; u < NC; ++u) rows_sw<0xf>(u, (u & 1) ? a1 : a0, x, cb[s_][u]);
+                    r[s_] += a0 + a1;
+                }
+            }
+            MPCQP_SCHED_FENCE();
+        }
+        if constexpr (T > 0) sbd_bwd<NS, SO, T - 1>(r, ndi, act);
+        else if constexpr (SO > 0) sbd_bwd<NS, SO - 1, 3>(r, ndi, act);
+    }
+    __device__ __forceinline__ void solve_big_dpp() {
+        constexpr int n = DM::nZ, NS = (n + WAVE - 1) / WAVE;
+        const double* dinv = sm + c.dinv;
+        double r[NS], di[NS], ndi[NS];
+        int rowo[NS];
+        bool act[NS];
+        MPCQP_UNROLL
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int i = w.lane + WAVE * s_;
+            act[s_] = i < n;
+            rowo[s_] = pk(act[s_] ? i : 0, 0);
+            di[s_] = act[s_] ? dinv[i] : 0.0;
+            ndi[s_] = -di[s_];
+            r[s_] = (act[s_] ? gt[i] : 0.0) * di[s_];            // L y = r in the variable scaled by 1/L_ii
+        }
+        sbd_fwd<NS, 0, 0>(r, ndi, rowo, act);
+        MPCQP_UNROLL
+        for (int s_ = 0; s_ < NS; ++s_) r[s_] *= di[s_];          // L'x = y
+        sbd_bwd<NS, NS - 1, 3>(r, ndi, act);
+        MPCQP_UNROLL
+        for (int s_ = 0; s_ < NS; ++s_)
+            if (act[s_]) dz[w.lane + WAVE * s_] = r[s_];
+        w.sync();
+    }
+#endif
     MPCQP_HD void solve_big() {
         MPCQP_TIC();
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (DM::is_static) {
+#if MPCQP_SOLVEBIG_DPP
+            solve_big_dpp();
+#else
             solve_big_static();
+#endif
             MPCQP_TOC(7);
             return;
         }
