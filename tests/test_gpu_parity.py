@@ -615,6 +615,12 @@ def test_team_kernel_with_custom_rows_and_terminal_bound(hiplib):
     e = run_soft_custom_constraints(B=5, kinds=kinds, Hp=60, Hc=60, terminal=True, periods=2)
     assert kinds == [mpcqp.api.KERNEL_ONDEMAND], kinds
     assert e <= 1e-6, e
+    # ... and with a move-blocking vector (60 intervals over Hp = 70: no zero blocks in front of the Sigma table, so the Toeplitz
+    # products take their general forms on wavefront 0 alone while the matrix-core passes are still split over the team)
+    kinds = []
+    e = run_soft_custom_constraints(B=3, kinds=kinds, Hp=70, Hc=[1] * 55 + [3] * 5, terminal=True, periods=2)
+    assert kinds == [mpcqp.api.KERNEL_ONDEMAND], kinds
+    assert e <= 1e-6, e
 
 
 def test_dual_warm_start_closed_loop_on_gpu(hiplib):
