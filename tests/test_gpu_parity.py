@@ -107,7 +107,11 @@ def test_slack_row_of_shapes_with_nDU_a_multiple_of_16(name, hiplib):
 
 @pytest.mark.parametrize("name,pattern", [("4,1,1,16,16", "c3"), ("6,2,3,32,31", "c3"), ("6,3,3,21,21", "all"), ("6,2,2,40,32", "yband"),
                                           ("8,4,4,24,20", "c3"), ("8,3,2,45,42", "all"), ("8,5,4,20,16", "box"),
-                                          ("12,3,3,50,50", "c3"), ("12,2,2,70,70", "all")])
+                                          ("12,3,3,50,50", "c3"), ("12,2,2,70,70", "all"),
+                                          # (round 6: the register-operand form of E'DE, MPCQP_ETDE_VREG, on every nu that divides 16 and
+                                          #  on ny = 8 -- the BASELINE shapes and the random families only have nu = ny = 4 of these)
+                                          ("6,2,4,20,12", "all"), ("8,8,4,10,8", "c3"), ("6,2,8,12,10", "all"), ("16,16,4,6,3", "c3"),
+                                          ("6,1,4,20,20", "c3")])
 def test_shapes_and_constraint_patterns_against_the_c_port(name, pattern, hiplib):
     """A few hundred instances per shape on its on-demand specialisation (nZ~ = 17 .. 127, around the one-row-per-lane
     limit, 16-multiples of nu*Hc, four constraint patterns; nZ~ = 151 and 141: beyond the 128 the specialisations stopped at
