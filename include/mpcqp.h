@@ -318,8 +318,14 @@ int mpcqp_kf_predict_device(mpcqp_handle h, double* xhat0, const double* u0, con
  *                      MPCQP_KERNEL_* kind of the shape (>= 0) or a negative error code.  The package ships a manifest
  *                      of shapes (spec_manifest.txt: `nu ny nxhat Hp Hc neps row_groups`) that its build and
  *                      `python -m mpcqp.prebuild [manifest]` turn into cached objects, so that a machine without
- *                      hipcc still runs a declared set of shapes on specialised kernels.
- *   mpcqp_last_build_error  text of the last failed build of this thread.
+ *                      hipcc still runs a declared set of shapes on specialised kernels.  A row_groups value with bit 0
+ *                      next to an output-bound group and without bit 1 (a manifest line written before kernel revision
+ *                      10, e.g. 0x8d) is still compiled, but mpcqp_last_build_error then says that only a controller
+ *                      with hard dUmin and no dUmax bounds matches the object (0x8d -> 0x8c).
+ *                      Beyond one row per lane (nZ~ > 64) the object holds a kernel that runs a team of two or four
+ *                      wavefronts per controller when the problem's LDS footprint leaves SIMDs idle (round 6: same
+ *                      results, same ABI; -DMPCQP_TEAM=1 in MPCQP_JIT_FLAGS keeps one wavefront per controller).
+ *   mpcqp_last_build_error  text of the last failed build of this thread (or the note above).
  * Environment: MPCQP_CACHE_DIR (default: <library dir>/spec_cache if writable, else
  * $XDG_CACHE_HOME/mpcqp or ~/.cache/mpcqp), HIPCC (compiler binary), MPCQP_JIT=0 (never specialise). */
 #define MPCQP_KERNEL_GENERIC   0
