@@ -1,6 +1,6 @@
 """Sweep of randomised controller families on the GPU against the certified oracle optimum
 (tests/parity_util.run_random_case): prints the relative ΔU error of every family.
-Usage: python scripts/family_sweep.py FIRST LAST [small|large|huge|huge2|any] [B] [MultipleShooting]
+Usage: python scripts/family_sweep.py FIRST LAST [small|large|huge|huge2|ny4|any] [B] [MultipleShooting]
 (huge: 64 < nZ~ <= 130, huge2: 130 < nZ~ <= 165 -- the team-of-wavefronts kernels of round 6; the kernel kind and nZ~ are printed)"""
 import sys, warnings
 sys.path.insert(0, '.')
@@ -13,7 +13,7 @@ if "DR" in os.environ:          # dual regularisation of the kernel (default: th
 
 kind = sys.argv[3] if len(sys.argv) > 3 else ""
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-kw = {kind: True} if kind in ("small", "large", "huge", "huge2") else {}
+kw = {kind: True} if kind in ("small", "large", "huge", "huge2", "ny4") else {}
 if len(sys.argv) > 5:
     kw["transcription"] = sys.argv[5]
 worst = 0.0

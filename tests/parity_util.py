@@ -307,7 +307,7 @@ def closed_loop_pair(cfg, bt, steps, lib=None, noise=0.02, seed=1, **kw):
 EXTRA_KW = None      # (experiments: extra BatchLinMPC keywords for run_random_case)
 
 
-def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, kinds=None, transcription="SingleShooting", huge2=False):
+def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, kinds=None, transcription="SingleShooting", huge2=False, ny4=False):
     """One randomly drawn controller family (dimensions, move blocking, which bounds exist, hard /
     soft mix, terminal bounds, measured disturbance, Cwt finite or Inf) as a batch of B DIFFERENT
     controllers of that family -- every member has its own model, weights, operating points, bound
@@ -321,6 +321,8 @@ def run_random_case(seed, lib=None, B=3, small=False, large=False, huge=False, k
     nx = int(rng.integers(2, 4 if small else 7)); nu = int(rng.integers(1, 3 if small else 5))
     ny = int(rng.integers(1, 3 if small else 4)); nd = int(rng.integers(0, 2))
     Hp = int(rng.integers(4, 9 if small else 24))
+    if ny4:                                 # four outputs, nu a divisor of 16: the shapes whose E'DE takes its operands from registers (round 6)
+        ny = 4; nu = int(rng.choice([1, 2, 4])); Hp = int(rng.integers(8, 31))
     if huge and not huge2:                  # beyond one row per lane: 64 < nZ~ <= ~130
         nu = int(rng.integers(2, 5)); Hp = int(rng.integers(32, 46))
         Hc = min(Hp, int(rng.integers(66, 130)) // nu)

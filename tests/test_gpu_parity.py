@@ -711,6 +711,18 @@ def test_families_beyond_two_rows_per_lane(seed, hiplib):
     assert_specialised(kinds)
 
 
+@pytest.mark.parametrize("seed", [5001, 5005, 5006, 5007, 5010, 5011])
+def test_random_families_with_four_outputs(seed, hiplib):
+    """Round 6: E'DE takes its matrix-core operands from registers when ny is a multiple of 4 and nu divides 16
+    (MPCQP_ETDE_VREG) -- shapes the other random families never draw (ny <= 3).  Families with ny = 4, nu in {1, 2, 4}, default move
+    blocking or a blocking vector (the latter keeps the operands-from-LDS form), every bound pattern, against the independent oracle."""
+    from tests.parity_util import run_random_case
+    kinds = []
+    e = run_random_case(seed, B=3, ny4=True, kinds=kinds)
+    assert e is not None and e <= TOL, e
+    assert_specialised(kinds)
+
+
 def test_hessian_is_recomputed_when_relaxed_bounds_make_the_problem_fit(hiplib):
     """ADVICE r5 (medium), see the emulator twin in tests/test_abi_and_host.py: stage-structured kernel first (does not fit),
     a condensed kernel after the bounds were reduced, whose packed H̃ (nΔU > 64: it is read) must exist by then."""
