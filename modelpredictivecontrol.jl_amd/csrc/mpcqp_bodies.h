@@ -168,6 +168,9 @@
 // the matrix-core shares (E'DE passes, panel updates): the helpers split them among themselves.  Measured at nZ~ = 151, four
 // wavefronts, 4096 controllers (profiles/r6h, after the spill of the substitution's relane site was repaired): 31.3 ms with
 // wavefront 0 in, 31.8 ms without
+#ifndef MPCQP_PANELROWS_RL
+#define MPCQP_PANELROWS_RL 0    // rows below a panel's diagonal block (chol_big_panel_rows): 1 = right-looking column steps (measured slower: 29.7 -> 30.4 ms at nZ~ = 151, 19.4 -> 19.5 ms at 106)
+#endif
 #ifndef MPCQP_TEAM_DIAG
 #define MPCQP_TEAM_DIAG 1       // teams of three or more: diagonal block of a panel in its DPP row (Step::chol_big_panel_diag)
 #endif
@@ -3181,6 +3184,26 @@ struct Step {
                 double x[16];
                 MPCQP_UNROLL
                 for (int u = 0; u < 4; ++u) load4(mine ? row + 4 * u : sm + c.zero, &x[4 * u]);
+#if MPCQP_PANELROWS_RL
+                // right-looking, one column per scheduling region: the 15 - cc updates of a column are independent
+                // multiply-adds (the compiler otherwise orders the work by target column: 120 multiply-adds in chains on one
+                // accumulator each); the block's next column is requested while the current one is applied
+                double lc[16], ln[16];
+                MPCQP_UNROLL
+                for (int c2 = 1; c2 < 16; ++c2) lc[c2] = lk(c2, 0);
+                MPCQP_UNROLL
+                for (int cc = 0; cc < 16; ++cc) {
+                    MPCQP_UNROLL
+                    for (int c2 = cc + 2; c2 < 16; ++c2) ln[c2] = lk(c2, cc + 1);
+                    const double dv = dinv[K0 + cc];
+                    x[cc] *= dv > 1e-32 ? dv : 0.0;                   // (a pivot below its threshold: zero column, as in the pivot slot)
+                    MPCQP_UNROLL
+                    for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] = fma(-x[cc], lc[c2], x[c2]);
+                    MPCQP_SCHED_FENCE();
+                    MPCQP_UNROLL
+                    for (int c2 = cc + 2; c2 < 16; ++c2) lc[c2] = ln[c2];
+                }
+#else
                 MPCQP_UNROLL
                 for (int cc = 0; cc < 16; ++cc) {
                     const double dv = dinv[K0 + cc];
@@ -3189,6 +3212,7 @@ struct Step {
                     for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] = fma(-x[cc], lk(c2, cc), x[c2]);
                     if (cc % 4 == 3) MPCQP_SCHED_FENCE();            // (bounds the broadcast reads in flight: registers)
                 }
+#endif
                 if (mine) {
                     MPCQP_UNROLL
                     for (int u = 0; u < 4; ++u) store4(row + 4 * u, &x[4 * u]);
