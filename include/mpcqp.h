@@ -138,7 +138,7 @@ int mpcqp_set_weights(mpcqp_handle h, const double* Mdiag, const double* Ndiag,
  * (1 block / dense weight matrices, 2 custom linear constraints, 4 stage data beyond 160 KB of LDS, 8 KEEP_QP / WARM_DUAL
  * flags); a step of an unsupported MultipleShooting handle returns MPCQP_ERR_UNSUPPORTED, and so do mpcqp_prepare and
  * mpcqp_kernel_kind for it (the Python mirror then keeps the SingleShooting kernels and says so).  The fused Kalman loop
- * (mpcqp_loop_device) runs on the condensed kernels only: MPCQP_ERR_UNSUPPORTED on a MultipleShooting handle.
+ * (mpcqp_loop_device) runs on the stage-structured kernel too (round 6; MPCQP_ERR_UNSUPPORTED before).
  *
  * Size: a SingleShooting handle with nZ̃ = nu Hc + nϵ > 256 has no condensed kernel (its Newton matrix does not fit the
  * LDS); it runs the same QP on the stage-structured kernel, whose cost is linear in the horizons -- the reference has no

@@ -636,7 +636,7 @@ static int step_device_impl(mpcqp_handle h, const double* xhat0, const double* l
     }
 #endif
     // (refusals first: nothing is recorded on the stream for a step that does not run)
-    if (uses_stage_kernel(h) && (ms_unsupported(h) || y0m || predict)) return MPCQP_ERR_UNSUPPORTED;
+    if (uses_stage_kernel(h) && ms_unsupported(h)) return MPCQP_ERR_UNSUPPORTED;      // (the fused Kalman loop runs on the stage-structured kernel too since round 6)
     HIPCHK(hipEventRecord(h->ev_s0, st));
     if (uses_stage_kernel(h)) {
         // the stage-structured kernel: model as equality constraints, Riccati recursion, H~ and E never formed

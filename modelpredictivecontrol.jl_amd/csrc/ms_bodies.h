@@ -263,6 +263,32 @@ struct MsStep {
         for (int i = w.lane; i < nx; i += WAVE) sm[c.x0 + i] = io.xhat0[(size_t)b * nx + i];
         for (int i = w.lane; i < nu; i += WAVE) sm[c.lu + i] = io.lastu0[(size_t)b * nu + i];
         w.sync();
+        if (io.kf_y0m) {
+            // fused control period (mpcqp_loop_device, round 6 on this kernel too): the SteadyKalmanFilter correction first
+            // (correct_estimate_obsv!, src/estimator/kalman.jl:284-295; same arithmetic order as kf_correct_lane and step_body)
+            double* xh = sm + c.x0;
+            const double* K = io.kf_K + (size_t)b * io.kf_nym * nx;
+            double acc[4];                                     // rows i = lane + 64 q (nx^ <= 256)
+            int nq = 0;
+            for (int i = w.lane; i < nx; i += WAVE, ++nq) {
+                double a_ = xh[i];
+                for (int mm = 0; mm < io.kf_nym; ++mm) {
+                    const int a = io.kf_iym[mm];
+                    double v = io.kf_y0m[(size_t)b * io.kf_nym + mm];
+                    for (int k = 0; k < nx; ++k) v -= gC[a + ny * k] * xh[k];
+                    for (int e = 0; e < nd; ++e) v -= m.Dd[(size_t)b * ny * nd + a + ny * e] * io.d0[(size_t)b * nd + e];
+                    a_ += K[i + nx * mm] * v;
+                }
+                acc[nq] = a_;
+            }
+            w.sync();
+            nq = 0;
+            for (int i = w.lane; i < nx; i += WAVE, ++nq) {
+                xh[i] = acc[nq];
+                if (!io.kf_predict) io.xhat0_out[(size_t)b * nx + i] = acc[nq];
+            }
+            w.sync();
+        }
         for (int j = w.lane; j < Hc; j += WAVE) ctrl[jlt[j]] = j;
         // g_t = B^d d0(k+t) + (f^op - x^op): d0(k) for t = 0, D^0 block t-1 after (transcription.jl:386-389)
         for (int i = w.lane; i < nXt; i += WAVE) {
@@ -1453,6 +1479,20 @@ MPCQP_HD void ms_step_body(W& w, const Dims& d, const Model& m, const StepIO& io
             double acc = st.bg[st.c.CX + r];
             for (int e = 0; e < d.nd; ++e) acc += m.Dd[(size_t)b * d.ny * d.nd + a + d.ny * e] * io.Dhat0[(size_t)b * d.nD + t * d.nd + e];
             io.Yhat0[(size_t)b * d.nY + r] = acc;
+        }
+    }
+    if (io.kf_predict) {
+        // updatestate! (predict_estimate_obsv!, kalman.jl:298-309) with the input just computed: x^0 <- A^ x^0 + B^u u0 + B^d d0 + (f^op - x^op)
+        const int nx = d.nxh, nu = d.nu, nd = d.nd;
+        const double* xh = sm + st.c.x0;
+        const double* A = m.Ahat + (size_t)b * nx * nx;
+        for (int i = w.lane; i < nx; i += WAVE) {
+            double acc = m.dop ? m.dop[(size_t)b * nx + i] : 0.0;
+            for (int k = 0; k < nx; ++k) acc += A[i + nx * k] * xh[k];
+            for (int cc = 0; cc < nu; ++cc)
+                acc += m.Bu[(size_t)b * nx * nu + i + nx * cc] * (DU[cc] + io.lastu0[(size_t)b * nu + cc]);
+            for (int e = 0; e < nd; ++e) acc += m.Bd[(size_t)b * nx * nd + i + nx * e] * io.d0[(size_t)b * nd + e];
+            io.xhat0_out[(size_t)b * nx + i] = acc;
         }
     }
     if (ms.Xhat)

@@ -63,7 +63,7 @@ def oracle_batch(cfg, bt):
             "q": np.array(Q), "H": np.array(H)}
 
 
-def fused_loop_vs_separate_steps(lib=None, B=3, periods=4, torch_device=None):
+def fused_loop_vs_separate_steps(lib=None, B=3, periods=4, torch_device=None, multiple_shooting=False):
     """mpcqp_loop_device (preparestate! + moveinput! + updatestate! in one launch) against the three
     separate entry points on the same resident data: returns max |difference| of x̂0, u0, Z̃ over the
     periods (the arithmetic is the same instruction for instruction: expected 0).  Arrays are torch
@@ -77,7 +77,11 @@ def fused_loop_vs_separate_steps(lib=None, B=3, periods=4, torch_device=None):
         # (FLAG_KEEP_QP: a step that keeps q̃ / F runs on the one-controller-per-wavefront kernel like the fused loop does; without
         #  it the separate step of this nZ̃ = 7 controller takes the small-problem kernel -- output-bound rows included since round
         #  4 -- whose arithmetic differs in the last bits)
-        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=1, flags=mpcqp.FLAG_RY_CONSTANT | mpcqp.FLAG_KEEP_QP, lib=lib)
+        # (multiple_shooting: the stage-structured kernel, which fuses the Kalman steps since round 6; it has no q̃ to keep)
+        hd = mpcqp.Handle(B, cfg.nxh, cfg.nu, cfg.ny, 0, cfg.Hp, cfg.Hc, neps=1,
+                          flags=mpcqp.FLAG_RY_CONSTANT | (0 if multiple_shooting else mpcqp.FLAG_KEEP_QP), lib=lib)
+        if multiple_shooting:
+            hd.set_transcription(mpcqp.api.MULTIPLE_SHOOTING)
         hd.set_model(mpcqp.colmajor(bt["Ahat"]), mpcqp.colmajor(bt["Bhu"]), mpcqp.colmajor(bt["Chat"]))
         hd.set_weights(np.full((B, hd.nY), cfg.Mwt), np.full((B, hd.nDU), cfg.Nwt), np.full((B, hd.nU), cfg.Lwt), np.full(B, cfg.Cwt))
         hd.set_bounds(U0min=np.full((B, hd.nU), cfg.umin), U0max=np.full((B, hd.nU), cfg.umax), Y0max=np.full((B, hd.nY), cfg.ymax))

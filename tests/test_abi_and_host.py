@@ -281,6 +281,8 @@ def test_fused_loop_equals_separate_steps_on_cpu_emulator(emulib):
     """mpcqp_loop_device: Kalman correction, moveinput! and Kalman prediction in one launch."""
     from tests.parity_util import fused_loop_vs_separate_steps
     assert fused_loop_vs_separate_steps(lib=emulib, B=2, periods=3) == 0.0
+    # round 6: the stage-structured (MultipleShooting) kernel fuses the Kalman steps as well (MPCQP_ERR_UNSUPPORTED before)
+    assert fused_loop_vs_separate_steps(lib=emulib, B=2, periods=3, multiple_shooting=True) == 0.0
 
 
 def _check_readme_example(worst, U, Y, Hp, nxh):

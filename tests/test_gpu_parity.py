@@ -289,6 +289,8 @@ def test_fused_loop_equals_separate_steps_on_gpu(hiplib):
     import torch
     from tests.parity_util import fused_loop_vs_separate_steps
     assert fused_loop_vs_separate_steps(B=64, periods=5, torch_device=torch.device("cuda", 0)) == 0.0
+    # round 6: also on the stage-structured (MultipleShooting) kernel
+    assert fused_loop_vs_separate_steps(B=64, periods=5, torch_device=torch.device("cuda", 0), multiple_shooting=True) == 0.0
 
 
 def test_config4_batch_on_one_gpu(hiplib):
